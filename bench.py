@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the BVH-traversal + path-tracing hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|c4]
+
+A "step" is one pass of the hot path over the whole workload: every rank renders its 64x64
+super-tiles (one HIP kernel launch) and the film is gathered on rank 0 (one RCCL gather for N>1).
+Default workload = BASELINE.json configs[3], the one the metric/target is quoted on: 1M random
+triangles, 2048x2048, 512 spp (32x16 strata), path integrator maxdepth 8; it fits one GPU, so N=1
+runs all of it and N>1 shards the same frame (strong scaling).  Scene build / upload and image
+writing are outside the timed region; inputs are resident in HBM when timing starts.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel = render_kernel, algorithmic bytes
+from the exact visit counters / HIP-event kernel time) and, at N=1, `cpu_baseline` (the CPU oracle
+timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured stream)
+
+WORKLOADS = {
+    # name: (scene factory args, integrator, maxdepth, (spp_x, spp_y), description)
+    "c3": (("mesh", 1_000_000, 2048), 0, 8, (32, 16), "C3: 1M random triangles in a box, 2048x2048, 512 spp, path maxdepth 8"),
+    "c2": (("mesh", 100_000, 1024), 0, 8, (16, 16), "C2: 100k random triangles in a box, 1024x1024, 256 spp, path maxdepth 8"),
+    "c1": (("sphere", 0, 1024), 1, 5, (8, 8), "C1: analytic sphere + point light, 1024x1024, 64 spp, direct lighting"),
+    "c4": (("cornell", 0, 4096), 0, 16, (64, 64), "C4: Cornell-style box, 4096x4096, 4096 spp, path maxdepth 16"),
+}
+
+
+def make_scene_data(kind, n, res, crop=(0.0, 1.0, 0.0, 1.0)):
+    from pbrt_amd import scenes
+    if kind == "mesh":
+        return scenes.random_mesh_scene(n, res, res, crop=crop)
+    if kind == "sphere":
+        return scenes.sphere_scene(res, res, crop=crop)
+    return scenes.cornell_scene(res, res, crop=crop)
+
+
+def algorithmic_bytes_per_sample(st, samples, spp):
+    """sum over rays of (32 B per node visited + 48 B per triangle tested)
+    + 28 B camera ray + 16/spp B film store, per camera sample."""
+    return (32.0 * st["nodes_visited"] + 48.0 * st["tris_tested"]) / samples + 28.0 + 16.0 / spp
+
+
+def cpu_baseline(kind, n, res, integrator, depth, spp):
+    """The CPU oracle ("port"), rebuilt -march=native on this box, all host cores, on a bounded
+    sample of the same workload: 5 of the frame's 64x64 super-tiles spread over the image
+    (super-tiles t = 0 mod 251) at reduced samples per pixel (throughput is spp-independent)."""
+    from oracle import binding as ob
+    ob.build(native=True)
+    sd = make_scene_data(kind, n, res)
+    sc = ob.OracleScene(sd, native=True)
+    cores = os.cpu_count() or 1
+    world = 251 if res >= 1024 else 1
+    sspp = (8, 8) if kind == "mesh" else spp
+    if kind == "cornell":
+        sspp = (16, 16)
+    film, st = sc.render(integrator=integrator, max_depth=depth, spp=sspp, seed=0, rank=0, world_size=world, n_threads=cores)
+    samples = int((film[..., 3] > 0).sum()) * sspp[0] * sspp[1]
+    rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+    return {
+        "value": samples / st["seconds"] / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": f"CPU oracle (ours; the reference has no renderer), {samples} samples: super-tiles t%{world}==0 of the "
+                  f"{res}x{res} frame at {sspp[0]}x{sspp[1]} spp, {st['seconds']:.1f} s",
+        "mrays_per_s": rays / st["seconds"] / 1e6,
+        "bytes_per_sample": algorithmic_bytes_per_sample(st, samples, sspp[0] * sspp[1]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, nargs=2, default=None, help="override strata (diagnostics; invalid as a headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true", help="skip the untimed counting pass (roofline.achieved = null)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import pbrt_amd
+    from pbrt_amd import dist as pdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available() or pbrt_amd.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: pbrt_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    (kind, n, res), integrator, depth, spp, descr = WORKLOADS[args.workload]
+    if args.spp:
+        spp = tuple(args.spp)
+    t0 = time.time()
+    sd = make_scene_data(kind, n, res)
+    scene = pbrt_amd.Scene(sd, device=local_rank)
+    info = scene.info()
+    build_s = time.time() - t0
+    kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        film, st = pdist.render_sharded(scene, rank, world, **kw)
+        return film, st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_start = time.perf_counter()
+    kernel_ms, local_samples = [], 0
+    film = None
+    for _ in range(args.steps):
+        film, st = step()
+        kernel_ms.append(st["kernel_ms"])
+        local_samples = st["samples"]
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_samples = res * res * spp[0] * spp[1]
+    value = total_samples * args.steps / elapsed / 1e6
+
+    # untimed counting pass: exact nodes-visited / triangles-tested of THIS rank's share (the
+    # counting instantiation of the same kernel; equal to the oracle's counters, tests/test_gpu_parity.py)
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    if not args.no_counters:
+        slab = torch.empty(max(scene.slab_floats(rank, world) // 4, 1), 4, device="cuda")
+        scene.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, rank=rank, world_size=world,
+                            counters=True, **kw)
+        cst = scene.render_wait()
+        bps = algorithmic_bytes_per_sample(cst, cst["samples"], spp[0] * spp[1])
+        alg_bytes = bps * local_samples  # per launch of this rank's kernel
+        ach = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        rays = cst["camera_rays"] + cst["bounce_rays"] + cst["shadow_rays"]
+        roof.update({
+            "achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel": "render_kernel", "kernel_ms": avg_kernel_ms,
+            "bytes_per_sample": bps, "algorithmic_bytes_per_launch": alg_bytes,
+            "rays_per_sample": rays / cst["samples"], "nodes_per_ray": cst["nodes_visited"] / rays,
+            "tris_per_ray": cst["tris_tested"] / rays, "mrays_per_s": rays / (avg_kernel_ms * 1e-3) / 1e6,
+            "frac_of_measured_stream_6290": ach / 6290.0,
+            "note": "algorithmic bytes (SURVEY 8d formula, exact counters) / HIP-event kernel time; the scene "
+                    f"({info['device_bytes'] / 1e6:.0f} MB) sits in the 256 MiB Infinity Cache, so physical HBM traffic is far lower",
+        })
+    else:
+        roof.update({"kernel": "render_kernel", "kernel_ms": avg_kernel_ms})
+
+    out = {
+        "metric": "Msamples/sec (rays/sec) at 1/2/4/8 GPUs; PSNR vs CPU reference",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": descr, "triangles": int(sd.idx.shape[0]), "resolution": [res, res], "spp": spp[0] * spp[1],
+                   "maxdepth": depth, "sharding": f"64x64 super-tiles round-robin over {world} rank(s), one gather",
+                   "bvh_nodes": info["n_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
+                   "scene_build_s": round(build_s, 2)},
+        "roofline": roof,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, n, res, integrator, depth, spp)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if film is not None:
+            import numpy as np
+            f = film.cpu().numpy()
+            out["film_check"] = {"weight_ok": bool((f[..., 3] == spp[0] * spp[1]).all()), "finite": bool(np.isfinite(f).all()),
+                                 "mean_Y": float(f[..., 1].mean() / (spp[0] * spp[1]))}
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+/*
+ * pbrt_hip.h -- C ABI of the MI355X render path ("what `PbrtAPI::world_end` calls").
+ *
+ * The reference (wathiede/pbrt, Rust) has no FFI layer and no renderer: the seam this
+ * library fills is the body of `fn world_end(&mut self)` (/root/reference/src/core/api.rs:432-473,
+ * whose render call survives only as the comment at :446-453), reached from the parser's
+ * "WorldEnd" arm (src/core/parser.rs:312).  Its inputs are the fields of `RenderOptions`
+ * (api.rs:201-224) -- camera_to_world (api.rs:813-820), film/sampler/integrator parameters --
+ * plus the geometry the reference never stores (api.rs:220-223 TODO).  INTEGRATION.md shows the
+ * `extern "C"` block and the `world_end` body a maintainer of the Rust crate would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; the caller owns every HOST pointer it passes, the library
+ *    copies what it needs during the call and keeps nothing;
+ *  - every function returns 0 on success or a negative pbrt_hip_status; the message is
+ *    available from pbrt_hip_last_error() (thread-local); no C++ exception crosses the ABI
+ *    (reference error style: api.rs:50-63 `Error`, api.rs:291-332 verify_* = log and continue);
+ *  - there is NO CPU fallback: without a HIP device every entry point that computes returns
+ *    PBRT_HIP_ERR_NO_DEVICE;
+ *  - a scene handle is used by one host thread at a time (api.rs is single-threaded).
+ */
+#ifndef PBRT_HIP_H
+#define PBRT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  PBRT_HIP_OK = 0,
+  PBRT_HIP_ERR_INVALID = -1,   /* bad argument */
+  PBRT_HIP_ERR_NO_DEVICE = -2, /* no HIP device / HIP runtime error at init */
+  PBRT_HIP_ERR_HIP = -3,       /* a HIP call failed */
+  PBRT_HIP_ERR_LIMIT = -4,     /* scene exceeds a compiled-in limit (BVH depth, material count) */
+  PBRT_HIP_ERR_INTERNAL = -5
+} pbrt_hip_status;
+
+/* Material "matte" / "mirror" (scene files name them: scenes/check-sphere.pbrt:21,29; the
+ * reference only has the TODO at api.rs:255-269).  32 bytes. */
+typedef struct {
+  uint32_t type; /* 0 = matte (Lambertian, k = Kd), 1 = mirror (perfect specular, k = Kr) */
+  float k[3];
+  float le[3]; /* emitted radiance; non-zero turns every triangle using it into an area light
+                  (replaces api.rs:476-478 area_light_source -> todo!()) */
+  float pad;
+} pbrt_hip_material;
+
+/* LightSource "point" / "distant" / "infinite" (api.rs:334-351 make_light: todo!() for all). */
+typedef struct {
+  uint32_t type; /* 0 point, 1 distant, 2 infinite with constant radiance */
+  float p[3];    /* point: position; distant: unit direction TOWARDS the light */
+  float c[3];    /* point: intensity I; distant / infinite: radiance L */
+  float pad;
+} pbrt_hip_light;
+
+/* Shape "sphere" (check-sphere.pbrt:22), world space. */
+typedef struct {
+  float c[3];
+  float r;
+  uint32_t mat;
+  uint32_t pad[3];
+} pbrt_hip_sphere;
+
+/* Everything RenderOptions would hold at WorldEnd (api.rs:201-224), as arrays. */
+typedef struct {
+  const float *P;         /* "point P": 3 * n_verts (parser.rs:821-839 shows the param shape) */
+  const uint32_t *idx;    /* "integer indices": 3 * n_tris */
+  const uint16_t *mat_id; /* n_tris, index into mats */
+  const pbrt_hip_material *mats;
+  const pbrt_hip_light *lights;
+  const pbrt_hip_sphere *spheres;
+  uint32_t n_verts, n_tris, n_mats, n_lights, n_spheres;
+  float cam_to_world[16]; /* RenderOptions.camera_to_world, row-major Matrix4x4 (transform.rs:75-77) */
+  float fov;              /* Camera "perspective" "float fov" (degrees, shorter axis) */
+  int32_t xres, yres;     /* Film "integer xresolution" / "yresolution" */
+  float crop[4];          /* Film "float cropwindow" x0 x1 y0 y1 (film.rs:92-101) */
+} pbrt_hip_scene_desc;
+
+#define PBRT_HIP_INTEGRATOR_PATH 0   /* Integrator "path" (default name, api.rs:239) */
+#define PBRT_HIP_INTEGRATOR_DIRECT 1 /* Integrator "directlighting" */
+#define PBRT_HIP_FLAG_COUNTERS 1u    /* also count nodes visited / triangles tested (slower) */
+
+typedef struct {
+  uint32_t integrator;
+  uint32_t max_depth;        /* Integrator "integer maxdepth" */
+  uint32_t spp_x, spp_y;     /* Sampler "stratified": pixelsamples = spp_x * spp_y */
+  uint64_t seed;
+  uint32_t rank, world_size; /* this process renders the 64x64 super-tiles t with t % world_size == rank */
+  uint32_t flags;
+  uint32_t pad;
+} pbrt_hip_render_desc;
+
+typedef struct {
+  uint64_t camera_rays, bounce_rays, shadow_rays; /* filled only with PBRT_HIP_FLAG_COUNTERS */
+  uint64_t nodes_visited, tris_tested;            /* " */
+  double kernel_ms;                               /* HIP-event time of the render kernel on its stream */
+  uint64_t samples;                               /* camera samples this call rendered */
+} pbrt_hip_stats;
+
+typedef struct pbrt_hip_scene pbrt_hip_scene;
+
+/* number of visible HIP devices (0 when there is none; never fails) */
+int pbrt_hip_device_count(void);
+const char *pbrt_hip_last_error(void);
+const char *pbrt_hip_version(void);
+
+/* ---- scene: flatten + BVH build on the host, upload to HBM.  device < 0: current device. ---- */
+int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_scene **out);
+void pbrt_hip_scene_destroy(pbrt_hip_scene *scene);
+/* BVH introspection (host copies; order maps leaf slot -> triangle id) */
+int pbrt_hip_scene_info(const pbrt_hip_scene *scene, uint32_t *n_nodes, uint32_t *depth, uint32_t *n_lights,
+                        uint64_t *device_bytes);
+int pbrt_hip_scene_export_bvh(const pbrt_hip_scene *scene, uint32_t *nodes /* 8 words each */, uint32_t *order);
+/* host-only variant for CPU-side tests of the builder: no device is touched */
+int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
+                            uint32_t *nodes /* 8*(2*n_tris) words cap */, uint32_t *order, uint32_t *n_nodes,
+                            uint32_t *depth);
+
+/* ---- the hot path ---- */
+/* Render this rank's super-tiles and return the assembled film in HOST memory:
+ * film_xyzw = (crop_w * crop_h * 4) floats, row-major over the cropped pixel bounds,
+ * {X, Y, Z, filter_weight_sum} per pixel = Film.pixels after merge_film_tile (film.rs:47-55,313-326).
+ * Pixels of super-tiles owned by other ranks are written as zeros. */
+int pbrt_hip_render(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, float *film_xyzw, pbrt_hip_stats *stats);
+/* Same, but asynchronous on `stream` (a hipStream_t, may be NULL) into a DEVICE slab of
+ * pbrt_hip_slab_floats() floats: this rank's super-tiles back to back, 64*64 float4 each.
+ * No synchronisation is done; stats->kernel_ms is filled by pbrt_hip_render_wait(). */
+int pbrt_hip_render_device(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, void *d_slab, void *stream);
+int pbrt_hip_render_wait(pbrt_hip_scene *scene, pbrt_hip_stats *stats);
+/* scatter one rank's slab (device) into a row-major film (device), both float4 per pixel */
+int pbrt_hip_film_assemble_device(const pbrt_hip_scene *scene, const void *d_slab, uint32_t rank, uint32_t world_size,
+                                  void *d_film_xyzw, void *stream);
+/* host-side geometry of the sharding (no device needed) */
+int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world_size);
+/* for every float4 slot of a rank's slab the row-major pixel index inside the cropped film, or -1 */
+int pbrt_hip_slab_pixel_index(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world_size,
+                              int64_t *out);
+
+/* Ray-batch entry points: the traversal kernels on their own (parity + roofline of the
+ * dominant loop).  Host SoA-of-xyz arrays, n rays.  prim = 0xffffffff on a miss. */
+int pbrt_hip_intersect(pbrt_hip_scene *scene, int64_t n, const float *o, const float *d, const float *tmax, float *t,
+                       uint32_t *prim, float *b1, float *b2, uint64_t *counters /* 2, may be NULL */);
+int pbrt_hip_occluded(pbrt_hip_scene *scene, int64_t n, const float *o, const float *d, const float *tmax,
+                      uint8_t *hit);
+
+/* ---- host pieces either side of the path that the reference does implement ---- */
+/* Film::new / get_sample_bounds / get_film_tile (film.rs:82-137,166-175,264-281); bounds are x0 y0 x1 y1 */
+void pbrt_hip_film_cropped_bounds(int32_t xres, int32_t yres, const float crop[4], int32_t out[4]);
+void pbrt_hip_film_sample_bounds(int32_t xres, int32_t yres, const float crop[4], float rx, float ry, int32_t out[4]);
+void pbrt_hip_film_tile_bounds(int32_t xres, int32_t yres, const float crop[4], float rx, float ry,
+                               const int32_t sample_bounds[4], int32_t out[4]);
+/* Film::write_image's pixel arithmetic (film.rs:340-372): xyzw -> linear RGB, 3 floats per pixel */
+void pbrt_hip_film_to_rgb(const float *film_xyzw, int64_t n_pixels, float scale, float *rgb);
+/* imageio::write_image (imageio.rs:235-283): ".png" (8-bit sRGB via to_byte, imageio.rs:66-68) or ".pfm" */
+int pbrt_hip_write_image(const char *name, const float *rgb, int32_t width, int32_t height);
+/* Transform::look_at (transform.rs:485-520): m = world->camera, m_inv = camera->world */
+void pbrt_hip_look_at(const float pos[3], const float look[3], const float up[3], float m[16], float m_inv[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,478 @@
+// oracle.cpp -- integrator, film and C API of the CPU ORACLE (test infrastructure only, see
+// pbrt_oracle.h).  The reference's render call is a comment (api.rs:446-453); the loop below is
+// the pbrt-v3 SamplerIntegrator::Render / PathIntegrator::Li structure that comment sketches,
+// with every arithmetic choice fixed in DESIGN.md section 3.
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+#include "oracle_scene.hpp"
+
+namespace orc {
+
+// -------- Sampler: stratified pixel position + independent later dimensions --------
+class StratifiedSampler {
+ public:
+  StratifiedSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s)
+      : nx_(nx), ny_(ny), seed_(seed), w_((uint64_t)s.xres), h_((uint64_t)s.yres) {
+    inv_nx_ = 1.0f / (float)nx;
+    inv_ny_ = 1.0f / (float)ny;
+  }
+  void StartPixel(int x, int y) {
+    rng_.set_sequence(seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x);
+    px_ = x; py_ = y; s_ = 0;
+  }
+  // film position of the current sample: stratum (s mod nx, s div nx), jittered
+  void GetCameraSample(float *fx, float *fy) {
+    const float one_minus_eps = 1.0f - std::numeric_limits<float>::epsilon();
+    uint32_t sx = s_ % nx_, sy = s_ / nx_;
+    float u1 = rng_.uniform_float();
+    float u2 = rng_.uniform_float();
+    float jx = ((float)sx + u1) * inv_nx_;
+    float jy = ((float)sy + u2) * inv_ny_;
+    if (jx > one_minus_eps) jx = one_minus_eps;
+    if (jy > one_minus_eps) jy = one_minus_eps;
+    *fx = (float)px_ + jx;
+    *fy = (float)py_ + jy;
+  }
+  float Get1D() { return rng_.uniform_float(); }
+  bool StartNextSample() { return ++s_ < nx_ * ny_; }
+  uint32_t SamplesPerPixel() const { return nx_ * ny_; }
+
+ private:
+  uint32_t nx_, ny_;
+  uint64_t seed_, w_, h_;
+  float inv_nx_, inv_ny_;
+  Rng rng_;
+  int px_ = 0, py_ = 0;
+  uint32_t s_ = 0;
+};
+
+// pbrt-v3 ConcentricSampleDisk with the fixed polynomials instead of libm sin/cos
+static inline void concentric_sample_disk(float u1, float u2, float *dx, float *dy) {
+  float ox = 2.0f * u1 - 1.0f;
+  float oy = 2.0f * u2 - 1.0f;
+  if (ox == 0.f && oy == 0.f) { *dx = 0.f; *dy = 0.f; return; }
+  if (std::fabs(ox) > std::fabs(oy)) {
+    float phi = kPiOver4 * (oy / ox);
+    *dx = ox * poly_cos(phi);
+    *dy = ox * poly_sin(phi);
+  } else {
+    float phi = kPiOver4 * (ox / oy);
+    *dx = oy * poly_sin(phi);
+    *dy = oy * poly_cos(phi);
+  }
+}
+
+// cosine-weighted direction about n (pbrt-v3 CosineSampleHemisphere + CoordinateSystem);
+// returns the local z (= cos theta); z == 0 means pdf == 0
+static inline float cosine_sample_about(Vec3 n, float u1, float u2, Vec3 *wi) {
+  float dx, dy;
+  concentric_sample_disk(u1, u2, &dx, &dy);
+  float zz = (1.0f - dx * dx) - dy * dy;
+  float z = std::sqrt(zz > 0.f ? zz : 0.f);
+  Vec3 v2;
+  if (std::fabs(n.x) > std::fabs(n.y)) {
+    float l = std::sqrt(n.x * n.x + n.z * n.z);
+    v2 = {-n.z / l, 0.f, n.x / l};
+  } else {
+    float l = std::sqrt(n.y * n.y + n.z * n.z);
+    v2 = {0.f, n.z / l, -n.y / l};
+  }
+  Vec3 v3_ = cross(n, v2);
+  *wi = (v2 * dx + v3_ * dy) + n * z;
+  return z;
+}
+
+struct RayStats {
+  uint64_t camera = 0, bounce = 0, shadow = 0;
+  Counters c;
+};
+
+// -------- Integrator --------
+class PathIntegrator {
+ public:
+  PathIntegrator(const Scene &s, uint32_t max_depth, bool direct_only)
+      : scene(s), max_depth_(max_depth), direct_only_(direct_only) {}
+
+  // PathIntegrator::Li.  `direct_only_` turns it into the direct-lighting
+  // integrator: first non-specular vertex gets its one-light estimate and the path ends.
+  Vec3 Li(Ray ray, StratifiedSampler &sampler, RayStats &st) const {
+    Vec3 L = {0, 0, 0}, beta = {1, 1, 1};
+    bool specular = false;
+    const uint32_t nL = (uint32_t)scene.lights.size();
+    const float nLf = (float)nL;
+    for (uint32_t bounces = 0;; bounces++) {
+      // a ray at the depth limit can only collect emission, and only after a specular bounce
+      if (bounces > 0 && bounces >= max_depth_ && !specular) break;
+      if (bounces == 0) st.camera++; else st.bounce++;
+      Hit h = scene.Intersect(ray, &st.c);
+      bool hit = h.prim != 0xffffffffu;
+      Vec3 p{}, ng{};
+      const orc_material *m = nullptr;
+      Vec3 wo = -ray.d;
+      if (hit) {
+        if (h.prim < scene.n_tris()) {
+          Vec3 p0, p1, p2;
+          scene.tri_verts(h.prim, &p0, &p1, &p2);
+          ng = normalize(cross(p1 - p0, p2 - p0));
+          float w = (1.0f - h.b1) - h.b2;
+          p = (p0 * w + p1 * h.b1) + p2 * h.b2;
+          m = &scene.mats[scene.mat_id[h.prim]];
+        } else {
+          const orc_sphere &sp = scene.spheres[h.prim - scene.n_tris()];
+          Vec3 c = v3(sp.c[0], sp.c[1], sp.c[2]);
+          Vec3 ph = (ray.o - c) + ray.d * h.t;
+          ng = ph / sp.r;
+          p = c + ph;
+          m = &scene.mats[sp.mat];
+        }
+      }
+      if (bounces == 0 || specular) {
+        if (hit) {
+          Vec3 le = v3(m->le[0], m->le[1], m->le[2]);
+          if ((le.x > 0.f || le.y > 0.f || le.z > 0.f) && dot(ng, wo) > 0.f) L = L + beta * le;
+        } else if (scene.has_infinite) {
+          L = L + beta * scene.le_infinite;
+        }
+      }
+      if (!hit || bounces >= max_depth_) break;
+      Vec3 nf = dot(ng, wo) < 0.f ? -ng : ng;
+      Vec3 po = p + nf * kSpawnEps;
+      Vec3 k = v3(m->k[0], m->k[1], m->k[2]);
+      Vec3 wi;
+      if (m->type == 0) {  // matte
+        if (nL > 0) {
+          float xi = sampler.Get1D();
+          float u1 = sampler.Get1D();
+          float u2 = sampler.Get1D();
+          uint32_t li = (uint32_t)(xi * nLf);
+          if (li > nL - 1) li = nL - 1;
+          Vec3 Ld;
+          Ray sh;
+          if (sample_light(scene.lights[li], po, nf, k, u1, u2, nLf, &Ld, &sh)) {
+            st.shadow++;
+            if (!scene.IntersectP(sh, &st.c)) L = L + beta * Ld;
+          }
+        }
+        if (direct_only_) break;
+        float u1 = sampler.Get1D();
+        float u2 = sampler.Get1D();
+        float z = cosine_sample_about(nf, u1, u2, &wi);
+        if (z == 0.f) break;
+        beta = beta * k;
+        specular = false;
+      } else {  // mirror
+        float c = dot(wo, nf);
+        wi = -wo + nf * (2.0f * c);
+        beta = beta * k;
+        specular = true;
+      }
+      if (beta.x == 0.f && beta.y == 0.f && beta.z == 0.f) break;
+      ray.o = po;
+      ray.d = wi;
+      ray.tmax = kInf;
+      if (bounces > 3) {
+        float mx = fmax2(beta.x, fmax2(beta.y, beta.z));
+        float q = fmax2(0.05f, 1.0f - mx);
+        if (sampler.Get1D() < q) break;
+        beta = beta / (1.0f - q);
+      }
+    }
+    return L;
+  }
+
+  // UniformSampleOneLight's per-light part.  Returns false when geometry rules the
+  // light out (no shadow ray is cast then).
+  static bool sample_light(const LightRec &l, Vec3 po, Vec3 nf, Vec3 kd, float u1, float u2, float nLf,
+                           Vec3 *Ld, Ray *sh) {
+    Vec3 f = kd * kInvPi;
+    sh->o = po;
+    if (l.type == 0) {  // point
+      Vec3 dv = l.p0 - po;
+      float dist2 = dot(dv, dv);
+      if (!(dist2 > 0.f)) return false;
+      float dist = std::sqrt(dist2);
+      Vec3 wi = dv / dist;
+      float cs = dot(wi, nf);
+      if (!(cs > 0.f)) return false;
+      float scale = (cs / dist2) * nLf;
+      *Ld = (f * l.c) * scale;
+      sh->d = wi;
+      sh->tmax = dist * kShadowShrink;
+      return true;
+    } else if (l.type == 1) {  // distant
+      Vec3 wi = l.p0;
+      float cs = dot(wi, nf);
+      if (!(cs > 0.f)) return false;
+      float scale = cs * nLf;
+      *Ld = (f * l.c) * scale;
+      sh->d = wi;
+      sh->tmax = kInf;
+      return true;
+    } else if (l.type == 2) {  // constant infinite: cosine sampled, f*cos/pdf = Kd
+      Vec3 wi;
+      float z = cosine_sample_about(nf, u1, u2, &wi);
+      if (z == 0.f) return false;
+      *Ld = (kd * l.c) * nLf;
+      sh->d = wi;
+      sh->tmax = kInf;
+      return true;
+    } else {  // emissive triangle, uniform area sampling (pbrt-v3 UniformSampleTriangle)
+      float su0 = std::sqrt(u1);
+      float b0 = 1.0f - su0;
+      float b1 = u2 * su0;
+      float b2 = (1.0f - b0) - b1;
+      Vec3 pl = (l.p0 * b0 + l.p1 * b1) + l.p2 * b2;
+      Vec3 dv = pl - po;
+      float dist2 = dot(dv, dv);
+      if (!(dist2 > 0.f)) return false;
+      float dist = std::sqrt(dist2);
+      Vec3 wi = dv / dist;
+      float cs = dot(wi, nf);
+      if (!(cs > 0.f)) return false;
+      float cl = -dot(wi, l.n);
+      if (!(cl > 0.f)) return false;
+      float scale = (((cs * cl) * l.area) / dist2) * nLf;
+      *Ld = (f * l.c) * scale;
+      sh->d = wi;
+      sh->tmax = dist * kShadowShrink;
+      return true;
+    }
+  }
+
+  const Scene &scene;
+
+ private:
+  uint32_t max_depth_;
+  bool direct_only_;
+};
+
+// pbrt-v3 SamplerIntegrator::Render's radiance sanitising before FilmTile::AddSample
+static inline Vec3 sanitize(Vec3 L) {
+  float y = (0.212671f * L.x + 0.715160f * L.y) + 0.072169f * L.z;
+  if (std::isnan(L.x) || std::isnan(L.y) || std::isnan(L.z) || y < -1e-5f || std::isinf(y)) return {0, 0, 0};
+  return L;
+}
+
+static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_render_desc &r, int x, int y,
+                         float out_xyzw[4], float *per_sample, RayStats &st) {
+  StratifiedSampler sampler(r.spp_x, r.spp_y, r.seed, s);
+  sampler.StartPixel(x, y);
+  Vec3 sum = {0, 0, 0};
+  float wsum = 0.f;
+  uint32_t i = 0;
+  do {
+    float fx, fy;
+    sampler.GetCameraSample(&fx, &fy);
+    Ray ray = s.camera_ray(fx, fy);
+    Vec3 L = sanitize(integ.Li(ray, sampler, st));
+    if (per_sample) { per_sample[3 * i] = L.x; per_sample[3 * i + 1] = L.y; per_sample[3 * i + 2] = L.z; }
+    sum = sum + L;     // FilmTile::AddSample with the box filter: weight 1, this pixel only
+    wsum = wsum + 1.0f;
+    i++;
+  } while (sampler.StartNextSample());
+  // Film::merge_film_tile (film.rs:313-326): xyz += to_xyz(contrib_sum); weight += filter_weight_sum
+  float rgb[3] = {sum.x, sum.y, sum.z}, xyz[3];
+  rgb_to_xyz(rgb, xyz);
+  out_xyzw[0] = xyz[0]; out_xyzw[1] = xyz[1]; out_xyzw[2] = xyz[2]; out_xyzw[3] = wsum;
+}
+
+}  // namespace orc
+
+using namespace orc;
+
+struct orc_scene {
+  Scene s;
+};
+
+extern "C" {
+
+void orc_rng_default_u32(uint32_t *out, int n) { Rng r; for (int i = 0; i < n; i++) out[i] = r.uniform_u32(); }
+void orc_rng_default_float(float *out, int n) { Rng r; for (int i = 0; i < n; i++) out[i] = r.uniform_float(); }
+void orc_rng_default_threshold(uint32_t b, uint32_t *out, int n) { Rng r; for (int i = 0; i < n; i++) out[i] = r.uniform_u32_threshold(b); }
+void orc_rng_seq_u32(uint64_t seq, uint32_t *out, int n) { Rng r(seq); for (int i = 0; i < n; i++) out[i] = r.uniform_u32(); }
+void orc_rng_seq_float(uint64_t seq, float *out, int n) { Rng r(seq); for (int i = 0; i < n; i++) out[i] = r.uniform_float(); }
+
+void orc_film_cropped_bounds(int xres, int yres, const float crop[4], int32_t out[4]) { film_cropped_bounds(xres, yres, crop, out); }
+
+// Film::get_sample_bounds, film.rs:166-175
+void orc_film_sample_bounds(int xres, int yres, const float crop[4], float rx, float ry, int32_t out[4]) {
+  int32_t c[4];
+  film_cropped_bounds(xres, yres, crop, c);
+  out[0] = (int32_t)std::floor(((float)c[0] + 0.5f) - rx);
+  out[1] = (int32_t)std::floor(((float)c[1] + 0.5f) - ry);
+  out[2] = (int32_t)std::ceil(((float)c[2] - 0.5f) + rx);
+  out[3] = (int32_t)std::ceil(((float)c[3] - 0.5f) + ry);
+}
+
+// Film::get_film_tile, film.rs:264-281 (bounds are x0 y0 x1 y1)
+void orc_film_tile_bounds(int xres, int yres, const float crop[4], float rx, float ry, const int32_t sb[4], int32_t out[4]) {
+  int32_t c[4];
+  film_cropped_bounds(xres, yres, crop, c);
+  int32_t p0x = (int32_t)std::ceil(((float)sb[0] - 0.5f) - rx);
+  int32_t p0y = (int32_t)std::ceil(((float)sb[1] - 0.5f) - ry);
+  int32_t p1x = (int32_t)(std::floor(((float)sb[2] - 0.5f) + rx) + 1.f);
+  int32_t p1y = (int32_t)(std::floor(((float)sb[3] - 0.5f) + ry) + 1.f);
+  out[0] = std::max(p0x, c[0]); out[1] = std::max(p0y, c[1]);
+  out[2] = std::min(p1x, c[2]); out[3] = std::min(p1y, c[3]);
+}
+
+// Film::get_physical_extent, film.rs:218-227
+void orc_film_physical_extent(int xres, int yres, float diagonal_mm, float out[4]) {
+  float diag = diagonal_mm * 0.001f;
+  float aspect = (float)yres / (float)xres;
+  float x = std::sqrt(diag * diag / (1.f + aspect * aspect));
+  float y = aspect * x;
+  out[0] = -x / 2.f; out[1] = -y / 2.f; out[2] = x / 2.f; out[3] = y / 2.f;
+}
+
+void orc_rgb_to_xyz(const float rgb[3], float xyz[3]) { rgb_to_xyz(rgb, xyz); }
+void orc_xyz_to_rgb(const float xyz[3], float rgb[3]) { xyz_to_rgb(xyz, rgb); }
+
+// Film::write_image's per-pixel arithmetic, film.rs:346-372 (no splats: splat_xyz is always 0)
+void orc_film_write_rgb(const float *xyzw, int64_t n_px, float scale, float *rgb) {
+  for (int64_t i = 0; i < n_px; i++) {
+    float c[3];
+    xyz_to_rgb(xyzw + 4 * i, c);
+    float w = xyzw[4 * i + 3];
+    if (w != 0.f) {
+      float inv = 1.f / w;
+      for (int k = 0; k < 3; k++) { float v = c[k] * inv; c[k] = v > 0.f ? v : 0.f; }
+    }
+    for (int k = 0; k < 3; k++) rgb[3 * i + k] = c[k] * scale;
+  }
+}
+
+void orc_look_at(const float pos[3], const float look[3], const float up[3], float m[16], float m_inv[16]) {
+  Mat4 w2c, c2w;
+  look_at(v3(pos[0], pos[1], pos[2]), v3(look[0], look[1], look[2]), v3(up[0], up[1], up[2]), &w2c, &c2w);
+  memcpy(m, w2c.m, 64);
+  memcpy(m_inv, c2w.m, 64);
+}
+void orc_matrix_inverse(const float m[16], float out[16]) { Mat4 a; memcpy(a.m, m, 64); Mat4 r = inverse(a); memcpy(out, r.m, 64); }
+void orc_matrix_mul(const float a[16], const float b[16], float out[16]) { Mat4 x, y; memcpy(x.m, a, 64); memcpy(y.m, b, 64); Mat4 r = mul(x, y); memcpy(out, r.m, 64); }
+int orc_quadratic(float a, float b, float c, float *t0, float *t1) { return quadratic(a, b, c, t0, t1) ? 1 : 0; }
+float orc_gamma_correct(float v) { return gamma_correct(v); }
+uint8_t orc_to_byte(float v) { return to_byte(v); }
+
+orc_scene *orc_scene_create(const orc_scene_desc *d) {
+  orc_scene *h = new orc_scene();
+  Scene &s = h->s;
+  s.P.resize(d->n_verts);
+  for (uint32_t i = 0; i < d->n_verts; i++) s.P[i] = v3(d->P[3 * i], d->P[3 * i + 1], d->P[3 * i + 2]);
+  s.idx.assign(d->idx, d->idx + 3 * (size_t)d->n_tris);
+  s.mat_id.assign(d->mat_id, d->mat_id + d->n_tris);
+  s.mats.assign(d->mats, d->mats + d->n_mats);
+  if (d->n_spheres) s.spheres.assign(d->spheres, d->spheres + d->n_spheres);
+  // light list: explicit lights in order, then every emissive triangle in index order
+  for (uint32_t i = 0; i < d->n_lights; i++) {
+    LightRec l{};
+    l.type = d->lights[i].type;
+    l.p0 = v3(d->lights[i].p[0], d->lights[i].p[1], d->lights[i].p[2]);
+    l.c = v3(d->lights[i].c[0], d->lights[i].c[1], d->lights[i].c[2]);
+    s.lights.push_back(l);
+    if (l.type == 2) { s.le_infinite = s.le_infinite + l.c; s.has_infinite = true; }
+  }
+  for (uint32_t t = 0; t < d->n_tris; t++) {
+    const orc_material &m = s.mats[s.mat_id[t]];
+    if (m.le[0] > 0.f || m.le[1] > 0.f || m.le[2] > 0.f) {
+      LightRec l{};
+      l.type = 3;
+      s.tri_verts(t, &l.p0, &l.p1, &l.p2);
+      l.c = v3(m.le[0], m.le[1], m.le[2]);
+      Vec3 cr = cross(l.p1 - l.p0, l.p2 - l.p0);
+      float len = length(cr);
+      l.n = cr / len;
+      l.area = 0.5f * len;
+      s.lights.push_back(l);
+    }
+  }
+  setup_camera(s, d->cam_to_world, d->fov, d->xres, d->yres, d->crop);
+  s.build_bvh();
+  return h;
+}
+void orc_scene_destroy(orc_scene *s) { delete s; }
+uint32_t orc_bvh_node_count(const orc_scene *s) { return (uint32_t)s->s.nodes.size(); }
+uint32_t orc_bvh_depth(const orc_scene *s) { return s->s.depth; }
+void orc_bvh_export(const orc_scene *s, uint32_t *nodes, uint32_t *order) {
+  if (!s->s.nodes.empty()) memcpy(nodes, s->s.nodes.data(), s->s.nodes.size() * 32);
+  if (!s->s.order.empty()) memcpy(order, s->s.order.data(), s->s.order.size() * 4);
+}
+uint32_t orc_light_count(const orc_scene *s) { return (uint32_t)s->s.lights.size(); }
+
+void orc_intersect(const orc_scene *sc, int64_t n, const float *o, const float *d, const float *tmax, float *t,
+                   uint32_t *prim, float *b1, float *b2, uint64_t *counters, int brute_force) {
+  const Scene &s = sc->s;
+  Counters c;
+  for (int64_t i = 0; i < n; i++) {
+    Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]};
+    Hit h = brute_force ? s.IntersectBrute(r) : s.Intersect(r, &c);
+    t[i] = h.t; prim[i] = h.prim; b1[i] = h.b1; b2[i] = h.b2;
+  }
+  if (counters) { counters[0] = c.nodes; counters[1] = c.tris; }
+}
+void orc_occluded(const orc_scene *sc, int64_t n, const float *o, const float *d, const float *tmax, uint8_t *hit,
+                  int brute_force) {
+  const Scene &s = sc->s;
+  for (int64_t i = 0; i < n; i++) {
+    Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]};
+    hit[i] = (brute_force ? s.IntersectPBrute(r) : s.IntersectP(r, nullptr)) ? 1 : 0;
+  }
+}
+void orc_camera_ray(const orc_scene *sc, float fx, float fy, float o[3], float d[3]) {
+  Ray r = sc->s.camera_ray(fx, fy);
+  o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z;
+  d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
+}
+void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int y, float *out) {
+  PathIntegrator integ(sc->s, r->max_depth, r->integrator == 1);
+  RayStats st;
+  float px[4];
+  render_pixel(sc->s, integ, *r, x, y, px, out, st);
+}
+
+int orc_render(const orc_scene *sc, const orc_render_desc *r, float *film, orc_stats *out, int n_threads) {
+  const Scene &s = sc->s;
+  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size) return -1;
+  PathIntegrator integ(s, r->max_depth, r->integrator == 1);
+  const int x0 = s.cropped[0], y0 = s.cropped[1], x1 = s.cropped[2], y1 = s.cropped[3];
+  const int W = x1 - x0, H = y1 - y0;
+  if (W <= 0 || H <= 0) return 0;
+  // 16x16 work tiles inside the 64x64 super-tiles this rank owns
+  const int stx = (W + 63) / 64;
+  const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
+  std::atomic<int> next(0);
+  if (n_threads < 1) n_threads = 1;
+  std::vector<RayStats> stats(n_threads);
+  auto t_start = std::chrono::steady_clock::now();
+  auto worker = [&](int tid) {
+    RayStats &st = stats[tid];
+    for (;;) {
+      int tile = next.fetch_add(1);
+      if (tile >= ntx * nty) break;
+      int tx = tile % ntx, ty = tile / ntx;
+      int super = (ty / 4) * stx + (tx / 4);
+      if ((uint32_t)super % r->world_size != r->rank) continue;
+      for (int yy = ty * 16; yy < std::min(ty * 16 + 16, H); yy++)
+        for (int xx = tx * 16; xx < std::min(tx * 16 + 16, W); xx++)
+          render_pixel(s, integ, *r, x0 + xx, y0 + yy, film + 4 * ((size_t)yy * W + xx), nullptr, st);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 1; i < n_threads; i++) th.emplace_back(worker, i);
+  worker(0);
+  for (auto &t : th) t.join();
+  auto t_end = std::chrono::steady_clock::now();
+  if (out) {
+    *out = orc_stats{};
+    for (auto &st : stats) {
+      out->camera_rays += st.camera; out->bounce_rays += st.bounce; out->shadow_rays += st.shadow;
+      out->nodes_visited += st.c.nodes; out->tris_tested += st.c.tris;
+    }
+    out->seconds = std::chrono::duration<double>(t_end - t_start).count();
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""ctypes binding of include/pbrt_hip.h.  Loading fails loudly when the HIP library has not been
+built: there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("k", C.c_float * 3), ("le", C.c_float * 3), ("pad", C.c_float)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("p", C.c_float * 3), ("c", C.c_float * 3), ("pad", C.c_float)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("c", C.c_float * 3), ("r", C.c_float), ("mat", C.c_uint32), ("pad", C.c_uint32 * 3)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("P", C.POINTER(C.c_float)), ("idx", C.POINTER(C.c_uint32)), ("mat_id", C.POINTER(C.c_uint16)),
+        ("mats", C.POINTER(Material)), ("lights", C.POINTER(Light)), ("spheres", C.POINTER(Sphere)),
+        ("n_verts", C.c_uint32), ("n_tris", C.c_uint32), ("n_mats", C.c_uint32), ("n_lights", C.c_uint32),
+        ("n_spheres", C.c_uint32),
+        ("cam_to_world", C.c_float * 16), ("fov", C.c_float), ("xres", C.c_int32), ("yres", C.c_int32),
+        ("crop", C.c_float * 4),
+    ]
+
+
+class RenderDesc(C.Structure):
+    _fields_ = [
+        ("integrator", C.c_uint32), ("max_depth", C.c_uint32), ("spp_x", C.c_uint32), ("spp_y", C.c_uint32),
+        ("seed", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32), ("flags", C.c_uint32),
+        ("pad", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("camera_rays", C.c_uint64), ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+        ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("kernel_ms", C.c_double),
+        ("samples", C.c_uint64),
+    ]
+
+
+# every symbol include/pbrt_hip.h declares: (restype, argtypes)
+_f, _u32, _i32, _i64, _u64, _vp = C.c_float, C.c_uint32, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+_pf, _pu32, _pi32, _pi64, _pu64, _pu8 = (C.POINTER(t) for t in (_f, _u32, _i32, _i64, _u64, C.c_uint8))
+SYMBOLS = {
+    "pbrt_hip_device_count": (C.c_int, []),
+    "pbrt_hip_last_error": (C.c_char_p, []),
+    "pbrt_hip_version": (C.c_char_p, []),
+    "pbrt_hip_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(_vp)]),
+    "pbrt_hip_scene_destroy": (None, [_vp]),
+    "pbrt_hip_scene_info": (C.c_int, [_vp, _pu32, _pu32, _pu32, _pu64]),
+    "pbrt_hip_scene_export_bvh": (C.c_int, [_vp, _pu32, _pu32]),
+    "pbrt_hip_bvh_build_host": (C.c_int, [_pf, _u32, _pu32, _u32, _pu32, _pu32, _pu32, _pu32]),
+    "pbrt_hip_render": (C.c_int, [_vp, C.POINTER(RenderDesc), _pf, C.POINTER(Stats)]),
+    "pbrt_hip_render_device": (C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp]),
+    "pbrt_hip_render_wait": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "pbrt_hip_film_assemble_device": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "pbrt_hip_slab_floats": (_i64, [_i32, _i32, _pf, _u32, _u32]),
+    "pbrt_hip_slab_pixel_index": (C.c_int, [_i32, _i32, _pf, _u32, _u32, _pi64]),
+    "pbrt_hip_intersect": (C.c_int, [_vp, _i64, _pf, _pf, _pf, _pf, _pu32, _pf, _pf, _pu64]),
+    "pbrt_hip_occluded": (C.c_int, [_vp, _i64, _pf, _pf, _pf, _pu8]),
+    "pbrt_hip_film_cropped_bounds": (None, [_i32, _i32, _pf, _pi32]),
+    "pbrt_hip_film_sample_bounds": (None, [_i32, _i32, _pf, _f, _f, _pi32]),
+    "pbrt_hip_film_tile_bounds": (None, [_i32, _i32, _pf, _f, _f, _pi32, _pi32]),
+    "pbrt_hip_film_to_rgb": (None, [_pf, _i64, _f, _pf]),
+    "pbrt_hip_write_image": (C.c_int, [C.c_char_p, _pf, _i32, _i32]),
+    "pbrt_hip_look_at": (None, [_pf, _pf, _pf, _pf, _pf]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded libpbrt_hip.so; raises if it was not built (run `python -m pbrt_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with __graft_entry__.build() or `python pbrt_amd/build.py`. "
+                "pbrt_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class PbrtHipError(RuntimeError):
+    def __init__(self, code, where):
+        msg = lib().pbrt_hip_last_error().decode("utf-8", "replace")
+        super().__init__(f"{where} failed with status {code}: {msg}")
+        self.code = code
+
+
+def check(code, where):
+    if code != 0:
+        raise PbrtHipError(code, where)

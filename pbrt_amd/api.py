@@ -1,0 +1,272 @@
+"""Host-side mirror of the render call: what `PbrtAPI::world_end` (reference src/core/api.rs:432-473)
+would do with its RenderOptions (api.rs:201-224) -- build the scene on the device and render it.
+
+Everything that computes goes through the C ABI of include/pbrt_hip.h into the HIP kernels.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import Light, Material, RenderDesc, SceneDesc, Sphere, Stats, check, lib
+
+MATTE, MIRROR = 0, 1
+LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2
+INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
+FLAG_COUNTERS = 1
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+@dataclass
+class SceneData:
+    """Plain arrays describing a scene: RenderOptions + the geometry the reference never stores
+    (api.rs:220-223).  `materials` rows: (type, kr, kg, kb, ler, leg, leb); `lights` rows:
+    (type, px, py, pz, cr, cg, cb); `spheres` rows: (cx, cy, cz, r, material)."""
+    P: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.uint32))
+    mat_id: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.uint16))
+    materials: np.ndarray = field(default_factory=lambda: np.zeros((0, 7), np.float32))
+    lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 7), np.float32))
+    spheres: np.ndarray = field(default_factory=lambda: np.zeros((0, 5), np.float32))
+    cam_to_world: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    fov: float = 45.0
+    xres: int = 64
+    yres: int = 64
+    crop: tuple = (0.0, 1.0, 0.0, 1.0)
+
+    def normalized(self):
+        self.P = np.ascontiguousarray(self.P, np.float32).reshape(-1, 3)
+        self.idx = np.ascontiguousarray(self.idx, np.uint32).reshape(-1, 3)
+        self.mat_id = np.ascontiguousarray(self.mat_id, np.uint16).reshape(-1)
+        self.materials = np.ascontiguousarray(self.materials, np.float32).reshape(-1, 7)
+        self.lights = np.ascontiguousarray(self.lights, np.float32).reshape(-1, 7)
+        self.spheres = np.ascontiguousarray(self.spheres, np.float32).reshape(-1, 5)
+        self.cam_to_world = np.ascontiguousarray(self.cam_to_world, np.float32).reshape(4, 4)
+        assert self.idx.shape[0] == self.mat_id.shape[0]
+        return self
+
+    def crop_size(self):
+        b = film_cropped_bounds(self.xres, self.yres, self.crop)
+        return max(b[2] - b[0], 0), max(b[3] - b[1], 0)
+
+
+def fill_desc(desc, sd, mat_t, light_t, sphere_t):
+    """Fill a SceneDesc-shaped ctypes struct from a SceneData; returns the keep-alive list."""
+    sd.normalized()
+    mats = (mat_t * max(len(sd.materials), 1))()
+    for i, m in enumerate(sd.materials):
+        mats[i].type = int(m[0])
+        mats[i].k[:] = [float(x) for x in m[1:4]]
+        mats[i].le[:] = [float(x) for x in m[4:7]]
+    lights = (light_t * max(len(sd.lights), 1))()
+    for i, l in enumerate(sd.lights):
+        lights[i].type = int(l[0])
+        lights[i].p[:] = [float(x) for x in l[1:4]]
+        lights[i].c[:] = [float(x) for x in l[4:7]]
+    spheres = (sphere_t * max(len(sd.spheres), 1))()
+    for i, s in enumerate(sd.spheres):
+        spheres[i].c[:] = [float(x) for x in s[0:3]]
+        spheres[i].r = float(s[3])
+        spheres[i].mat = int(s[4])
+    desc.P = _fp(sd.P)
+    desc.idx = _u32p(sd.idx)
+    desc.mat_id = sd.mat_id.ctypes.data_as(C.POINTER(C.c_uint16))
+    desc.mats = mats
+    desc.lights = lights
+    desc.spheres = spheres
+    desc.n_verts = sd.P.shape[0]
+    desc.n_tris = sd.idx.shape[0]
+    desc.n_mats = len(sd.materials)
+    desc.n_lights = len(sd.lights)
+    desc.n_spheres = len(sd.spheres)
+    desc.cam_to_world[:] = [float(x) for x in sd.cam_to_world.reshape(-1)]
+    desc.fov = float(sd.fov)
+    desc.xres = int(sd.xres)
+    desc.yres = int(sd.yres)
+    desc.crop[:] = [float(x) for x in sd.crop]
+    return [mats, lights, spheres, sd]
+
+
+def make_render_desc(desc_t, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
+                     flags=0):
+    r = desc_t()
+    r.integrator = integrator
+    r.max_depth = max_depth
+    r.spp_x, r.spp_y = int(spp[0]), int(spp[1])
+    r.seed = seed
+    r.rank = rank
+    r.world_size = world_size
+    r.flags = flags
+    return r
+
+
+def device_count():
+    return lib().pbrt_hip_device_count()
+
+
+def look_at(pos, look, up):
+    """Transform::look_at (transform.rs:485-520) -> (world_to_camera, camera_to_world) 4x4 float32."""
+    m = np.zeros(16, np.float32)
+    mi = np.zeros(16, np.float32)
+    a = [np.asarray(v, np.float32) for v in (pos, look, up)]
+    lib().pbrt_hip_look_at(_fp(a[0]), _fp(a[1]), _fp(a[2]), _fp(m), _fp(mi))
+    return m.reshape(4, 4), mi.reshape(4, 4)
+
+
+def film_cropped_bounds(xres, yres, crop):
+    out = (C.c_int32 * 4)()
+    lib().pbrt_hip_film_cropped_bounds(xres, yres, (C.c_float * 4)(*crop), out)
+    return tuple(out)
+
+
+def film_sample_bounds(xres, yres, crop, radius):
+    out = (C.c_int32 * 4)()
+    lib().pbrt_hip_film_sample_bounds(xres, yres, (C.c_float * 4)(*crop), radius[0], radius[1], out)
+    return tuple(out)
+
+
+def film_tile_bounds(xres, yres, crop, radius, sample_bounds):
+    out = (C.c_int32 * 4)()
+    lib().pbrt_hip_film_tile_bounds(xres, yres, (C.c_float * 4)(*crop), radius[0], radius[1],
+                                    (C.c_int32 * 4)(*sample_bounds), out)
+    return tuple(out)
+
+
+def film_to_rgb(film_xyzw, scale=1.0):
+    """Film::write_image's pixel arithmetic (film.rs:340-372): (h, w, 4) XYZW -> (h, w, 3) linear RGB."""
+    f = np.ascontiguousarray(film_xyzw, np.float32)
+    rgb = np.zeros(f.shape[:-1] + (3,), np.float32)
+    lib().pbrt_hip_film_to_rgb(_fp(f), f.size // 4, scale, _fp(rgb))
+    return rgb
+
+
+def write_image(name, rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w = rgb.shape[:2]
+    check(lib().pbrt_hip_write_image(str(name).encode(), _fp(rgb), w, h), "pbrt_hip_write_image")
+
+
+def bvh_build_host(P, idx):
+    """The host BVH builder alone (no device): returns (nodes[n,8] uint32 view, order, depth)."""
+    P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    nt = idx.shape[0]
+    nodes = np.zeros((max(2 * nt, 1), 8), np.uint32)
+    order = np.zeros(max(nt, 1), np.uint32)
+    nn, depth = C.c_uint32(), C.c_uint32()
+    check(lib().pbrt_hip_bvh_build_host(_fp(P), P.shape[0], _u32p(idx), nt, _u32p(nodes), _u32p(order),
+                                        C.byref(nn), C.byref(depth)), "pbrt_hip_bvh_build_host")
+    return nodes[:nn.value].copy(), order[:nt].copy(), depth.value
+
+
+def slab_pixel_index(xres, yres, crop, rank, world_size):
+    n = lib().pbrt_hip_slab_floats(xres, yres, (C.c_float * 4)(*crop), rank, world_size)
+    if n < 0:
+        raise ValueError("bad sharding arguments")
+    out = np.zeros(n // 4, np.int64)
+    if n:
+        check(lib().pbrt_hip_slab_pixel_index(xres, yres, (C.c_float * 4)(*crop), rank, world_size,
+                                              out.ctypes.data_as(C.POINTER(C.c_int64))), "pbrt_hip_slab_pixel_index")
+    return out
+
+
+class Scene:
+    """A scene resident in HBM (flattened BVH + leaf-ordered triangles + tables)."""
+
+    def __init__(self, sd, device=-1):
+        self.sd = sd.normalized()
+        desc = SceneDesc()
+        keep = fill_desc(desc, self.sd, Material, Light, Sphere)
+        h = C.c_void_p()
+        check(lib().pbrt_hip_scene_create(C.byref(desc), device, C.byref(h)), "pbrt_hip_scene_create")
+        del keep
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pbrt_hip_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        nn, depth, nl, nb = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        check(lib().pbrt_hip_scene_info(self._h, C.byref(nn), C.byref(depth), C.byref(nl), C.byref(nb)),
+              "pbrt_hip_scene_info")
+        return {"n_nodes": nn.value, "depth": depth.value, "n_lights": nl.value, "device_bytes": nb.value}
+
+    def export_bvh(self):
+        i = self.info()
+        nodes = np.zeros((max(i["n_nodes"], 1), 8), np.uint32)
+        order = np.zeros(max(self.sd.idx.shape[0], 1), np.uint32)
+        check(lib().pbrt_hip_scene_export_bvh(self._h, _u32p(nodes), _u32p(order)), "pbrt_hip_scene_export_bvh")
+        return nodes[:i["n_nodes"]], order[:self.sd.idx.shape[0]]
+
+    def render(self, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
+               counters=False):
+        """-> (film[h, w, 4] float32 {X, Y, Z, weight}, stats dict)."""
+        r = make_render_desc(RenderDesc, integrator, max_depth, spp, seed, rank, world_size,
+                             FLAG_COUNTERS if counters else 0)
+        w, h = self.sd.crop_size()
+        film = np.zeros((h, w, 4), np.float32)
+        st = Stats()
+        check(lib().pbrt_hip_render(self._h, C.byref(r), _fp(film), C.byref(st)), "pbrt_hip_render")
+        return film, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def render_device(self, d_slab_ptr, stream_ptr=None, **kw):
+        """Asynchronous render into a device slab (e.g. a torch tensor's data_ptr())."""
+        counters = kw.pop("counters", False)
+        r = make_render_desc(RenderDesc, flags=FLAG_COUNTERS if counters else 0, **kw)
+        check(lib().pbrt_hip_render_device(self._h, C.byref(r), C.c_void_p(d_slab_ptr), C.c_void_p(stream_ptr or 0)),
+              "pbrt_hip_render_device")
+
+    def render_wait(self):
+        st = Stats()
+        check(lib().pbrt_hip_render_wait(self._h, C.byref(st)), "pbrt_hip_render_wait")
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def film_assemble_device(self, d_slab_ptr, rank, world_size, d_film_ptr, stream_ptr=None):
+        check(lib().pbrt_hip_film_assemble_device(self._h, C.c_void_p(d_slab_ptr), rank, world_size,
+                                                  C.c_void_p(d_film_ptr), C.c_void_p(stream_ptr or 0)),
+              "pbrt_hip_film_assemble_device")
+
+    def slab_floats(self, rank=0, world_size=1):
+        return lib().pbrt_hip_slab_floats(self.sd.xres, self.sd.yres, (C.c_float * 4)(*self.sd.crop), rank, world_size)
+
+    def intersect(self, o, d, tmax, counters=False):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        tmax = np.ascontiguousarray(tmax, np.float32).reshape(-1)
+        n = o.shape[0]
+        t = np.zeros(n, np.float32)
+        prim = np.zeros(n, np.uint32)
+        b1 = np.zeros(n, np.float32)
+        b2 = np.zeros(n, np.float32)
+        cnt = (C.c_uint64 * 2)()
+        check(lib().pbrt_hip_intersect(self._h, n, _fp(o), _fp(d), _fp(tmax), _fp(t), _u32p(prim), _fp(b1), _fp(b2),
+                                       cnt if counters else None), "pbrt_hip_intersect")
+        return t, prim, b1, b2, (cnt[0], cnt[1])
+
+    def occluded(self, o, d, tmax):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        tmax = np.ascontiguousarray(tmax, np.float32).reshape(-1)
+        n = o.shape[0]
+        hit = np.zeros(n, np.uint8)
+        check(lib().pbrt_hip_occluded(self._h, n, _fp(o), _fp(d), _fp(tmax),
+                                      hit.ctypes.data_as(C.POINTER(C.c_uint8))), "pbrt_hip_occluded")
+        return hit

@@ -1,0 +1,53 @@
+"""Builds libpbrt_hip.so (the C-ABI library of include/pbrt_hip.h) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU.  Flags that matter for parity with the CPU oracle:
+  -ffp-contract=off   no fused multiply-add is formed (hipcc's default would contract)
+  (no -ffast-math)    IEEE division / sqrt stay correctly rounded, NaN semantics kept
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libpbrt_hip.so")
+SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "kernels.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    """Compile every translation unit with hipcc and link the shared library."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(HERE, "..", "include", "pbrt_hip.h"))
+    deps.append(os.path.abspath(__file__))
+    if not force and _newer(LIB_PATH, deps):
+        return LIB_PATH
+    objs = []
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+              "-Wno-unused-function", f"--offload-arch={ARCH}"] + list(extra_flags)
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
+        cmd = [HIPCC] + common + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,562 @@
+// capi.cpp -- the extern "C" boundary declared in include/pbrt_hip.h: scene flattening + upload,
+// kernel launches, film assembly.  Replaces the (empty) body of PbrtAPI::world_end,
+// /root/reference/src/core/api.rs:432-473.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pbrt_hip.h"
+#include "bvh_build.hpp"
+#include "device_types.h"
+#include "host_math.hpp"
+
+using namespace pbrt_hip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(PBRT_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+// number of 64x64 super-tiles a rank owns, and the grid of super-tiles
+struct Shard {
+  int32_t w, h;
+  uint32_t stx, sty, total, n_local;
+};
+Shard make_shard(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world) {
+  int32_t b[4];
+  film_cropped_bounds(xres, yres, crop, b);
+  Shard s;
+  s.w = b[2] - b[0];
+  s.h = b[3] - b[1];
+  if (s.w < 0) s.w = 0;
+  if (s.h < 0) s.h = 0;
+  s.stx = (uint32_t)(s.w + 63) / 64;
+  s.sty = (uint32_t)(s.h + 63) / 64;
+  s.total = s.stx * s.sty;
+  s.n_local = (world && rank < world && s.total > rank) ? (s.total - rank + world - 1) / world : 0;
+  return s;
+}
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct pbrt_hip_scene {
+  int device = 0;
+  pbrt_hip_scene_desc desc{};  // scalar fields only; pointers are cleared
+  Bvh bvh;
+  uint32_t n_lights = 0;
+  DevScene dev{};
+  // device allocations
+  DevBuf<float> d_P;
+  DevBuf<uint32_t> d_idx, d_order;
+  DevBuf<uint16_t> d_mat_id;
+  DevBuf<uint4> d_nodes;
+  DevBuf<float4> d_tris, d_mats, d_lights, d_spheres;
+  DevBuf<float4> d_slab, d_film;          // scratch of pbrt_hip_render()
+  DevBuf<unsigned long long> d_counters;  // 5
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t stream = nullptr;  // own stream of pbrt_hip_render()
+  bool pending = false;
+  bool pending_counters = false;
+  uint64_t pending_samples = 0;
+  uint64_t device_bytes = 0;
+
+  ~pbrt_hip_scene() {
+    d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release();
+    d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
+    d_slab.release(); d_film.release(); d_counters.release();
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+extern "C" {
+
+int pbrt_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *pbrt_hip_last_error(void) { return g_err.c_str(); }
+const char *pbrt_hip_version(void) { return "pbrt_hip 0.1 (gfx950)"; }
+
+int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, uint32_t *nodes,
+                            uint32_t *order, uint32_t *n_nodes, uint32_t *depth) {
+  try {
+    if ((n_tris && (!P || !idx)) || !n_nodes || !depth) return fail(PBRT_HIP_ERR_INVALID, "bvh_build_host: null argument");
+    for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
+      if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "bvh_build_host: vertex index out of range");
+    Bvh b;
+    build_bvh(P, idx, n_tris, &b);
+    *n_nodes = (uint32_t)b.nodes.size();
+    *depth = b.depth;
+    if (nodes && !b.nodes.empty()) std::memcpy(nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode));
+    if (order && !b.order.empty()) std::memcpy(order, b.order.data(), b.order.size() * 4);
+    return PBRT_HIP_OK;
+  } catch (const std::exception &e) {
+    return fail(PBRT_HIP_ERR_INTERNAL, e.what());
+  }
+}
+
+int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_scene **out) {
+  if (!d || !out) return fail(PBRT_HIP_ERR_INVALID, "scene_create: null argument");
+  *out = nullptr;
+  try {
+    if (d->xres <= 0 || d->yres <= 0) return fail(PBRT_HIP_ERR_INVALID, "scene_create: resolution must be positive");
+    if (d->n_tris && (!d->P || !d->idx || !d->mat_id)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: missing mesh arrays");
+    if ((d->n_tris || d->n_spheres) && (!d->mats || d->n_mats == 0)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: no materials");
+    if (d->n_mats > 65536) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 65536 materials");
+    for (size_t i = 0; i < 3 * (size_t)d->n_tris; i++)
+      if (d->idx[i] >= d->n_verts) return fail(PBRT_HIP_ERR_INVALID, "scene_create: vertex index out of range");
+    for (uint32_t t = 0; t < d->n_tris; t++)
+      if (d->mat_id[t] >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: material id out of range");
+    for (uint32_t s = 0; s < d->n_spheres; s++)
+      if (d->spheres[s].mat >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere material id out of range");
+
+    int ndev = pbrt_hip_device_count();
+    if (ndev <= 0) return fail(PBRT_HIP_ERR_NO_DEVICE, "scene_create: no HIP device (there is no CPU fallback)");
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(PBRT_HIP_ERR_INVALID, "scene_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    std::unique_ptr<pbrt_hip_scene> s(new pbrt_hip_scene());
+    s->device = device;
+    s->desc = *d;
+    s->desc.P = nullptr; s->desc.idx = nullptr; s->desc.mat_id = nullptr;
+    s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
+
+    // --- accelerator ---
+    build_bvh(d->P, d->idx, d->n_tris, &s->bvh);
+    if (s->bvh.depth > 64) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: BVH deeper than the 64-entry traversal stack");
+
+    // --- light table: explicit lights, then every emissive triangle in index order ---
+    std::vector<float4> lights;
+    float le_inf[3] = {0.f, 0.f, 0.f};
+    bool has_inf = false;
+    auto as_f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+      const pbrt_hip_light &l = d->lights[i];
+      if (l.type > 2) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown light type");
+      lights.push_back(make_float4(as_f(l.type), l.p[0], l.p[1], l.p[2]));
+      lights.push_back(make_float4(0, 0, 0, 0));
+      lights.push_back(make_float4(0, 0, 0, 0));
+      lights.push_back(make_float4(l.c[0], l.c[1], l.c[2], 0));
+      lights.push_back(make_float4(0, 0, 0, 0));
+      if (l.type == 2) {
+        for (int k = 0; k < 3; k++) le_inf[k] = le_inf[k] + l.c[k];
+        has_inf = true;
+      }
+    }
+    for (uint32_t t = 0; t < d->n_tris; t++) {
+      const pbrt_hip_material &m = d->mats[d->mat_id[t]];
+      if (!(m.le[0] > 0.f || m.le[1] > 0.f || m.le[2] > 0.f)) continue;
+      F3 p[3];
+      for (int v = 0; v < 3; v++) {
+        const float *q = d->P + 3 * (size_t)d->idx[3 * (size_t)t + v];
+        p[v] = {q[0], q[1], q[2]};
+      }
+      F3 cr = cross3(sub(p[1], p[0]), sub(p[2], p[0]));
+      float len = std::sqrt(dot3(cr, cr));
+      lights.push_back(make_float4(as_f(3u), p[0].x, p[0].y, p[0].z));
+      lights.push_back(make_float4(p[1].x, p[1].y, p[1].z, 0.5f * len));
+      lights.push_back(make_float4(p[2].x, p[2].y, p[2].z, 0));
+      lights.push_back(make_float4(m.le[0], m.le[1], m.le[2], 0));
+      lights.push_back(make_float4(cr.x / len, cr.y / len, cr.z / len, 0));
+    }
+    s->n_lights = (uint32_t)(lights.size() / 5);
+
+    std::vector<float4> mats(2 * (size_t)d->n_mats);
+    for (uint32_t i = 0; i < d->n_mats; i++) {
+      const pbrt_hip_material &m = d->mats[i];
+      if (m.type > 1) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown material type");
+      mats[2 * i] = make_float4(as_f(m.type), m.k[0], m.k[1], m.k[2]);
+      mats[2 * i + 1] = make_float4(m.le[0], m.le[1], m.le[2], 0);
+    }
+    std::vector<float4> spheres(2 * (size_t)d->n_spheres);
+    for (uint32_t i = 0; i < d->n_spheres; i++) {
+      const pbrt_hip_sphere &sp = d->spheres[i];
+      spheres[2 * i] = make_float4(sp.c[0], sp.c[1], sp.c[2], sp.r);
+      spheres[2 * i + 1] = make_float4(as_f(sp.mat), 0, 0, 0);
+    }
+
+    // --- upload: vertex / index buffers, flattened nodes, leaf order; pack leaf records on device ---
+    const uint32_t nt = d->n_tris;
+    HIP_TRY(s->d_P.alloc(3 * (size_t)d->n_verts));
+    HIP_TRY(s->d_idx.alloc(3 * (size_t)nt));
+    HIP_TRY(s->d_mat_id.alloc(nt));
+    HIP_TRY(s->d_order.alloc(nt));
+    HIP_TRY(s->d_nodes.alloc(2 * s->bvh.nodes.size()));
+    HIP_TRY(s->d_tris.alloc(3 * (size_t)nt));
+    HIP_TRY(s->d_mats.alloc(mats.size()));
+    HIP_TRY(s->d_lights.alloc(lights.size()));
+    HIP_TRY(s->d_spheres.alloc(spheres.size()));
+    HIP_TRY(s->d_counters.alloc(5));
+    HIP_TRY(hipStreamCreate(&s->stream));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+    auto up = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+      if (!bytes) return hipSuccess;
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream);
+    };
+    HIP_TRY(up(s->d_P.p, d->P, s->d_P.n * 4));
+    HIP_TRY(up(s->d_idx.p, d->idx, s->d_idx.n * 4));
+    HIP_TRY(up(s->d_mat_id.p, d->mat_id, s->d_mat_id.n * 2));
+    HIP_TRY(up(s->d_order.p, s->bvh.order.data(), s->d_order.n * 4));
+    HIP_TRY(up(s->d_nodes.p, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(BvhNode)));
+    HIP_TRY(up(s->d_mats.p, mats.data(), mats.size() * 16));
+    HIP_TRY(up(s->d_lights.p, lights.data(), lights.size() * 16));
+    HIP_TRY(up(s->d_spheres.p, spheres.data(), spheres.size() * 16));
+    HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order.p, nt, s->d_tris.p, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->device_bytes = s->d_P.n * 4 + s->d_idx.n * 4 + s->d_mat_id.n * 2 + s->d_order.n * 4 + s->d_nodes.n * 16 +
+                      s->d_tris.n * 16 + s->d_mats.n * 16 + s->d_lights.n * 16 + s->d_spheres.n * 16;
+
+    // --- kernel argument block ---
+    DevScene &D = s->dev;
+    D.nodes = s->d_nodes.p;
+    D.tris = s->d_tris.p;
+    D.mats = s->d_mats.p;
+    D.lights = s->d_lights.p;
+    D.spheres = s->d_spheres.p;
+    D.n_nodes = (uint32_t)s->bvh.nodes.size();
+    D.n_tris = nt;
+    D.n_spheres = d->n_spheres;
+    D.n_lights = s->n_lights;
+    for (int k = 0; k < 3; k++) D.le_inf[k] = le_inf[k];
+    D.has_inf = has_inf ? 1u : 0u;
+    for (int k = 0; k < 12; k++) D.c2w[k] = d->cam_to_world[k];
+    // perspective camera: screen window from the aspect ratio, fov on the shorter axis
+    const float aspect = (float)d->xres / (float)d->yres;
+    float sx0, sx1, sy0, sy1;
+    if (aspect > 1.f) { sx0 = -aspect; sx1 = aspect; sy0 = -1.f; sy1 = 1.f; }
+    else { sx0 = -1.f; sx1 = 1.f; sy0 = -1.f / aspect; sy1 = 1.f / aspect; }
+    const float tan_half = (float)std::tan((double)d->fov * (3.14159265358979323846 / 180.0) * 0.5);
+    D.cam_ax = ((sx1 - sx0) / (float)d->xres) * tan_half;
+    D.cam_bx = sx0 * tan_half;
+    D.cam_ay = -((sy1 - sy0) / (float)d->yres) * tan_half;
+    D.cam_by = sy1 * tan_half;
+    D.xres = d->xres;
+    D.yres = d->yres;
+    int32_t cb[4];
+    film_cropped_bounds(d->xres, d->yres, d->crop, cb);
+    D.cx0 = cb[0]; D.cy0 = cb[1]; D.cx1 = cb[2]; D.cy1 = cb[3];
+    *out = s.release();
+    return PBRT_HIP_OK;
+  } catch (const std::exception &e) {
+    return fail(PBRT_HIP_ERR_INTERNAL, e.what());
+  }
+}
+
+void pbrt_hip_scene_destroy(pbrt_hip_scene *scene) {
+  if (!scene) return;
+  (void)hipSetDevice(scene->device);
+  delete scene;
+}
+
+int pbrt_hip_scene_info(const pbrt_hip_scene *s, uint32_t *n_nodes, uint32_t *depth, uint32_t *n_lights,
+                        uint64_t *device_bytes) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "scene_info: null scene");
+  if (n_nodes) *n_nodes = (uint32_t)s->bvh.nodes.size();
+  if (depth) *depth = s->bvh.depth;
+  if (n_lights) *n_lights = s->n_lights;
+  if (device_bytes) *device_bytes = s->device_bytes;
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_scene_export_bvh(const pbrt_hip_scene *s, uint32_t *nodes, uint32_t *order) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "export_bvh: null scene");
+  if (nodes && !s->bvh.nodes.empty()) std::memcpy(nodes, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(BvhNode));
+  if (order && !s->bvh.order.empty()) std::memcpy(order, s->bvh.order.data(), s->bvh.order.size() * 4);
+  return PBRT_HIP_OK;
+}
+
+static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc *r) {
+  if (!s || !r) return fail(PBRT_HIP_ERR_INVALID, "render: null argument");
+  if (r->spp_x == 0 || r->spp_y == 0) return fail(PBRT_HIP_ERR_INVALID, "render: spp_x and spp_y must be >= 1");
+  if (r->world_size == 0 || r->rank >= r->world_size) return fail(PBRT_HIP_ERR_INVALID, "render: rank must be < world_size");
+  if (r->integrator > 1) return fail(PBRT_HIP_ERR_INVALID, "render: unknown integrator");
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, void *d_slab, void *stream) {
+  int rc = check_render_desc(s, r);
+  if (rc) return rc;
+  try {
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    const Shard sh = make_shard(s->desc.xres, s->desc.yres, s->desc.crop, r->rank, r->world_size);
+    if (sh.n_local && !d_slab) return fail(PBRT_HIP_ERR_INVALID, "render_device: null slab");
+    RenderParams R;
+    R.integrator = r->integrator;
+    R.max_depth = r->max_depth;
+    R.spp_x = r->spp_x;
+    R.spp_y = r->spp_y;
+    R.seed = r->seed;
+    R.rank = r->rank;
+    R.world = r->world_size;
+    R.inv_nx = 1.0f / (float)r->spp_x;
+    R.inv_ny = 1.0f / (float)r->spp_y;
+    R.slab = (float4 *)d_slab;
+    R.counters = s->d_counters.p;
+    const bool counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) != 0;
+    if (counters) HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 5 * sizeof(unsigned long long), st));
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    s->pending = true;
+    s->pending_counters = counters;
+    // samples = pixels of this rank's super-tiles that lie inside the film
+    uint64_t px = 0;
+    for (uint32_t j = 0; j < sh.n_local; j++) {
+      uint32_t t = r->rank + j * r->world_size;
+      int32_t x0 = (int32_t)(t % sh.stx) * 64, y0 = (int32_t)(t / sh.stx) * 64;
+      int32_t w = sh.w - x0 < 64 ? sh.w - x0 : 64, h = sh.h - y0 < 64 ? sh.h - y0 : 64;
+      px += (uint64_t)w * (uint64_t)h;
+    }
+    s->pending_samples = px * (uint64_t)r->spp_x * (uint64_t)r->spp_y;
+    return PBRT_HIP_OK;
+  } catch (const std::exception &e) {
+    return fail(PBRT_HIP_ERR_INTERNAL, e.what());
+  }
+}
+
+int pbrt_hip_render_wait(pbrt_hip_scene *s, pbrt_hip_stats *stats) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "render_wait: null scene");
+  if (!s->pending) return fail(PBRT_HIP_ERR_INVALID, "render_wait: no render in flight");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->ev1));
+  s->pending = false;
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->samples = s->pending_samples;
+    if (s->pending_counters) {
+      unsigned long long c[5];
+      HIP_TRY(hipMemcpy(c, s->d_counters.p, sizeof(c), hipMemcpyDeviceToHost));
+      stats->camera_rays = c[0]; stats->bounce_rays = c[1]; stats->shadow_rays = c[2];
+      stats->nodes_visited = c[3]; stats->tris_tested = c[4];
+    }
+  }
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_film_assemble_device(const pbrt_hip_scene *s, const void *d_slab, uint32_t rank, uint32_t world,
+                                  void *d_film, void *stream) {
+  if (!s || !d_film) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: null argument");
+  if (world == 0 || rank >= world) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: rank must be < world_size");
+  HIP_TRY(hipSetDevice(s->device));
+  const Shard sh = make_shard(s->desc.xres, s->desc.yres, s->desc.crop, rank, world);
+  if (sh.n_local && !d_slab) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: null slab");
+  HIP_TRY(launch_assemble((const float4 *)d_slab, (float4 *)d_film, sh.w, sh.h, rank, world, sh.n_local,
+                          (hipStream_t)stream));
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_render(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, float *film, pbrt_hip_stats *stats) {
+  int rc = check_render_desc(s, r);
+  if (rc) return rc;
+  if (!film) return fail(PBRT_HIP_ERR_INVALID, "render: null film");
+  HIP_TRY(hipSetDevice(s->device));
+  const Shard sh = make_shard(s->desc.xres, s->desc.yres, s->desc.crop, r->rank, r->world_size);
+  const size_t n_px = (size_t)sh.w * (size_t)sh.h;
+  const size_t slab_n = (size_t)sh.n_local * 4096;
+  if (s->d_slab.n < slab_n) { s->d_slab.release(); HIP_TRY(s->d_slab.alloc(slab_n)); }
+  if (s->d_film.n < n_px) { s->d_film.release(); HIP_TRY(s->d_film.alloc(n_px)); }
+  if (n_px) HIP_TRY(hipMemsetAsync(s->d_film.p, 0, n_px * 16, s->stream));
+  rc = pbrt_hip_render_device(s, r, s->d_slab.p, s->stream);
+  if (rc) return rc;
+  rc = pbrt_hip_film_assemble_device(s, s->d_slab.p, r->rank, r->world_size, s->d_film.p, s->stream);
+  if (rc) return rc;
+  if (n_px) HIP_TRY(hipMemcpyAsync(film, s->d_film.p, n_px * 16, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return pbrt_hip_render_wait(s, stats);
+}
+
+int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world) {
+  if (!crop || world == 0 || rank >= world || xres <= 0 || yres <= 0) return -1;
+  return (int64_t)make_shard(xres, yres, crop, rank, world).n_local * 4096 * 4;
+}
+
+int pbrt_hip_slab_pixel_index(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world,
+                              int64_t *out) {
+  if (!crop || !out || world == 0 || rank >= world || xres <= 0 || yres <= 0)
+    return fail(PBRT_HIP_ERR_INVALID, "slab_pixel_index: bad argument");
+  const Shard sh = make_shard(xres, yres, crop, rank, world);
+  for (uint32_t j = 0; j < sh.n_local; j++) {
+    const uint32_t t = rank + j * world;
+    const int32_t x0 = (int32_t)(t % sh.stx) * 64, y0 = (int32_t)(t / sh.stx) * 64;
+    for (int32_t py = 0; py < 64; py++)
+      for (int32_t px = 0; px < 64; px++) {
+        const int32_t x = x0 + px, y = y0 + py;
+        out[(size_t)j * 4096 + py * 64 + px] = (x < sh.w && y < sh.h) ? (int64_t)y * sh.w + x : -1;
+      }
+  }
+  return PBRT_HIP_OK;
+}
+
+static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *d, const float *tmax, float *t,
+                     uint32_t *prim, float *b1, float *b2, uint8_t *occ, uint64_t *counters, bool any) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "intersect: null scene");
+  if (n < 0 || (n && (!o || !d || !tmax))) return fail(PBRT_HIP_ERR_INVALID, "intersect: bad ray arrays");
+  if (n == 0) {
+    if (counters) counters[0] = counters[1] = 0;
+    return PBRT_HIP_OK;
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  DevBuf<float> d_o, d_d, d_tmax, d_t, d_b1, d_b2;
+  DevBuf<uint32_t> d_prim;
+  DevBuf<uint8_t> d_occ;
+  int rc = PBRT_HIP_OK;
+  auto cleanup = [&]() {
+    d_o.release(); d_d.release(); d_tmax.release(); d_t.release(); d_b1.release(); d_b2.release();
+    d_prim.release(); d_occ.release();
+  };
+#define RB_TRY(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      cleanup();                                                                                  \
+      return fail(PBRT_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    }                                                                                             \
+  } while (0)
+  RB_TRY(d_o.alloc(3 * (size_t)n));
+  RB_TRY(d_d.alloc(3 * (size_t)n));
+  RB_TRY(d_tmax.alloc((size_t)n));
+  RB_TRY(hipMemcpyAsync(d_o.p, o, 12 * (size_t)n, hipMemcpyHostToDevice, s->stream));
+  RB_TRY(hipMemcpyAsync(d_d.p, d, 12 * (size_t)n, hipMemcpyHostToDevice, s->stream));
+  RB_TRY(hipMemcpyAsync(d_tmax.p, tmax, 4 * (size_t)n, hipMemcpyHostToDevice, s->stream));
+  RayBatch B{};
+  B.o = d_o.p; B.d = d_d.p; B.tmax = d_tmax.p; B.n = n;
+  if (any) {
+    RB_TRY(d_occ.alloc((size_t)n));
+    B.occluded = d_occ.p;
+  } else {
+    RB_TRY(d_t.alloc((size_t)n)); RB_TRY(d_prim.alloc((size_t)n)); RB_TRY(d_b1.alloc((size_t)n)); RB_TRY(d_b2.alloc((size_t)n));
+    B.t = d_t.p; B.prim = d_prim.p; B.b1 = d_b1.p; B.b2 = d_b2.p;
+  }
+  if (counters) {
+    RB_TRY(hipMemsetAsync(s->d_counters.p, 0, 2 * sizeof(unsigned long long), s->stream));
+    B.counters = s->d_counters.p;
+  }
+  RB_TRY(launch_intersect(s->dev, B, any, s->bvh.depth, s->stream));
+  if (any) {
+    RB_TRY(hipMemcpyAsync(occ, d_occ.p, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+  } else {
+    RB_TRY(hipMemcpyAsync(t, d_t.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    RB_TRY(hipMemcpyAsync(prim, d_prim.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    RB_TRY(hipMemcpyAsync(b1, d_b1.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    RB_TRY(hipMemcpyAsync(b2, d_b2.p, 4 * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+  }
+  if (counters) {
+    unsigned long long c[2];
+    RB_TRY(hipMemcpyAsync(c, s->d_counters.p, sizeof(c), hipMemcpyDeviceToHost, s->stream));
+    RB_TRY(hipStreamSynchronize(s->stream));
+    counters[0] = c[0];
+    counters[1] = c[1];
+  } else {
+    RB_TRY(hipStreamSynchronize(s->stream));
+  }
+#undef RB_TRY
+  cleanup();
+  return rc;
+}
+
+int pbrt_hip_intersect(pbrt_hip_scene *s, int64_t n, const float *o, const float *d, const float *tmax, float *t,
+                       uint32_t *prim, float *b1, float *b2, uint64_t *counters) {
+  if (n > 0 && (!t || !prim || !b1 || !b2)) return fail(PBRT_HIP_ERR_INVALID, "intersect: null output array");
+  return ray_batch(s, n, o, d, tmax, t, prim, b1, b2, nullptr, counters, false);
+}
+
+int pbrt_hip_occluded(pbrt_hip_scene *s, int64_t n, const float *o, const float *d, const float *tmax, uint8_t *hit) {
+  if (n > 0 && !hit) return fail(PBRT_HIP_ERR_INVALID, "occluded: null output array");
+  return ray_batch(s, n, o, d, tmax, nullptr, nullptr, nullptr, nullptr, hit, nullptr, true);
+}
+
+// ---- host pieces ----
+void pbrt_hip_film_cropped_bounds(int32_t xres, int32_t yres, const float crop[4], int32_t out[4]) {
+  film_cropped_bounds(xres, yres, crop, out);
+}
+
+// Film::get_sample_bounds, core/film.rs:166-175
+void pbrt_hip_film_sample_bounds(int32_t xres, int32_t yres, const float crop[4], float rx, float ry, int32_t out[4]) {
+  int32_t c[4];
+  film_cropped_bounds(xres, yres, crop, c);
+  out[0] = (int32_t)std::floor((float)c[0] + 0.5f - rx);
+  out[1] = (int32_t)std::floor((float)c[1] + 0.5f - ry);
+  out[2] = (int32_t)std::ceil((float)c[2] - 0.5f + rx);
+  out[3] = (int32_t)std::ceil((float)c[3] - 0.5f + ry);
+}
+
+// Film::get_film_tile, core/film.rs:264-281
+void pbrt_hip_film_tile_bounds(int32_t xres, int32_t yres, const float crop[4], float rx, float ry, const int32_t sb[4],
+                               int32_t out[4]) {
+  int32_t c[4];
+  film_cropped_bounds(xres, yres, crop, c);
+  const int32_t x0 = (int32_t)std::ceil((float)sb[0] - 0.5f - rx), y0 = (int32_t)std::ceil((float)sb[1] - 0.5f - ry);
+  const int32_t x1 = (int32_t)(std::floor((float)sb[2] - 0.5f + rx) + 1.f);
+  const int32_t y1 = (int32_t)(std::floor((float)sb[3] - 0.5f + ry) + 1.f);
+  out[0] = x0 > c[0] ? x0 : c[0];
+  out[1] = y0 > c[1] ? y0 : c[1];
+  out[2] = x1 < c[2] ? x1 : c[2];
+  out[3] = y1 < c[3] ? y1 : c[3];
+}
+
+// Film::write_image's pixel loop, core/film.rs:346-372 (splat_xyz is never written: add_splat is
+// unimplemented!() at film.rs:334-336, so the splat term is identically zero)
+void pbrt_hip_film_to_rgb(const float *film, int64_t n, float scale, float *rgb) {
+  for (int64_t i = 0; i < n; i++) {
+    float c[3];
+    xyz_to_rgb(film + 4 * i, c);
+    const float w = film[4 * i + 3];
+    if (w != 0.f) {
+      const float inv = 1.f / w;
+      for (int k = 0; k < 3; k++) {
+        const float v = c[k] * inv;
+        c[k] = v > 0.f ? v : 0.f;
+      }
+    }
+    for (int k = 0; k < 3; k++) rgb[3 * i + k] = c[k] * scale;
+  }
+}
+
+void pbrt_hip_look_at(const float pos[3], const float look[3], const float up[3], float m[16], float m_inv[16]) {
+  look_at(pos, look, up, m, m_inv);
+}
+
+}  // extern "C"

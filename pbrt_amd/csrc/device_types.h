@@ -1,0 +1,59 @@
+// device_types.h -- kernel argument blocks shared by the host launcher and the HIP kernels.
+// HBM layout:
+//   nodes   : 2 x 16 B per BVH node   {lo.x lo.y lo.z hi.x} {hi.y hi.z offset n_prims|axis<<16}
+//   tris    : 3 x 16 B per LEAF SLOT  {p0.xyz, triangle id} {p1.xyz, material id} {p2.xyz, 0}
+//             (leaf order, so the <=4 triangles of a leaf are one contiguous 48..192 B run)
+//   mats    : 2 x 16 B per material   {type, k.xyz} {le.xyz, 0}
+//   lights  : 5 x 16 B per light      {type, p0.xyz} {p1.xyz, area} {p2.xyz, 0} {c.xyz, 0} {n.xyz, 0}
+//   spheres : 2 x 16 B per sphere     {c.xyz, r} {material id, 0, 0, 0}
+#pragma once
+#include <stdint.h>
+
+#include <hip/hip_runtime.h>
+
+namespace pbrt_hip {
+
+struct DevScene {
+  const uint4 *nodes;
+  const float4 *tris;
+  const float4 *mats;
+  const float4 *lights;
+  const float4 *spheres;
+  uint32_t n_nodes, n_tris, n_spheres, n_lights;
+  float le_inf[3];
+  uint32_t has_inf;
+  float c2w[12];  // rows 0..2 of camera_to_world
+  float cam_ax, cam_bx, cam_ay, cam_by;
+  int32_t xres, yres;
+  int32_t cx0, cy0, cx1, cy1;  // cropped pixel bounds
+};
+
+struct RenderParams {
+  uint32_t integrator, max_depth, spp_x, spp_y;
+  uint64_t seed;
+  uint32_t rank, world;
+  float inv_nx, inv_ny;
+  float4 *slab;
+  unsigned long long *counters;  // 5: camera, bounce, shadow rays, nodes visited, triangles tested
+};
+
+struct RayBatch {
+  const float *o, *d, *tmax;  // 3n, 3n, n
+  int64_t n;
+  float *t;
+  uint32_t *prim;
+  float *b1, *b2;
+  uint8_t *occluded;
+  unsigned long long *counters;  // 2: nodes, tris (may be null)
+};
+
+// launchers (kernels.hip)
+hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
+                         bool counters, hipStream_t stream);
+hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
+hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
+                            uint32_t n_tris, float4 *tris, hipStream_t stream);
+hipError_t launch_assemble(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
+                           uint32_t n_local_super, hipStream_t stream);
+
+}  // namespace pbrt_hip

@@ -1,0 +1,104 @@
+// host_math.hpp -- host-side pieces of the render path that the reference crate implements and
+// this library must agree with: Matrix4x4 / look_at, Film geometry, RGB<->XYZ, sRGB quantisation.
+// Plain fp32, fixed operation order, compiled with -ffp-contract=off.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace pbrt_hip {
+
+struct F3 {
+  float x, y, z;
+};
+inline F3 sub(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float dot3(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// core/geometry/vector.rs:314-324
+inline F3 cross3(F3 a, F3 b) { return {(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)}; }
+// core/geometry/vector.rs:165-167, 204-206: self / self.length(), per-component division
+inline F3 unit3(F3 a) {
+  float len = std::sqrt(dot3(a, a));
+  return {a.x / len, a.y / len, a.z / len};
+}
+
+// Matrix4x4: 16 floats, row-major (core/transform.rs:75-77)
+inline void mat_identity(float m[16]) {
+  for (int i = 0; i < 16; i++) m[i] = (i % 5 == 0) ? 1.f : 0.f;
+}
+
+// Gauss-Jordan with full pivoting, core/transform.rs:162-234
+inline void mat_inverse(const float in[16], float out[16]) {
+  float a[4][4];
+  std::memcpy(a, in, 64);
+  int row_of[4], col_of[4], used[4] = {0, 0, 0, 0};
+  for (int step = 0; step < 4; step++) {
+    int pr = 0, pc = 0;
+    float best = 0.f;
+    for (int r = 0; r < 4; r++) {
+      if (used[r] == 1) continue;
+      for (int c = 0; c < 4; c++) {
+        if (used[c] != 0) continue;
+        float v = std::fabs(a[r][c]);
+        if (v >= best) { best = v; pr = r; pc = c; }
+      }
+    }
+    used[pc]++;
+    if (pr != pc)
+      for (int k = 0; k < 4; k++) { float t = a[pr][k]; a[pr][k] = a[pc][k]; a[pc][k] = t; }
+    row_of[step] = pr;
+    col_of[step] = pc;
+    float piv = 1.0f / a[pc][pc];
+    a[pc][pc] = 1.f;
+    for (int k = 0; k < 4; k++) a[pc][k] *= piv;
+    for (int r = 0; r < 4; r++) {
+      if (r == pc) continue;
+      float f = a[r][pc];
+      a[r][pc] = 0.f;
+      for (int k = 0; k < 4; k++) a[r][k] -= a[pc][k] * f;
+    }
+  }
+  for (int step = 3; step >= 0; step--) {
+    if (row_of[step] == col_of[step]) continue;
+    for (int r = 0; r < 4; r++) { float t = a[r][row_of[step]]; a[r][row_of[step]] = a[r][col_of[step]]; a[r][col_of[step]] = t; }
+  }
+  std::memcpy(out, a, 64);
+}
+
+// Transform::look_at, core/transform.rs:485-520.  Left-handed; m = inverse(camera_to_world).
+inline void look_at(const float pos[3], const float look[3], const float up[3], float m[16], float m_inv[16]) {
+  F3 p = {pos[0], pos[1], pos[2]}, l = {look[0], look[1], look[2]}, u = {up[0], up[1], up[2]};
+  F3 dir = unit3(sub(l, p));
+  F3 right = unit3(cross3(unit3(u), dir));
+  F3 new_up = cross3(dir, right);
+  float c2w[16] = {right.x, new_up.x, dir.x, p.x,  //
+                   right.y, new_up.y, dir.y, p.y,  //
+                   right.z, new_up.z, dir.z, p.z,  //
+                   0.f,     0.f,      0.f,   1.f};
+  std::memcpy(m_inv, c2w, 64);
+  mat_inverse(c2w, m);
+}
+
+// Film::new, core/film.rs:92-101: cropped_pixel_bounds = ceil(resolution * crop)
+inline void film_cropped_bounds(int xres, int yres, const float crop[4], int32_t b[4]) {
+  b[0] = (int32_t)std::ceil((float)xres * crop[0]);
+  b[1] = (int32_t)std::ceil((float)yres * crop[2]);
+  b[2] = (int32_t)std::ceil((float)xres * crop[1]);
+  b[3] = (int32_t)std::ceil((float)yres * crop[3]);
+}
+
+// core/spectrum.rs:129-145
+inline void xyz_to_rgb(const float xyz[3], float rgb[3]) {
+  rgb[0] = 3.240479f * xyz[0] - 1.537150f * xyz[1] - 0.498535f * xyz[2];
+  rgb[1] = -0.969256f * xyz[0] + 1.875991f * xyz[1] + 0.041556f * xyz[2];
+  rgb[2] = 0.055648f * xyz[0] - 0.204043f * xyz[1] + 1.057311f * xyz[2];
+}
+
+// lib.rs:93-99 and core/imageio.rs:66-68
+inline float gamma_correct(float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.f / 2.4f) - 0.055f; }
+inline uint8_t to_byte(float v) {
+  float q = 255.f * gamma_correct(v) + 0.5f;
+  q = q < 0.f ? 0.f : (q > 255.f ? 255.f : q);
+  return (uint8_t)q;
+}
+
+}  // namespace pbrt_hip

@@ -1,0 +1,70 @@
+"""Multi-GPU film assembly: one process per GPU, 64x64 super-tiles dealt round-robin
+(super-tile t belongs to rank t % world_size), scene replicated, no communication while
+rendering, and ONE gather of the per-rank slabs to rank 0 (RCCL over xGMI when the process group
+backend is "nccl"; "gloo" in the CPU tests).  The box filter's radius 0.5 (reference
+src/filters/box.rs:57-61) keeps every sample inside its own pixel, so tiles never overlap and the
+assembly is a pure scatter -- the multi-process form of Film::merge_film_tile
+(src/core/film.rs:313-326).
+
+torch is used for device buffers, streams and torch.distributed only.
+"""
+import numpy as np
+
+from . import api
+
+
+def slab_index_tensor(xres, yres, crop, rank, world_size, device="cpu"):
+    """int64 tensor: for every float4 slot of `rank`'s slab, the row-major pixel index in the
+    cropped film, or -1 for padding (host geometry from pbrt_hip_slab_pixel_index)."""
+    import torch
+    return torch.from_numpy(api.slab_pixel_index(xres, yres, crop, rank, world_size)).to(device)
+
+
+def max_slab_slots(xres, yres, crop, world_size):
+    """slab slots of the rank that owns the most super-tiles (rank 0): the gather's common size"""
+    return len(api.slab_pixel_index(xres, yres, crop, 0, world_size))
+
+
+def assemble_film(slabs, xres, yres, crop, world_size):
+    """Scatter the gathered slabs (list indexed by rank, each [slots, 4], possibly padded at the
+    end) into the row-major film [h, w, 4]."""
+    import torch
+    b = api.film_cropped_bounds(xres, yres, crop)
+    w, h = max(b[2] - b[0], 0), max(b[3] - b[1], 0)
+    film = torch.zeros(h * w, 4, dtype=torch.float32, device=slabs[0].device)
+    for r in range(world_size):
+        idx = slab_index_tensor(xres, yres, crop, r, world_size, device=film.device)
+        keep = idx >= 0
+        film[idx[keep]] = slabs[r][: idx.numel()][keep]
+    return film.view(h, w, 4)
+
+
+def gather_film(local_slab, xres, yres, crop, rank, world_size, group=None):
+    """Gather every rank's slab on rank 0 and assemble the film there (None elsewhere).
+    `local_slab`: [slots_of_this_rank, 4] float32 tensor on the rank's device."""
+    import torch
+    import torch.distributed as dist
+    n = max_slab_slots(xres, yres, crop, world_size)
+    send = torch.zeros(n, 4, dtype=torch.float32, device=local_slab.device)
+    send[: local_slab.shape[0]] = local_slab
+    if world_size == 1:
+        return assemble_film([send], xres, yres, crop, 1)
+    recv = [torch.empty_like(send) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(send, recv, dst=0, group=group)
+    if rank != 0:
+        return None
+    return assemble_film(recv, xres, yres, crop, world_size)
+
+
+def render_sharded(scene, rank, world_size, group=None, **render_kw):
+    """Render this rank's super-tiles on its GPU (asynchronously on torch's current stream),
+    gather, and return (film on rank 0 or None, stats of the local kernel)."""
+    import torch
+    sd = scene.sd
+    n_floats = scene.slab_floats(rank, world_size)
+    slab = torch.empty(max(n_floats // 4, 1), 4, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.render_device(slab.data_ptr(), stream, rank=rank, world_size=world_size, **render_kw)
+    film = gather_film(slab[: n_floats // 4], sd.xres, sd.yres, sd.crop, rank, world_size, group)
+    stats = scene.render_wait()
+    return film, stats

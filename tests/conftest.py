@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the HIP library and the oracle once per session if they are missing (hipcc
+    cross-compiles on CPU; on the GPU box the prebuilt .so files travel with the snapshot)."""
+    from pbrt_amd.build import build_hip
+    build_hip()
+    from oracle import binding
+    binding.build()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    return binding
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import pbrt_amd
+    if pbrt_amd.device_count() < 1:
+        pytest.fail("a gpu-marked test ran without a HIP device: pbrt_amd has no CPU fallback")
+    return pbrt_amd

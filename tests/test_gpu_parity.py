@@ -1,0 +1,200 @@
+"""The parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bar: BIT-EXACT -- every fp32 operation of the path is +,-,*,/,sqrt or a
+comparison, executed in the same order on both sides with FMA contraction off,
+so the film, the hit records and the visit counters must be identical, not merely close.
+(BASELINE.json asks for PSNR >= 50 dB; identical images are PSNR = inf.)"""
+import numpy as np
+import pytest
+
+import pbrt_amd
+from pbrt_amd import INTEGRATOR_DIRECT, INTEGRATOR_PATH, LIGHT_INFINITE, SceneData, scenes
+from util import SMALL_SCENES, assert_bit_equal, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def psnr(a, b):
+    a = np.clip(a.astype(np.float64), 0, 1)
+    b = np.clip(b.astype(np.float64), 0, 1)
+    mse = ((a - b) ** 2).mean()
+    return np.inf if mse == 0 else 10 * np.log10(1.0 / mse)
+
+
+def test_native_library_is_the_one_loaded(gpu):
+    """The GPU tests run on the in-tree HIP library, not on a fallback."""
+    maps = open("/proc/self/maps").read()
+    gpu.api.lib()
+    maps = open("/proc/self/maps").read()
+    assert "pbrt_amd/lib/libpbrt_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere"])
+def test_intersect_matches_oracle(gpu, oracle, name):
+    sd = SMALL_SCENES[name]()
+    o, d, tmax = random_rays(200_000 if name != "mesh20k" else 400_000, 21)
+    ref = oracle.OracleScene(sd)
+    rt, rp, rb1, rb2, rc = ref.intersect(o, d, tmax)
+    with gpu.Scene(sd) as sc:
+        t, prim, b1, b2, cnt = sc.intersect(o, d, tmax, counters=True)
+        occ = sc.occluded(o, d, tmax)
+        t2 = sc.intersect(o, d, tmax)[0]  # the non-counting instantiation
+    assert_bit_equal(prim, rp, "prim")
+    assert_bit_equal(t, rt, "t")
+    assert_bit_equal(b1, rb1, "b1")
+    assert_bit_equal(b2, rb2, "b2")
+    assert_bit_equal(t2, rt, "t (no counters)")
+    assert cnt == rc, f"nodes visited / triangles tested {cnt} vs oracle {rc}"  # identical traversal
+    assert_bit_equal(occ, ref.occluded(o, d, tmax), "occluded")
+    assert (prim != 0xFFFFFFFF).mean() > 0.05
+
+
+def test_intersect_edge_cases(gpu, oracle):
+    sd = SMALL_SCENES["mesh1k"]()
+    with gpu.Scene(sd) as sc:
+        e = np.zeros((0, 3), np.float32)
+        t, prim, *_ = sc.intersect(e, e, np.zeros(0, np.float32))  # empty batch
+        assert len(t) == 0
+        o, d, tmax = random_rays(37, 2)  # ragged: not a multiple of the wave / block size
+        ref = oracle.OracleScene(sd).intersect(o, d, tmax)
+        got = sc.intersect(o, d, tmax)
+        assert_bit_equal(got[0], ref[0], "t ragged")
+        tz = np.zeros(len(o), np.float32)  # tmax = 0: nothing can be hit
+        assert (sc.intersect(o, d, tz)[1] == 0xFFFFFFFF).all() and (sc.occluded(o, d, tz) == 0).all()
+    # a scene with no geometry at all
+    sd = SceneData(xres=16, yres=16, lights=np.array([[LIGHT_INFINITE, 0, 0, 0, 0.25, 0.5, 1.0]], np.float32))
+    with gpu.Scene(sd) as sc:
+        assert (sc.intersect(o, d, tmax)[1] == 0xFFFFFFFF).all()
+        film, st = sc.render(spp=(2, 1))
+        ref, _ = oracle.OracleScene(sd).render(spp=(2, 1))
+        assert_bit_equal(film, ref, "empty-scene film")
+
+
+RENDER_CASES = [
+    ("mesh1k", INTEGRATOR_PATH, 8, (2, 2), 3),
+    ("mesh20k", INTEGRATOR_PATH, 8, (4, 2), 0),
+    ("cornell", INTEGRATOR_PATH, 16, (3, 3), 1),
+    ("cornell", INTEGRATOR_PATH, 0, (1, 1), 1),
+    ("check_sphere", INTEGRATOR_PATH, 5, (2, 2), 9),
+    ("sphere", INTEGRATOR_DIRECT, 5, (4, 4), 0),
+    ("check_sphere", INTEGRATOR_DIRECT, 5, (2, 1), 4),
+]
+
+
+@pytest.mark.parametrize("name,integrator,depth,spp,seed", RENDER_CASES)
+def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
+    sd = SMALL_SCENES[name]()
+    ref, rst = oracle.OracleScene(sd).render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed, counters=True)
+        film2, st2 = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
+    assert_bit_equal(film, ref, f"{name} film")
+    assert_bit_equal(film2, ref, f"{name} film (no counters)")
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+        assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
+    assert st2["samples"] == sd.xres * sd.yres * spp[0] * spp[1] and st2["kernel_ms"] > 0
+    assert psnr(gpu.film_to_rgb(film), oracle.film_write_rgb(ref)) >= 50.0
+
+
+def test_golden_fixture(gpu):
+    """tests/golden/render_golden.npz: films the oracle produced when the fixtures were made
+    (tests/golden/make_golden.py); the HIP path must reproduce them bit for bit."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_golden.npz"))
+    for key in g.files:
+        name, integ, depth, sx, sy, seed = key.split("-")
+        sd = SMALL_SCENES[name]()
+        with gpu.Scene(sd) as sc:
+            film, _ = sc.render(integrator=int(integ), max_depth=int(depth), spp=(int(sx), int(sy)), seed=int(seed))
+        assert_bit_equal(film, g[key], key)
+
+
+def test_ranks_partition_and_crop(gpu, oracle):
+    sd = scenes.cornell_scene(200, 136)
+    ref, _ = oracle.OracleScene(sd).render(max_depth=4, spp=(2, 1), seed=2)
+    with gpu.Scene(sd) as sc:
+        full, _ = sc.render(max_depth=4, spp=(2, 1), seed=2)
+        acc = np.zeros_like(full)
+        for r in range(3):
+            part, st = sc.render(max_depth=4, spp=(2, 1), seed=2, rank=r, world_size=3)
+            assert ((acc[..., 3] == 0) | (part[..., 3] == 0)).all()
+            acc += part
+    assert_bit_equal(full, ref, "full")
+    assert_bit_equal(acc, ref, "union of 3 ranks")
+    crop = (0.25, 0.75, 0.5, 1.0)
+    sdc = scenes.cornell_scene(64, 64, crop=crop)
+    with gpu.Scene(sdc) as sc:
+        part, _ = sc.render(max_depth=4, spp=(2, 1), seed=1)
+    with gpu.Scene(scenes.cornell_scene(64, 64)) as sc:
+        whole, _ = sc.render(max_depth=4, spp=(2, 1), seed=1)
+    assert_bit_equal(part, whole[32:64, 16:48], "crop window")
+
+
+def test_device_slab_path_with_torch(gpu, oracle):
+    """render_device + film_assemble_device on torch-owned buffers / torch's stream, and the
+    torch-side assembly used by the multi-GPU launcher."""
+    import torch
+    from pbrt_amd import dist as pdist
+    sd = scenes.cornell_scene(200, 136)
+    ref, _ = oracle.OracleScene(sd).render(max_depth=3, spp=(2, 2), seed=6)
+    with gpu.Scene(sd) as sc:
+        slabs = []
+        for r in range(2):
+            n = sc.slab_floats(r, 2)
+            slab = torch.full((n // 4, 4), -1.0, device="cuda")
+            sc.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, max_depth=3, spp=(2, 2), seed=6,
+                             rank=r, world_size=2)
+            st = sc.render_wait()
+            assert st["kernel_ms"] > 0
+            slabs.append(slab)
+        film = pdist.assemble_film(slabs, sd.xres, sd.yres, sd.crop, 2)
+        assert_bit_equal(film.cpu().numpy(), ref, "torch-assembled film")
+        film2 = torch.zeros(sd.yres, sd.xres, 4, device="cuda")
+        for r in range(2):
+            sc.film_assemble_device(slabs[r].data_ptr(), r, 2, film2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_equal(film2.cpu().numpy(), ref, "kernel-assembled film")
+        f1, _ = pdist.render_sharded(sc, 0, 1, max_depth=3, spp=(2, 2), seed=6)
+        assert_bit_equal(f1.cpu().numpy(), ref, "render_sharded world 1")
+
+
+def test_c2_crop_windows_at_full_spp(gpu, oracle):
+    """BASELINE config C2 (100k triangles, 1024x1024, 256 spp, maxdepth 8): two 32x32 windows of
+    the frame at the full sample count against the oracle, bit for bit."""
+    for crop in [(0.5, 0.53125, 0.5, 0.53125), (0.125, 0.15625, 0.8125, 0.84375)]:
+        sd = scenes.random_mesh_scene(100_000, 1024, 1024, crop=crop)
+        ref, rst = oracle.OracleScene(sd).render(max_depth=8, spp=(16, 16), seed=0)
+        with gpu.Scene(sd) as sc:
+            film, st = sc.render(max_depth=8, spp=(16, 16), seed=0, counters=True)
+        assert film.shape == (32, 32, 4)
+        assert_bit_equal(film, ref, f"C2 window {crop}")
+        assert st["nodes_visited"] == rst["nodes_visited"] and st["tris_tested"] == rst["tris_tested"]
+
+
+def test_full_size_properties_c2(gpu, oracle):
+    """The whole C2 frame at reduced spp: size-independent properties + a window against the oracle."""
+    sd = scenes.random_mesh_scene(100_000, 1024, 1024)
+    with gpu.Scene(sd) as sc:
+        info = sc.info()
+        film, st = sc.render(max_depth=8, spp=(2, 2), seed=0)
+        again, _ = sc.render(max_depth=8, spp=(2, 2), seed=0)
+    assert info["depth"] <= 64
+    assert film.shape == (1024, 1024, 4)
+    assert (film[..., 3] == 4).all()                      # every pixel got exactly spp samples
+    assert np.isfinite(film).all() and (film[..., 1] >= 0).all()
+    assert_bit_equal(film, again, "idempotence")           # no run-to-run nondeterminism
+    assert st["samples"] == 1024 * 1024 * 4
+    win = scenes.random_mesh_scene(100_000, 1024, 1024, crop=(0.25, 0.3125, 0.25, 0.3125))
+    ref, _ = oracle.OracleScene(win).render(max_depth=8, spp=(2, 2), seed=0)
+    assert_bit_equal(film[256:320, 256:320], ref, "window of the full frame")
+
+
+def test_c3_scene_window(gpu, oracle):
+    """BASELINE config C3's scene (1M triangles, 2048x2048): a 16x16 window at 32x16 = 512 spp."""
+    crop = (0.5, 0.5 + 16 / 2048, 0.5, 0.5 + 16 / 2048)
+    sd = scenes.random_mesh_scene(1_000_000, 2048, 2048, crop=crop)
+    ref, rst = oracle.OracleScene(sd).render(max_depth=8, spp=(32, 16), seed=0)
+    with gpu.Scene(sd) as sc:
+        assert sc.info()["depth"] <= 64
+        film, st = sc.render(max_depth=8, spp=(32, 16), seed=0, counters=True)
+    assert_bit_equal(film, ref, "C3 window")
+    assert st["nodes_visited"] == rst["nodes_visited"]

@@ -1,0 +1,188 @@
+"""CPU-side tests of the product's host logic and of the C-ABI library itself (no GPU, no
+compute calls): symbols, error behaviour, the BVH builder, the sharding geometry, the inputs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pbrt_amd
+from pbrt_amd import _lib, scenes
+from util import SMALL_SCENES, assert_bit_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "pbrt_hip.h")).read()
+    declared = set(re.findall(r"\b(pbrt_hip_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    l = _lib.lib()
+    for name in declared:
+        assert hasattr(l, name)
+    assert b"gfx950" in l.pbrt_hip_version()
+
+
+def test_library_holds_gfx950_code_object():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"render_kernel" in blob
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """include/pbrt_hip.h compiles as plain C, and the ctypes mirrors have the C sizes."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "pbrt_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(pbrt_hip_material),sizeof(pbrt_hip_light),sizeof(pbrt_hip_sphere),sizeof(pbrt_hip_scene_desc),"
+                   "sizeof(pbrt_hip_render_desc),sizeof(pbrt_hip_stats));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    mirrors = [_lib.Material, _lib.Light, _lib.Sphere, _lib.SceneDesc, _lib.RenderDesc, _lib.Stats]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+    assert sizes[:3] == [32, 32, 32]
+
+
+@pytest.mark.skipif(pbrt_amd.device_count() > 0, reason="checks the no-device behaviour")
+def test_no_device_fails_loudly():
+    with pytest.raises(_lib.PbrtHipError) as e:
+        pbrt_amd.Scene(scenes.sphere_scene(8, 8))
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_bad_arguments_are_rejected_before_any_device_work():
+    sd = scenes.cornell_scene(8, 8)
+    sd.mat_id = sd.mat_id.copy()
+    sd.mat_id[0] = 99
+    with pytest.raises(_lib.PbrtHipError) as e:
+        pbrt_amd.Scene(sd)
+    assert e.value.code == -1 and "material id" in str(e.value)
+    sd = scenes.cornell_scene(8, 8)
+    sd.idx = sd.idx.copy()
+    sd.idx[3, 1] = 10_000
+    with pytest.raises(_lib.PbrtHipError) as e:
+        pbrt_amd.Scene(sd)
+    assert e.value.code == -1 and "vertex index" in str(e.value)
+    sd = scenes.cornell_scene(8, 8)
+    sd.xres = 0
+    with pytest.raises(_lib.PbrtHipError):
+        pbrt_amd.Scene(sd)
+    with pytest.raises(ValueError):
+        pbrt_amd.slab_pixel_index(64, 64, (0, 1, 0, 1), 2, 2)
+
+
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere"])
+def test_builder_equals_oracle_builder(oracle, name):
+    """Two independently written builders of the same spec agree word for word."""
+    sd = SMALL_SCENES[name]()
+    nodes, order, depth = pbrt_amd.bvh_build_host(sd.P, sd.idx)
+    on, oo, od = oracle.OracleScene(sd).bvh()
+    assert depth == od
+    assert_bit_equal(nodes, on, "nodes")
+    assert_bit_equal(order, oo, "order")
+
+
+def _check_tree(nodes, order, P, idx):
+    nt = idx.shape[0]
+    assert sorted(order.tolist()) == list(range(nt))  # a permutation: every triangle in exactly one leaf
+    f = nodes.view(np.float32)
+    seen = np.zeros(len(nodes), bool)
+    leaf_slots = 0
+    stack = [(0, 1)]
+    max_level = 0
+    while stack:
+        i, level = stack.pop()
+        assert not seen[i]
+        seen[i] = True
+        max_level = max(max_level, level)
+        lo, hi = f[i, 0:3], f[i, 3:6]
+        cnt, axis = int(nodes[i, 7] & 0xFFFF), int(nodes[i, 7] >> 16)
+        if cnt:
+            assert axis == 0
+            tri = order[nodes[i, 6]:nodes[i, 6] + cnt]
+            v = P[idx[tri]].reshape(-1, 3)
+            assert np.array_equal(v.min(0), lo) and np.array_equal(v.max(0), hi)  # tight
+            leaf_slots += cnt
+        else:
+            assert axis < 3
+            a, b = i + 1, int(nodes[i, 6])
+            assert b > a
+            for c in (a, b):
+                assert (f[c, 0:3] >= lo).all() and (f[c, 3:6] <= hi).all()  # children inside the parent
+            assert np.array_equal(np.minimum(f[a, 0:3], f[b, 0:3]), lo) and np.array_equal(np.maximum(f[a, 3:6], f[b, 3:6]), hi)
+            stack += [(a, level + 1), (b, level + 1)]
+    assert seen.all() and leaf_slots == nt
+    return max_level
+
+
+def test_builder_structure():
+    sd = SMALL_SCENES["mesh20k"]()
+    nodes, order, depth = pbrt_amd.bvh_build_host(sd.P, sd.idx)
+    assert _check_tree(nodes, order, sd.P, sd.idx) == depth
+    assert (nodes[:, 7] & 0xFFFF).max() <= 4
+
+
+def test_builder_edge_cases():
+    nodes, order, depth = pbrt_amd.bvh_build_host(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32))
+    assert len(nodes) == 0 and depth == 0
+    P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    nodes, order, depth = pbrt_amd.bvh_build_host(P, np.array([[0, 1, 2]], np.uint32))
+    assert len(nodes) == 1 and depth == 1 and nodes[0, 7] == 1 and order.tolist() == [0]
+    # 600 identical triangles: all centroids coincide -> halved by position into leaves of <= 255
+    idx = np.tile(np.array([[0, 1, 2]], np.uint32), (600, 1))
+    nodes, order, depth = pbrt_amd.bvh_build_host(P, idx)
+    cnt = nodes[:, 7] & 0xFFFF
+    assert cnt.max() <= 255 and cnt.sum() == 600
+    _check_tree(nodes, order, P, idx)
+    # a long chain of nested triangles stays within the 64-entry traversal stack
+    k = 3000
+    s = (0.5 ** (np.arange(k) / 40.0)).astype(np.float32)
+    Pn = np.concatenate([np.stack([s * 0, s * 0, s * 0], 1), np.stack([s, s * 0, s * 0], 1), np.stack([s * 0, s, s * 0], 1)])
+    In = np.stack([np.arange(k), k + np.arange(k), 2 * k + np.arange(k)], 1).astype(np.uint32)
+    nodes, order, depth = pbrt_amd.bvh_build_host(Pn, In)
+    assert depth <= 64
+    _check_tree(nodes, order, Pn, In)
+
+
+def test_slab_pixel_index_partitions_the_film():
+    xres, yres, crop = 200, 136, (0.0, 1.0, 0.0, 1.0)
+    for world in (1, 2, 3, 8, 13):
+        seen = np.zeros(xres * yres, int)
+        for r in range(world):
+            idx = pbrt_amd.slab_pixel_index(xres, yres, crop, r, world)
+            assert len(idx) % 4096 == 0
+            ok = idx[idx >= 0]
+            seen[ok] += 1
+            # super-tile j of rank r is super-tile r + j*world of the film, row-major 64x64
+            for j in range(len(idx) // 4096):
+                t = r + j * world
+                x0, y0 = (t % 4) * 64, (t // 4) * 64
+                blk = idx[j * 4096:(j + 1) * 4096].reshape(64, 64)
+                assert blk[0, 0] == y0 * xres + x0
+                assert (blk[:, min(63, xres - 1 - x0) + 1:] == -1).all()
+        assert (seen == 1).all()
+    # cropped film: indices are relative to the cropped bounds
+    idx = pbrt_amd.slab_pixel_index(256, 256, (0.25, 0.5, 0.5, 1.0), 0, 1)
+    assert len(idx) == 2 * 4096 and idx.max() == 64 * 128 - 1
+    assert len(pbrt_amd.slab_pixel_index(64, 64, (0, 0, 0, 0), 0, 1)) == 0  # empty film
+
+
+def test_scene_generators_are_deterministic_and_shaped():
+    a = scenes.random_mesh_scene(5000, 32, 32)
+    b = scenes.random_mesh_scene(5000, 32, 32)
+    assert_bit_equal(a.P, b.P, "P")
+    assert a.idx.shape == (5000 + 14, 3) and a.materials.shape == (252, 7)
+    tri = a.P[a.idx[:5000]]
+    centre_span = (tri.max(1) - tri.min(1)).max()
+    assert centre_span <= 2 * 5000 ** (-1 / 3) + 1e-6  # vertices within +-s of the centre
+    assert (np.abs(tri) <= 1 + 5000 ** (-1 / 3) + 1e-6).all()
+    assert (a.materials[np.arange(0, 250, 5), 0] == 1).all() and (a.materials[1:5, 0] == 0).all()
+    le = a.materials[a.mat_id[-2:], 4:7]
+    assert (le == 20).all()
+    e1 = a.P[a.idx[-1, 1]] - a.P[a.idx[-1, 0]]
+    e2 = a.P[a.idx[-1, 2]] - a.P[a.idx[-1, 0]]
+    assert np.cross(e1, e2)[2] < 0  # the ceiling light faces down
+    c = scenes.random_mesh_scene(5000, 32, 32, seed=99)
+    assert not np.array_equal(a.P, c.P)
