@@ -49,28 +49,53 @@ def algorithmic_bytes_per_sample(st, samples, spp):
     return (32.0 * st["nodes_visited"] + 48.0 * st["tris_tested"]) / samples + 28.0 + 16.0 / spp
 
 
-def cpu_baseline(kind, n, res, integrator, depth, spp):
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 CPUs but its cgroup grants cpu.max = 16 CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0):
     """The CPU oracle ("port"), rebuilt -march=native on this box, all host cores, on a bounded
-    sample of the same workload: 5 of the frame's 64x64 super-tiles spread over the image
-    (super-tiles t = 0 mod 251) at reduced samples per pixel (throughput is spp-independent)."""
+    sample of the same workload: every `world`-th 64x64 super-tile of the frame (spread over the
+    whole image, at least 8 work tiles per host thread) at a reduced sample count chosen by a
+    calibration pass so that the timed pass does about `target_s` seconds of CPU work
+    (throughput is spp-independent: every sample is an independent path)."""
     from oracle import binding as ob
     ob.build(native=True)
     sd = make_scene_data(kind, n, res)
     sc = ob.OracleScene(sd, native=True)
-    cores = os.cpu_count() or 1
-    world = 251 if res >= 1024 else 1
-    sspp = (8, 8) if kind == "mesh" else spp
-    if kind == "cornell":
-        sspp = (16, 16)
-    film, st = sc.render(integrator=integrator, max_depth=depth, spp=sspp, seed=0, rank=0, world_size=world, n_threads=cores)
-    samples = int((film[..., 3] > 0).sum()) * sspp[0] * sspp[1]
+    cores = usable_cores()
+    n_super = ((res + 63) // 64) ** 2
+    want_super = min(n_super, max(1, (8 * cores + 15) // 16))
+    world = max(1, n_super // want_super)
+    if world > 1 and world % 2 == 0:
+        world += 1  # odd stride: the sample does not fall on one column of super-tiles
+    kw = dict(integrator=integrator, max_depth=depth, seed=0, rank=0, world_size=world, n_threads=cores)
+    film, st = sc.render(spp=(1, 1), **kw)  # calibration
+    pixels = int((film[..., 3] > 0).sum())
+    rate = pixels / max(st["seconds"], 1e-6)
+    want_spp = max(1, min(spp[0] * spp[1], int(target_s * rate / pixels)))
+    sx = 1
+    while sx * sx * 4 <= want_spp and sx * 2 <= spp[0]:
+        sx *= 2
+    sy = max(1, min(spp[1], want_spp // sx))
+    film, st = sc.render(spp=(sx, sy), **kw)
+    samples = pixels * sx * sy
     rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
     return {
         "value": samples / st["seconds"] / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": f"CPU oracle (ours; the reference has no renderer), {samples} samples: super-tiles t%{world}==0 of the "
-                  f"{res}x{res} frame at {sspp[0]}x{sspp[1]} spp, {st['seconds']:.1f} s",
+        "sample": f"CPU oracle (ours; the reference has no renderer), {samples} samples = super-tiles t%{world}==0 "
+                  f"({pixels} pixels) of the {res}x{res} frame at {sx}x{sy} spp, {st['seconds']:.1f} s on {cores} threads",
         "mrays_per_s": rays / st["seconds"] / 1e6,
-        "bytes_per_sample": algorithmic_bytes_per_sample(st, samples, sspp[0] * sspp[1]),
+        "bytes_per_sample": algorithmic_bytes_per_sample(st, samples, sx * sy),
     }
 
 
@@ -168,6 +193,15 @@ def main():
         })
     else:
         roof.update({"kernel": "render_kernel", "kernel_ms": avg_kernel_ms})
+    # HBM-side traffic cannot be read in-process: it comes from the separate rocprofv3 --pmc passes of this same
+    # workload whose summary is committed under profiles/ (tools/summarize_profile.py); null when there is none.
+    pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+    if world == 1 and not args.spp and os.path.exists(pmc):
+        p = json.load(open(pmc))
+        roof["traffic"] = p["traffic_bytes_raw"]
+        roof["traffic_note"] = (f"(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from {os.path.relpath(pmc, ROOT)} "
+                                f"(round {p.get('round', '?')} kernel, {p['avg_ms']:.0f} ms); FETCH_SIZE counts L2-miss requests "
+                                "incl. Infinity-Cache hits and is uncalibrated for 16-B gathers (x2 if the wide-stream correction applied)")
 
     out = {
         "metric": "Msamples/sec (rays/sec) at 1/2/4/8 GPUs; PSNR vs CPU reference",
