@@ -136,7 +136,7 @@ class Scene {
     float cmin = cb.pmin[dim], cmax = cb.pmax[dim];
     size_t mid = (start + end) / 2;
     if (cmax == cmin) {
-      if (n <= 255) return make_leaf();
+      if (n <= 64) return make_leaf();
       // degenerate: split by position in the current order
     } else if (d >= 32) {
       // depth guard: median split, deterministic through a stable sort

@@ -72,7 +72,7 @@ struct Builder {
     uint32_t mid = (start + end) / 2;
 
     if (c1 == c0) {
-      if (n <= 255) return leaf();
+      if (n <= 64) return leaf();
       // all centroids coincide on the widest axis: halve the range as it stands
     } else if (level >= kDepthGuard) {
       std::stable_sort(ids.begin() + start, ids.begin() + end,

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -52,6 +53,57 @@ Shard make_shard(int32_t xres, int32_t yres, const float crop[4], uint32_t rank,
   s.total = s.stx * s.sty;
   s.n_local = (world && rank < world && s.total > rank) ? (s.total - rank + world - 1) / world : 0;
   return s;
+}
+
+// Scheduling thresholds of the traversal loop (kernels.hip trav_run).  They change only how lanes
+// are interleaved, never a result; PBRT_HIP_MIN_WALKERS / PBRT_HIP_MIN_PARKED override them for
+// tuning runs.
+uint32_t tuning(const char *name, uint32_t dflt) {
+  const char *v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  long x = std::strtol(v, nullptr, 10);
+  return x < 0 ? 0u : (x > 64 ? 64u : (uint32_t)x);
+}
+constexpr uint32_t kMinWalkers = 32, kMinParked = 8;
+
+constexpr uint32_t kLeafRef = 0x80000000u;
+
+// "Children in parent" form of the binary tree for the kernels: one 64-byte record per INTERIOR
+// node with the boxes and references of its two children.  ref = interior index
+// (dense numbering of interior nodes in depth-first order) or kLeafRef | n_prims << 24 | first slot.
+struct PairNodes {
+  std::vector<uint4> q;  // 4 per interior node
+  uint32_t root_ref = 0xffffffffu;
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+};
+bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
+  const size_t n = b.nodes.size();
+  if (n == 0) return true;
+  if (b.order.size() > (1u << 24)) { *why = "more than 2^24 triangles (leaf references hold a 24-bit slot)"; return false; }
+  std::vector<uint32_t> interior_index(n, 0);
+  uint32_t n_int = 0;
+  for (size_t i = 0; i < n; i++)
+    if ((b.nodes[i].count_axis & 0xffffu) == 0) interior_index[i] = n_int++;
+  auto ref_of = [&](uint32_t i) -> uint32_t {
+    const BvhNode &c = b.nodes[i];
+    const uint32_t cnt = c.count_axis & 0xffffu;
+    return cnt ? (kLeafRef | (cnt << 24) | c.offset) : interior_index[i];
+  };
+  auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  out->q.resize(4 * (size_t)n_int);
+  for (size_t i = 0; i < n; i++) {
+    const BvhNode &p = b.nodes[i];
+    if (p.count_axis & 0xffffu) continue;
+    const BvhNode &c0 = b.nodes[i + 1], &c1 = b.nodes[p.offset];
+    uint4 *q = &out->q[4 * (size_t)interior_index[i]];
+    q[0] = make_uint4(as_u(c0.lo[0]), as_u(c0.lo[1]), as_u(c0.lo[2]), as_u(c0.hi[0]));
+    q[1] = make_uint4(as_u(c0.hi[1]), as_u(c0.hi[2]), as_u(c1.lo[0]), as_u(c1.lo[1]));
+    q[2] = make_uint4(as_u(c1.lo[2]), as_u(c1.hi[0]), as_u(c1.hi[1]), as_u(c1.hi[2]));
+    q[3] = make_uint4(ref_of((uint32_t)i + 1), ref_of(p.offset), p.count_axis >> 16, 0u);
+  }
+  out->root_ref = ref_of(0);
+  for (int a = 0; a < 3; a++) { out->root_lo[a] = b.nodes[0].lo[a]; out->root_hi[a] = b.nodes[0].hi[a]; }
+  return true;
 }
 
 template <class T>
@@ -162,6 +214,11 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     // --- accelerator ---
     build_bvh(d->P, d->idx, d->n_tris, &s->bvh);
     if (s->bvh.depth > 64) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: BVH deeper than the 64-entry traversal stack");
+    PairNodes pairs;
+    {
+      std::string why;
+      if (!make_pair_nodes(s->bvh, &pairs, &why)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: " + why);
+    }
 
     // --- light table: explicit lights, then every emissive triangle in index order ---
     std::vector<float4> lights;
@@ -219,7 +276,7 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(s->d_idx.alloc(3 * (size_t)nt));
     HIP_TRY(s->d_mat_id.alloc(nt));
     HIP_TRY(s->d_order.alloc(nt));
-    HIP_TRY(s->d_nodes.alloc(2 * s->bvh.nodes.size()));
+    HIP_TRY(s->d_nodes.alloc(pairs.q.size()));
     HIP_TRY(s->d_tris.alloc(3 * (size_t)nt));
     HIP_TRY(s->d_mats.alloc(mats.size()));
     HIP_TRY(s->d_lights.alloc(lights.size()));
@@ -236,7 +293,7 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(up(s->d_idx.p, d->idx, s->d_idx.n * 4));
     HIP_TRY(up(s->d_mat_id.p, d->mat_id, s->d_mat_id.n * 2));
     HIP_TRY(up(s->d_order.p, s->bvh.order.data(), s->d_order.n * 4));
-    HIP_TRY(up(s->d_nodes.p, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(BvhNode)));
+    HIP_TRY(up(s->d_nodes.p, pairs.q.data(), pairs.q.size() * 16));
     HIP_TRY(up(s->d_mats.p, mats.data(), mats.size() * 16));
     HIP_TRY(up(s->d_lights.p, lights.data(), lights.size() * 16));
     HIP_TRY(up(s->d_spheres.p, spheres.data(), spheres.size() * 16));
@@ -253,6 +310,8 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     D.lights = s->d_lights.p;
     D.spheres = s->d_spheres.p;
     D.n_nodes = (uint32_t)s->bvh.nodes.size();
+    D.root_ref = pairs.root_ref;
+    for (int k = 0; k < 3; k++) { D.root_lo[k] = pairs.root_lo[k]; D.root_hi[k] = pairs.root_hi[k]; }
     D.n_tris = nt;
     D.n_spheres = d->n_spheres;
     D.n_lights = s->n_lights;
@@ -332,6 +391,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.inv_ny = 1.0f / (float)r->spp_y;
     R.slab = (float4 *)d_slab;
     R.counters = s->d_counters.p;
+    R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
+    R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const bool counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) != 0;
     if (counters) HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 5 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
@@ -463,6 +524,8 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
   RB_TRY(hipMemcpyAsync(d_tmax.p, tmax, 4 * (size_t)n, hipMemcpyHostToDevice, s->stream));
   RayBatch B{};
   B.o = d_o.p; B.d = d_d.p; B.tmax = d_tmax.p; B.n = n;
+  B.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
+  B.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
   if (any) {
     RB_TRY(d_occ.alloc((size_t)n));
     B.occluded = d_occ.p;

@@ -1,6 +1,9 @@
 // device_types.h -- kernel argument blocks shared by the host launcher and the HIP kernels.
 // HBM layout:
-//   nodes   : 2 x 16 B per BVH node   {lo.x lo.y lo.z hi.x} {hi.y hi.z offset n_prims|axis<<16}
+//   nodes   : 4 x 16 B per INTERIOR node of the binary BVH, holding the boxes of its two children
+//             ("children in parent": one fetch tests both children, leaves need no fetch at all)
+//             {c0.lo.xyz c0.hi.x} {c0.hi.yz c1.lo.xy} {c1.lo.z c1.hi.xyz} {ref0 ref1 axis 0}
+//             ref = interior index, or 0x80000000 | n_prims << 24 | first leaf slot
 //   tris    : 3 x 16 B per LEAF SLOT  {p0.xyz, triangle id} {p1.xyz, material id} {p2.xyz, 0}
 //             (leaf order, so the <=4 triangles of a leaf are one contiguous 48..192 B run)
 //   mats    : 2 x 16 B per material   {type, k.xyz} {le.xyz, 0}
@@ -19,7 +22,9 @@ struct DevScene {
   const float4 *mats;
   const float4 *lights;
   const float4 *spheres;
-  uint32_t n_nodes, n_tris, n_spheres, n_lights;
+  uint32_t n_nodes, n_tris, n_spheres, n_lights;  // n_nodes: nodes of the binary tree (0 = no triangles)
+  uint32_t root_ref;                                // ref of the root (a leaf ref for tiny scenes)
+  float root_lo[3], root_hi[3];                     // its box
   float le_inf[3];
   uint32_t has_inf;
   float c2w[12];  // rows 0..2 of camera_to_world
@@ -35,6 +40,7 @@ struct RenderParams {
   float inv_nx, inv_ny;
   float4 *slab;
   unsigned long long *counters;  // 5: camera, bounce, shadow rays, nodes visited, triangles tested
+  uint32_t min_walkers, min_parked;  // traversal scheduling thresholds (kernels.hip trav_run)
 };
 
 struct RayBatch {
@@ -45,6 +51,7 @@ struct RayBatch {
   float *b1, *b2;
   uint8_t *occluded;
   unsigned long long *counters;  // 2: nodes, tris (may be null)
+  uint32_t min_walkers, min_parked;
 };
 
 // launchers (kernels.hip)

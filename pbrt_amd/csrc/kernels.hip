@@ -154,97 +154,223 @@ __device__ __forceinline__ bool sphere_hit(const DevScene &S, uint32_t s, V3 o, 
   return true;
 }
 
-// Closest hit (any == false) or any hit (any == true; returns true when occluded) of one ray per
-// lane.  `stk` points at this lane's column of the LDS stack; consecutive levels are 64 dwords
-// apart.  Tie rule for equal t: the lower primitive id wins, so the answer does not depend on the
-// shape of the tree.
-template <bool SPH, bool COUNT>
-__device__ __forceinline__ bool traverse(const DevScene &S, V3 o, V3 d, float tmax, bool any, uint32_t *stk,
-                                         HitRec &h, unsigned long long &cn, unsigned long long &ct) {
-  h.t = kInf;
-  h.prim = kNoPrim;
-  h.slot = kNoPrim;
-  h.b1 = 0.f;
-  h.b2 = 0.f;
-  if (S.n_nodes) {
+constexpr uint32_t kDone = 0xffffffffu;
+constexpr uint32_t kLeafRef = 0x80000000u;  // ref = kLeafRef | n_prims << 24 | first slot (n_prims <= 64)
+
+// Per-lane traversal state.  It lives in registers across iterations of the kernels' outer loops,
+// so a lane can be suspended in the middle of a walk while other lanes of the wave are served.
+struct Trav {
+  V3 o, d;
+  float tmax;
+  uint32_t cur;       // interior ref to process next; kDone when the walk is over
+  uint32_t sp;        // LDS stack entries in use
+  uint32_t leaf_off;  // first slot of the leaf this lane is parked at
+  uint32_t leaf_cnt;  // triangles in that leaf; 0 = not parked
+  uint32_t any;       // any-hit (shadow) ray
+  uint32_t occluded;  // any-hit result
+  HitRec h;           // closest-hit result
+};
+
+struct TravTuning {
+  uint32_t min_walkers;  // leave the loop when fewer lanes are walking and some lane waits for service
+  uint32_t min_parked;   // test triangles once this many lanes are parked at a leaf
+};
+
+// The slab test of DESIGN.md 3.4 against [kRayTMin, tfar]: near / far plane per axis by the sign of
+// the inverse direction; fmin / fmax ignore a 0 * inf = NaN (conservative); far side padded.
+__device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, V3 inv,
+                                         bool negx, bool negy, bool negz, float tfar, float &tn) {
+  const float nx = ((negx ? hx : lx) - o.x) * inv.x, fx = ((negx ? lx : hx) - o.x) * inv.x;
+  const float ny = ((negy ? hy : ly) - o.y) * inv.y, fy = ((negy ? ly : hy) - o.y) * inv.y;
+  const float nz = ((negz ? hz : lz) - o.z) * inv.z, fz = ((negz ? lz : hz) - o.z) * inv.z;
+  tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, kRayTMin));
+  const float tf = fminf(fminf(fx, fy), fminf(fz, tfar));
+  return tn <= tf * kBoxPad;
+}
+
+// Next node from the stack.  EXACT (the counting instantiation): every entry carries the entry
+// distance tn of its box (NaN if the box already failed when it was pushed); the pop counts the node
+// as visited and re-tests `tn <= tfar * pad`, which is equivalent to the oracle's slab test of the
+// popped node with the current tfar (the far-plane part of that test can only have loosened).
+// Otherwise entries are bare refs and a popped node is simply processed (a superset walk).
+template <bool EXACT>
+__device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt, unsigned long long &cn) {
+  if (EXACT) {
+    while (T.sp != 0u) {
+      T.sp--;
+      const uint32_t ref = stk[T.sp * 64u];
+      const float tn = stkt[T.sp * 64u];
+      cn++;
+      if (tn <= fminf(T.h.t, T.tmax) * kBoxPad) return ref;
+    }
+    return kDone;
+  }
+  if (T.sp == 0u) return kDone;
+  T.sp--;
+  return stk[T.sp * 64u];
+}
+
+__device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) {
+  if (ref != kDone && (ref & kLeafRef)) {  // park at the leaf
+    T.leaf_off = ref & 0xffffffu;
+    T.leaf_cnt = (ref >> 24) & 0x7fu;
+  }
+  T.cur = ref;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 d, float tmax, bool any,
+                                           unsigned long long &cn) {
+  T.o = o;
+  T.d = d;
+  T.tmax = tmax;
+  T.sp = 0;
+  T.leaf_off = 0;
+  T.leaf_cnt = 0;
+  T.any = any ? 1u : 0u;
+  T.occluded = 0;
+  T.h.t = kInf;
+  T.h.prim = kNoPrim;
+  T.h.slot = kNoPrim;
+  T.h.b1 = 0.f;
+  T.h.b2 = 0.f;
+  T.cur = kDone;
+  if (S.n_nodes) {  // the root is the one node whose box is not held by a parent
+    if (EXACT) cn++;
     const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    const uint32_t neg = (inv.x < 0.f ? 1u : 0u) | (inv.y < 0.f ? 2u : 0u) | (inv.z < 0.f ? 4u : 0u);
-    uint32_t cur = 0;
-    int sp = 0;
-    for (;;) {
-      const uint4 n0 = S.nodes[2 * cur];
-      const uint4 n1 = S.nodes[2 * cur + 1];
-      if (COUNT) cn++;
-      const float tfar = fminf(h.t, tmax);
-      // near / far plane per axis by the sign of the inverse direction; fmin / fmax ignore a
-      // 0 * inf = NaN, which keeps the test conservative
-      const float lx = __uint_as_float(n0.x), ly = __uint_as_float(n0.y), lz = __uint_as_float(n0.z);
-      const float hx = __uint_as_float(n0.w), hy = __uint_as_float(n1.x), hz = __uint_as_float(n1.y);
-      const float nx = ((neg & 1u ? hx : lx) - o.x) * inv.x, fx = ((neg & 1u ? lx : hx) - o.x) * inv.x;
-      const float ny = ((neg & 2u ? hy : ly) - o.y) * inv.y, fy = ((neg & 2u ? ly : hy) - o.y) * inv.y;
-      const float nz = ((neg & 4u ? hz : lz) - o.z) * inv.z, fz = ((neg & 4u ? lz : hz) - o.z) * inv.z;
-      const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, kRayTMin));
-      const float tf = fminf(fminf(fx, fy), fminf(fz, tfar));
-      bool pop = true;
-      if (tn <= tf * kBoxPad) {
-        const uint32_t cnt = n1.w & 0xffffu;
-        if (cnt) {
-          for (uint32_t i = 0; i < cnt; i++) {
-            const uint32_t slot = n1.z + i;
-            const float4 a = S.tris[3 * slot], b = S.tris[3 * slot + 1], c = S.tris[3 * slot + 2];
-            if (COUNT) ct++;
-            const V3 p0 = xyz(a);
-            const V3 e1 = xyz(b) - p0, e2 = xyz(c) - p0;
-            const V3 pv = cross(d, e2);
-            const float det = dot(e1, pv);
-            if (fabsf(det) < 1e-8f) continue;
+    float tn;
+    if (box_test(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, inv,
+                 inv.x < 0.f, inv.y < 0.f, inv.z < 0.f, tmax, tn))
+      trav_enter(T, S.root_ref);
+  }
+}
+
+// The traversal loop of a whole wave ("while-while" with parked leaves) over the child-pair nodes.
+// Every lane walks its own ray through the binary tree of DESIGN.md 3.3 in the order of 3.4 (near
+// child by the sign of the split axis first, far child pushed); one step fetches ONE 64-byte record
+// and tests BOTH children of an interior node, leaves are never fetched (their ref holds slot and
+// count).  With EXACT the sequence of nodes visited and triangles tested is the oracle's, counter
+// for counter; without it the far child is dropped at once if its box fails and is not re-tested
+// when popped -- a superset walk whose RESULT is identical because of the tie rule (lower primitive
+// id wins at equal t).  What is scheduling, and never changes a lane's arithmetic:
+//   * a lane that reaches a leaf PARKS there; the wave tests triangles (one per parked lane per
+//     pass) only when `min_parked` lanes are parked or nobody can step, so the long
+//     Moeller-Trumbore body runs with many lanes instead of one or two;
+//   * the loop EXITS when no lane walks, or when fewer than `min_walkers` do and some lane whose
+//     walk is over is waiting to be served (shade / regenerate / fetch the next ray); walking
+//     lanes keep their state and resume on the next call.
+// `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
+// caller once its walk is over.
+template <bool EXACT>
+__device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, const bool alive,
+                                         const TravTuning tune, unsigned long long &cn, unsigned long long &ct) {
+  const V3 o = T.o, d = T.d;
+  const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  const bool negx = inv.x < 0.f, negy = inv.y < 0.f, negz = inv.z < 0.f;
+  const char *nodes = reinterpret_cast<const char *>(S.nodes);
+  const char *tris = reinterpret_cast<const char *>(S.tris);
+  for (;;) {
+    const bool walking = T.cur != kDone;
+    const unsigned long long mwalk = __ballot(walking);
+    if (mwalk == 0ull) break;
+    if ((uint32_t)__popcll(mwalk) < tune.min_walkers && __ballot(!walking && alive) != 0ull) break;
+
+    if (walking && T.leaf_cnt == 0u) {
+      // ---- one step: both children of interior node T.cur ----
+      const uint32_t off = T.cur * 64u;
+      const uint4 q0 = *reinterpret_cast<const uint4 *>(nodes + off);
+      const uint4 q1 = *reinterpret_cast<const uint4 *>(nodes + off + 16u);
+      const uint4 q2 = *reinterpret_cast<const uint4 *>(nodes + off + 32u);
+      const uint4 q3 = *reinterpret_cast<const uint4 *>(nodes + off + 48u);
+      const float tfar = fminf(T.h.t, T.tmax);
+      float tn0, tn1;
+      const bool hit0 = box_test(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z),
+                                 __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y), o, inv, negx,
+                                 negy, negz, tfar, tn0);
+      const bool hit1 = box_test(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x),
+                                 __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w), o, inv, negx,
+                                 negy, negz, tfar, tn1);
+      const uint32_t axis = q3.z;
+      const bool far_first = axis == 0u ? negx : (axis == 1u ? negy : negz);  // child 1 is the near one
+      const uint32_t ref_near = far_first ? q3.y : q3.x, ref_far = far_first ? q3.x : q3.y;
+      const bool hit_near = far_first ? hit1 : hit0, hit_far = far_first ? hit0 : hit1;
+      if (EXACT) {
+        cn++;  // the near child is visited now; the far one when it is popped
+        stk[T.sp * 64u] = ref_far;
+        stkt[T.sp * 64u] = hit_far ? (far_first ? tn0 : tn1) : __builtin_nanf("");
+        T.sp++;
+      } else if (hit_far) {
+        stk[T.sp * 64u] = ref_far;
+        T.sp++;
+      }
+      trav_enter(T, hit_near ? ref_near : trav_pop<EXACT>(T, stk, stkt, cn));
+    }
+
+    // ---- leaf flush (wave-uniform decision) ----
+    const unsigned long long mleaf = __ballot(T.leaf_cnt != 0u);
+    if (mleaf != 0ull &&
+        ((uint32_t)__popcll(mleaf) >= tune.min_parked || __ballot(T.cur != kDone && T.leaf_cnt == 0u) == 0ull)) {
+      const bool parked = T.leaf_cnt != 0u;
+      for (uint32_t i = 0;; i++) {
+        if (__ballot(T.leaf_cnt > i) == 0ull) break;
+        if (T.leaf_cnt > i) {
+          const uint32_t slot = T.leaf_off + i;
+          const float4 a = *reinterpret_cast<const float4 *>(tris + slot * 48u);
+          const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
+          const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
+          if (EXACT) ct++;
+          // Moeller-Trumbore, operation order of DESIGN.md 3.5
+          const V3 p0 = xyz(a);
+          const V3 e1 = xyz(b) - p0, e2 = xyz(c) - p0;
+          const V3 pv = cross(d, e2);
+          const float det = dot(e1, pv);
+          if (!(fabsf(det) < 1e-8f)) {
             const float idet = 1.0f / det;
             const V3 tv = o - p0;
             const float u = dot(tv, pv) * idet;
             const V3 qv = cross(tv, e1);
             const float v = dot(d, qv) * idet;
             const float th = dot(e2, qv) * idet;
-            if (!(u >= 0.f) || !(v >= 0.f) || !(u + v <= 1.0f)) continue;
-            if (!(th > kRayTMin) || !(th < tmax)) continue;
-            if (any) return true;
-            const uint32_t id = __float_as_uint(a.w);
-            if (th < h.t || (th == h.t && id < h.prim)) {
-              h.t = th; h.prim = id; h.slot = slot; h.b1 = u; h.b2 = v;
+            if ((u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax)) {
+              if (T.any) {
+                T.occluded = 1u;  // the walk ends at the first valid hit
+                T.leaf_cnt = 0u;
+                T.cur = kDone;
+                T.sp = 0u;
+              } else {
+                const uint32_t id = __float_as_uint(a.w);
+                if (th < T.h.t || (th == T.h.t && id < T.h.prim)) {
+                  T.h.t = th; T.h.prim = id; T.h.slot = slot; T.h.b1 = u; T.h.b2 = v;
+                }
+              }
             }
           }
-        } else {
-          const uint32_t axis = n1.w >> 16;
-          pop = false;
-          if ((neg >> axis) & 1u) {
-            stk[sp * 64] = cur + 1;
-            cur = n1.z;
-          } else {
-            stk[sp * 64] = n1.z;
-            cur = cur + 1;
-          }
-          sp++;
         }
       }
-      if (pop) {
-        if (sp == 0) break;
-        sp--;
-        cur = stk[sp * 64];
+      if (parked && T.cur != kDone) {  // leave the leaf: next node from the stack
+        T.leaf_cnt = 0u;
+        trav_enter(T, trav_pop<EXACT>(T, stk, stkt, cn));
       }
     }
   }
-  if (SPH) {
-    for (uint32_t s = 0; s < S.n_spheres; s++) {
-      float th;
-      if (sphere_hit(S, s, o, d, tmax, th)) {
-        if (any) return true;
+}
+
+// Spheres are tested after the BVH walk, with the same tie rule.
+__device__ __forceinline__ void trav_spheres(const DevScene &S, Trav &T) {
+  for (uint32_t s = 0; s < S.n_spheres; s++) {
+    if (T.any && T.occluded) break;
+    float th;
+    if (sphere_hit(S, s, T.o, T.d, T.tmax, th)) {
+      if (T.any) {
+        T.occluded = 1u;
+      } else {
         const uint32_t id = S.n_tris + s;
-        if (th < h.t || (th == h.t && id < h.prim)) {
-          h.t = th; h.prim = id; h.slot = kNoPrim; h.b1 = 0.f; h.b2 = 0.f;
+        if (th < T.h.t || (th == T.h.t && id < T.h.prim)) {
+          T.h.t = th; T.h.prim = id; T.h.slot = kNoPrim; T.h.b1 = 0.f; T.h.b2 = 0.f;
         }
       }
     }
   }
-  return false;
 }
 
 // One light of UniformSampleOneLight.  false: geometry rules the light out.
@@ -312,8 +438,10 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3 };
 template <bool SPH, bool COUNT, int STACK>
 __global__ void __launch_bounds__(256) render_kernel(const DevScene S, const RenderParams R) {
   __shared__ uint32_t lds_stack[4][STACK][64];
+  __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];  // entry distances: exact walk only
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *stk = &lds_stack[wave][0][lane];
+  float *stkt = &lds_tn[COUNT ? wave : 0][0][lane];
 
   // block -> (local super-tile, 16x16 tile inside it); wave -> 8x8 quadrant; lane -> pixel
   const int32_t W = S.cx1 - S.cx0, H = S.cy1 - S.cy0;
@@ -330,164 +458,185 @@ __global__ void __launch_bounds__(256) render_kernel(const DevScene S, const Ren
   const uint32_t nL = S.n_lights;
   const float nLf = (float)nL;
   const bool direct_only = R.integrator == 1u;
+  const TravTuning tune = {R.min_walkers, R.min_parked};
 
   Pcg rng;
   pcg_seq(rng, R.seed * (uint64_t)S.xres * (uint64_t)S.yres + (uint64_t)py * (uint64_t)S.xres + (uint64_t)px);
 
   V3 sum = {0.f, 0.f, 0.f};
   V3 L = {0.f, 0.f, 0.f}, beta = {1.f, 1.f, 1.f};
-  V3 ro = {0.f, 0.f, 0.f}, rd = {0.f, 0.f, 1.f};
-  float rtmax = kInf;
   V3 wi_next = {0.f, 0.f, 0.f}, Lpend = {0.f, 0.f, 0.f};
   uint32_t s = 0, bounces = 0, state = valid ? ST_NEW : ST_DONE;
   bool specular = false, cont = false;
   unsigned long long c_cam = 0, c_bounce = 0, c_shadow = 0, c_nodes = 0, c_tris = 0;
+  Trav T;
+  T.o = mk(0.f, 0.f, 0.f);
+  T.d = mk(0.f, 0.f, 1.f);
+  T.tmax = 0.f;
+  T.cur = kDone;
+  T.sp = 0;
+  T.leaf_off = 0;
+  T.leaf_cnt = 0;
+  T.any = 0;
+  T.occluded = 0;
+  T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
 
   for (;;) {
-    if (state == ST_NEW) {
-      if (s == spp) {
-        state = ST_DONE;
-      } else {
-        // stratified camera sample and PerspectiveCamera ray (3.2)
-        const uint32_t sx = s % R.spp_x, sy = s / R.spp_x;
-        const float u1 = pcg_float(rng), u2 = pcg_float(rng);
-        const float jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
-        const float jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
-        const float fx = (float)px + jx, fy = (float)py + jy;
-        const V3 dc = unit(mk(fx * S.cam_ax + S.cam_bx, fy * S.cam_ay + S.cam_by, 1.0f));
-        rd = {(S.c2w[0] * dc.x + S.c2w[1] * dc.y) + S.c2w[2] * dc.z,
-              (S.c2w[4] * dc.x + S.c2w[5] * dc.y) + S.c2w[6] * dc.z,
-              (S.c2w[8] * dc.x + S.c2w[9] * dc.y) + S.c2w[10] * dc.z};
-        ro = {S.c2w[3], S.c2w[7], S.c2w[11]};
-        rtmax = kInf;
-        L = {0.f, 0.f, 0.f};
-        beta = {1.f, 1.f, 1.f};
-        specular = false;
-        bounces = 0;
-        state = ST_CLOSEST;
-        if (COUNT) c_cam++;
-      }
-    }
-    if (__ballot(state != ST_DONE) == 0ull) break;
-    if (state != ST_DONE) {
-    HitRec h;
-    const bool any = state == ST_SHADOW;
-    const bool occluded = traverse<SPH, COUNT>(S, ro, rd, rtmax, any, stk, h, c_nodes, c_tris);
-
-    bool advance = false;  // take the prepared bounce (or end the sample)
-    if (any) {
-      if (!occluded) L = L + Lpend;
-      advance = true;
-    } else {
-      const bool hit = h.prim != kNoPrim;
-      V3 p = {0.f, 0.f, 0.f}, ng = {0.f, 0.f, 1.f};
-      float4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
-      const V3 wo = -rd;
-      if (hit) {
-        uint32_t mid;
-        if (!SPH || h.prim < S.n_tris) {
-          const float4 a = S.tris[3 * h.slot], b = S.tris[3 * h.slot + 1], c = S.tris[3 * h.slot + 2];
-          const V3 p0 = xyz(a), p1 = xyz(b), p2 = xyz(c);
-          ng = unit(cross(p1 - p0, p2 - p0));
-          const float w = (1.0f - h.b1) - h.b2;
-          p = (p0 * w + p1 * h.b1) + p2 * h.b2;
-          mid = __float_as_uint(b.w);
+    // ---- service stage: lanes whose walk is over consume the result and launch the next ray ----
+    if (state != ST_DONE && T.cur == kDone) {
+      bool launch = false, launch_any = false;
+      V3 ro = T.o, rd = T.d;
+      float rtmax = kInf;
+      if (state != ST_NEW) {
+        if (SPH) trav_spheres(S, T);
+        bool advance = false;  // take the prepared bounce (or end the sample)
+        if (state == ST_SHADOW) {
+          if (!T.occluded) L = L + Lpend;
+          advance = true;
         } else {
-          const uint32_t si = h.prim - S.n_tris;
-          const float4 cr = S.spheres[2 * si];
-          const V3 c = xyz(cr);
-          const V3 ph = (ro - c) + rd * h.t;
-          ng = ph / cr.w;
-          p = c + ph;
-          mid = __float_as_uint(S.spheres[2 * si + 1].x);
-        }
-        m0 = S.mats[2 * mid];
-        m1 = S.mats[2 * mid + 1];
-      }
-      if (bounces == 0 || specular) {
-        if (hit) {
-          const V3 le = xyz(m1);
-          if ((le.x > 0.f || le.y > 0.f || le.z > 0.f) && dot(ng, wo) > 0.f) L = L + beta * le;
-        } else if (S.has_inf) {
-          L = L + beta * mk(S.le_inf[0], S.le_inf[1], S.le_inf[2]);
-        }
-      }
-      cont = false;
-      bool need_shadow = false;
-      if (hit && bounces < R.max_depth) {
-        const V3 nf = dot(ng, wo) < 0.f ? -ng : ng;
-        const V3 po = p + nf * kSpawnEps;
-        const V3 k = {m0.y, m0.z, m0.w};
-        V3 sh_d = {0.f, 0.f, 1.f};
-        float sh_tmax = kInf;
-        bool alive = true;
-        if (__float_as_uint(m0.x) == 0u) {  // matte
-          if (nL > 0u) {
-            const float xi = pcg_float(rng), u1 = pcg_float(rng), u2 = pcg_float(rng);
-            uint32_t li = (uint32_t)(xi * nLf);
-            if (li > nL - 1u) li = nL - 1u;
-            V3 Ld;
-            if (sample_light(S, li, po, nf, k, u1, u2, nLf, Ld, sh_d, sh_tmax)) {
-              need_shadow = true;
-              Lpend = beta * Ld;
+          const HitRec h = T.h;
+          const bool hit = h.prim != kNoPrim;
+          V3 p = {0.f, 0.f, 0.f}, ng = {0.f, 0.f, 1.f};
+          float4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
+          const V3 wo = -T.d;
+          if (hit) {
+            uint32_t mid;
+            if (!SPH || h.prim < S.n_tris) {
+              const float4 a = S.tris[3 * h.slot], b = S.tris[3 * h.slot + 1], c = S.tris[3 * h.slot + 2];
+              const V3 p0 = xyz(a), p1 = xyz(b), p2 = xyz(c);
+              ng = unit(cross(p1 - p0, p2 - p0));
+              const float w = (1.0f - h.b1) - h.b2;
+              p = (p0 * w + p1 * h.b1) + p2 * h.b2;
+              mid = __float_as_uint(b.w);
+            } else {
+              const uint32_t si = h.prim - S.n_tris;
+              const float4 cr = S.spheres[2 * si];
+              const V3 c = xyz(cr);
+              const V3 ph = (T.o - c) + T.d * h.t;
+              ng = ph / cr.w;
+              p = c + ph;
+              mid = __float_as_uint(S.spheres[2 * si + 1].x);
+            }
+            m0 = S.mats[2 * mid];
+            m1 = S.mats[2 * mid + 1];
+          }
+          if (bounces == 0 || specular) {
+            if (hit) {
+              const V3 le = xyz(m1);
+              if ((le.x > 0.f || le.y > 0.f || le.z > 0.f) && dot(ng, wo) > 0.f) L = L + beta * le;
+            } else if (S.has_inf) {
+              L = L + beta * mk(S.le_inf[0], S.le_inf[1], S.le_inf[2]);
             }
           }
-          if (direct_only) {
-            alive = false;
-          } else {
-            const float u1 = pcg_float(rng), u2 = pcg_float(rng);
-            const float z = cosine_about(nf, u1, u2, wi_next);
-            if (z == 0.f) alive = false;
-            else { beta = beta * k; specular = false; }
+          cont = false;
+          bool need_shadow = false;
+          if (hit && bounces < R.max_depth) {
+            const V3 nf = dot(ng, wo) < 0.f ? -ng : ng;
+            const V3 po = p + nf * kSpawnEps;
+            const V3 k = {m0.y, m0.z, m0.w};
+            V3 sh_d = {0.f, 0.f, 1.f};
+            float sh_tmax = kInf;
+            bool alive = true;
+            if (__float_as_uint(m0.x) == 0u) {  // matte
+              if (nL > 0u) {
+                const float xi = pcg_float(rng), u1 = pcg_float(rng), u2 = pcg_float(rng);
+                uint32_t li = (uint32_t)(xi * nLf);
+                if (li > nL - 1u) li = nL - 1u;
+                V3 Ld;
+                if (sample_light(S, li, po, nf, k, u1, u2, nLf, Ld, sh_d, sh_tmax)) {
+                  need_shadow = true;
+                  Lpend = beta * Ld;
+                }
+              }
+              if (direct_only) {
+                alive = false;
+              } else {
+                const float u1 = pcg_float(rng), u2 = pcg_float(rng);
+                const float z = cosine_about(nf, u1, u2, wi_next);
+                if (z == 0.f) alive = false;
+                else { beta = beta * k; specular = false; }
+              }
+            } else {  // mirror
+              const float c = dot(wo, nf);
+              wi_next = -wo + nf * (2.0f * c);
+              beta = beta * k;
+              specular = true;
+            }
+            if (alive && beta.x == 0.f && beta.y == 0.f && beta.z == 0.f) alive = false;
+            if (alive && bounces > 3u) {
+              const float mx = fmaxf(beta.x, fmaxf(beta.y, beta.z));
+              const float q = fmaxf(0.05f, 1.0f - mx);
+              if (pcg_float(rng) < q) alive = false;
+              else beta = beta / (1.0f - q);
+            }
+            cont = alive;
+            ro = po;  // shadow ray and bounce ray both leave from the offset point
+            if (need_shadow) {
+              rd = sh_d;
+              rtmax = sh_tmax;
+              state = ST_SHADOW;
+              launch = true;
+              launch_any = true;
+              if (COUNT) c_shadow++;
+            }
           }
-        } else {  // mirror
-          const float c = dot(wo, nf);
-          wi_next = -wo + nf * (2.0f * c);
-          beta = beta * k;
-          specular = true;
+          if (!need_shadow) advance = true;
         }
-        if (alive && beta.x == 0.f && beta.y == 0.f && beta.z == 0.f) alive = false;
-        if (alive && bounces > 3u) {
-          const float mx = fmaxf(beta.x, fmaxf(beta.y, beta.z));
-          const float q = fmaxf(0.05f, 1.0f - mx);
-          if (pcg_float(rng) < q) alive = false;
-          else beta = beta / (1.0f - q);
-        }
-        cont = alive;
-        ro = po;  // shadow ray and bounce ray both leave from the offset point
-        if (need_shadow) {
-          rd = sh_d;
-          rtmax = sh_tmax;
-          state = ST_SHADOW;
-          if (COUNT) c_shadow++;
+        if (advance) {
+          bool go = cont;
+          if (go) {
+            bounces++;
+            // a ray at the depth limit can only collect emission, and only after a specular bounce
+            if (bounces >= R.max_depth && !specular) go = false;
+          }
+          if (go) {
+            rd = wi_next;
+            rtmax = kInf;
+            state = ST_CLOSEST;
+            launch = true;
+            launch_any = false;
+            if (COUNT) c_bounce++;
+          } else {
+            // radiance sanitising of SamplerIntegrator::Render, then FilmTile::AddSample (box filter)
+            const float y = (0.212671f * L.x + 0.715160f * L.y) + 0.072169f * L.z;
+            if (isnan(L.x) || isnan(L.y) || isnan(L.z) || y < -1e-5f || isinf(y)) L = {0.f, 0.f, 0.f};
+            sum = sum + L;
+            s++;
+            state = ST_NEW;
+          }
+          cont = false;
         }
       }
-      if (!need_shadow) advance = true;
+      if (state == ST_NEW) {
+        if (s == spp) {
+          state = ST_DONE;
+        } else {
+          // stratified camera sample and PerspectiveCamera ray (3.2)
+          const uint32_t sx = s % R.spp_x, sy = s / R.spp_x;
+          const float u1 = pcg_float(rng), u2 = pcg_float(rng);
+          const float jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
+          const float jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
+          const float fx = (float)px + jx, fy = (float)py + jy;
+          const V3 dc = unit(mk(fx * S.cam_ax + S.cam_bx, fy * S.cam_ay + S.cam_by, 1.0f));
+          rd = {(S.c2w[0] * dc.x + S.c2w[1] * dc.y) + S.c2w[2] * dc.z,
+                (S.c2w[4] * dc.x + S.c2w[5] * dc.y) + S.c2w[6] * dc.z,
+                (S.c2w[8] * dc.x + S.c2w[9] * dc.y) + S.c2w[10] * dc.z};
+          ro = {S.c2w[3], S.c2w[7], S.c2w[11]};
+          rtmax = kInf;
+          L = {0.f, 0.f, 0.f};
+          beta = {1.f, 1.f, 1.f};
+          specular = false;
+          bounces = 0;
+          state = ST_CLOSEST;
+          launch = true;
+          launch_any = false;
+          if (COUNT) c_cam++;
+        }
+      }
+      if (launch) trav_begin<COUNT>(S, T, ro, rd, rtmax, launch_any, c_nodes);
     }
-
-    if (advance) {
-      bool go = cont;
-      if (go) {
-        bounces++;
-        // a ray at the depth limit can only collect emission, and only after a specular bounce
-        if (bounces >= R.max_depth && !specular) go = false;
-      }
-      if (go) {
-        rd = wi_next;
-        rtmax = kInf;
-        state = ST_CLOSEST;
-        if (COUNT) c_bounce++;
-      } else {
-        // radiance sanitising of SamplerIntegrator::Render, then FilmTile::AddSample (box filter)
-        const float y = (0.212671f * L.x + 0.715160f * L.y) + 0.072169f * L.z;
-        if (isnan(L.x) || isnan(L.y) || isnan(L.z) || y < -1e-5f || isinf(y)) L = {0.f, 0.f, 0.f};
-        sum = sum + L;
-        s++;
-        state = ST_NEW;
-      }
-      cont = false;
-    }
-    }  // state != ST_DONE
+    if (__ballot(state != ST_DONE) == 0ull) break;
+    trav_run<COUNT>(S, T, stk, stkt, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
   if (valid) {
@@ -509,25 +658,55 @@ __global__ void __launch_bounds__(256) render_kernel(const DevScene S, const Ren
   }
 }
 
+// The traversal loop alone over a ray batch, as persistent waves with dynamic fetch: a lane whose
+// walk is over writes its result and pulls its next ray while the other lanes keep walking.
 template <bool SPH, bool COUNT, int STACK>
 __global__ void __launch_bounds__(256) intersect_kernel(const DevScene S, const RayBatch B, const int any_hit) {
   __shared__ uint32_t lds_stack[4][STACK][64];
+  __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *stk = &lds_stack[wave][0][lane];
+  float *stkt = &lds_tn[COUNT ? wave : 0][0][lane];
+  const TravTuning tune = {B.min_walkers, B.min_parked};
   unsigned long long cn = 0, ct = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B.n; i += (int64_t)gridDim.x * 256) {
-    const V3 o = {B.o[3 * i], B.o[3 * i + 1], B.o[3 * i + 2]};
-    const V3 d = {B.d[3 * i], B.d[3 * i + 1], B.d[3 * i + 2]};
-    HitRec h;
-    const bool occ = traverse<SPH, COUNT>(S, o, d, B.tmax[i], any_hit != 0, stk, h, cn, ct);
-    if (any_hit) {
-      B.occluded[i] = occ ? 1 : 0;
-    } else {
-      B.t[i] = h.t;
-      B.prim[i] = h.prim;
-      B.b1[i] = h.b1;
-      B.b2[i] = h.b2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t next = (int64_t)blockIdx.x * 256 + threadIdx.x, idx = 0;
+  bool have = false;
+  Trav T;
+  T.o = mk(0.f, 0.f, 0.f);
+  T.d = mk(0.f, 0.f, 1.f);
+  T.tmax = 0.f;
+  T.cur = kDone;
+  T.sp = 0;
+  T.leaf_off = 0;
+  T.leaf_cnt = 0;
+  T.any = 0;
+  T.occluded = 0;
+  T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
+  for (;;) {
+    if (T.cur == kDone) {
+      if (have) {
+        if (SPH) trav_spheres(S, T);
+        if (any_hit) {
+          B.occluded[idx] = T.occluded ? 1 : 0;
+        } else {
+          B.t[idx] = T.h.t;
+          B.prim[idx] = T.h.prim;
+          B.b1[idx] = T.h.b1;
+          B.b2[idx] = T.h.b2;
+        }
+        have = false;
+      }
+      if (next < B.n) {
+        idx = next;
+        next += stride;
+        trav_begin<COUNT>(S, T, mk(B.o[3 * idx], B.o[3 * idx + 1], B.o[3 * idx + 2]),
+                          mk(B.d[3 * idx], B.d[3 * idx + 1], B.d[3 * idx + 2]), B.tmax[idx], any_hit != 0, cn);
+        have = true;
+      }
     }
+    if (__ballot(have) == 0ull) break;
+    trav_run<COUNT>(S, T, stk, stkt, have, tune, cn, ct);
   }
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {

@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Tiny driver for rocprofv3 --pmc passes: builds a BASELINE scene and renders it once at a low
+sample count (no torch, no baseline leg).  usage: pmc_probe.py [c2|c3] [spp_x spp_y]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pbrt_amd  # noqa: E402
+from pbrt_amd import scenes  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+spp = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2, 2)
+n, res = (1_000_000, 2048) if wl == "c3" else (100_000, 1024)
+sd = scenes.random_mesh_scene(n, res, res)
+with pbrt_amd.Scene(sd) as sc:
+    film, st = sc.render(max_depth=8, spp=spp, seed=0)
+    print(wl, spp, "kernel_ms", st["kernel_ms"], "Msamples/s", st["samples"] / st["kernel_ms"] / 1e3)
