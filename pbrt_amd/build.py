@@ -33,8 +33,9 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     if not force and _newer(LIB_PATH, deps):
         return LIB_PATH
     objs = []
+    extra_flags = list(extra_flags) + os.environ.get("PBRT_HIP_EXTRA_FLAGS", "").split()
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-              "-Wno-unused-function", f"--offload-arch={ARCH}"] + list(extra_flags)
+              "-Wno-unused-function", f"--offload-arch={ARCH}"] + extra_flags
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
         cmd = [HIPCC] + common + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]

@@ -162,10 +162,8 @@ constexpr uint32_t kLeafRef = 0x80000000u;  // ref = kLeafRef | n_prims << 24 | 
 struct Trav {
   V3 o, d;
   float tmax;
-  uint32_t cur;       // interior ref to process next; kDone when the walk is over
+  uint32_t cur;       // ref to process next: interior = step, leaf = the lane is PARKED there; kDone = walk over
   uint32_t sp;        // LDS stack entries in use
-  uint32_t leaf_off;  // first slot of the leaf this lane is parked at
-  uint32_t leaf_cnt;  // triangles in that leaf; 0 = not parked
   uint32_t any;       // any-hit (shadow) ray
   uint32_t occluded;  // any-hit result
   HitRec h;           // closest-hit result
@@ -210,13 +208,9 @@ __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt
   return stk[T.sp * 64u];
 }
 
-__device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) {
-  if (ref != kDone && (ref & kLeafRef)) {  // park at the leaf
-    T.leaf_off = ref & 0xffffffu;
-    T.leaf_cnt = (ref >> 24) & 0x7fu;
-  }
-  T.cur = ref;
-}
+__device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) { T.cur = ref; }
+__device__ __forceinline__ bool trav_parked(const Trav &T) { return T.cur != kDone && (T.cur & kLeafRef) != 0u; }
+__device__ __forceinline__ uint32_t trav_leaf_cnt(const Trav &T) { return trav_parked(T) ? (T.cur >> 24) & 0x7fu : 0u; }
 
 template <bool EXACT>
 __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 d, float tmax, bool any,
@@ -225,8 +219,6 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 
   T.d = d;
   T.tmax = tmax;
   T.sp = 0;
-  T.leaf_off = 0;
-  T.leaf_cnt = 0;
   T.any = any ? 1u : 0u;
   T.occluded = 0;
   T.h.t = kInf;
@@ -275,7 +267,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     if (mwalk == 0ull) break;
     if ((uint32_t)__popcll(mwalk) < tune.min_walkers && __ballot(!walking && alive) != 0ull) break;
 
-    if (walking && T.leaf_cnt == 0u) {
+    if (walking && !trav_parked(T)) {
       // ---- one step: both children of interior node T.cur ----
       const uint32_t off = T.cur * 64u;
       const uint4 q0 = *reinterpret_cast<const uint4 *>(nodes + off);
@@ -307,14 +299,16 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     }
 
     // ---- leaf flush (wave-uniform decision) ----
-    const unsigned long long mleaf = __ballot(T.leaf_cnt != 0u);
+    const bool parked = trav_parked(T);
+    const unsigned long long mleaf = __ballot(parked);
     if (mleaf != 0ull &&
-        ((uint32_t)__popcll(mleaf) >= tune.min_parked || __ballot(T.cur != kDone && T.leaf_cnt == 0u) == 0ull)) {
-      const bool parked = T.leaf_cnt != 0u;
+        ((uint32_t)__popcll(mleaf) >= tune.min_parked || __ballot(T.cur != kDone && !parked) == 0ull)) {
+      const uint32_t cnt = parked ? (T.cur >> 24) & 0x7fu : 0u, first = T.cur & 0xffffffu;
+      bool stop = false;  // any-hit ray found its hit
       for (uint32_t i = 0;; i++) {
-        if (__ballot(T.leaf_cnt > i) == 0ull) break;
-        if (T.leaf_cnt > i) {
-          const uint32_t slot = T.leaf_off + i;
+        if (__ballot(cnt > i && !stop) == 0ull) break;
+        if (cnt > i && !stop) {
+          const uint32_t slot = first + i;
           const float4 a = *reinterpret_cast<const float4 *>(tris + slot * 48u);
           const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
           const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
@@ -334,9 +328,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
             if ((u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax)) {
               if (T.any) {
                 T.occluded = 1u;  // the walk ends at the first valid hit
-                T.leaf_cnt = 0u;
-                T.cur = kDone;
-                T.sp = 0u;
+                stop = true;
               } else {
                 const uint32_t id = __float_as_uint(a.w);
                 if (th < T.h.t || (th == T.h.t && id < T.h.prim)) {
@@ -347,9 +339,13 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           }
         }
       }
-      if (parked && T.cur != kDone) {  // leave the leaf: next node from the stack
-        T.leaf_cnt = 0u;
-        trav_enter(T, trav_pop<EXACT>(T, stk, stkt, cn));
+      if (parked) {  // leave the leaf: the walk is over (any-hit found) or the next node comes off the stack
+        if (stop) {
+          T.cur = kDone;
+          T.sp = 0u;
+        } else {
+          trav_enter(T, trav_pop<EXACT>(T, stk, stkt, cn));
+        }
       }
     }
   }
@@ -435,8 +431,13 @@ __device__ __forceinline__ bool sample_light(const DevScene &S, uint32_t li, V3 
 
 enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3 };
 
+// waves per SIMD the register allocator must leave room for (launch_bounds' 2nd argument)
+#ifndef PBRT_RENDER_WAVES_PER_SIMD
+#define PBRT_RENDER_WAVES_PER_SIMD 4
+#endif
+
 template <bool SPH, bool COUNT, int STACK>
-__global__ void __launch_bounds__(256) render_kernel(const DevScene S, const RenderParams R) {
+__global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel(const DevScene S, const RenderParams R) {
   __shared__ uint32_t lds_stack[4][STACK][64];
   __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];  // entry distances: exact walk only
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -475,8 +476,6 @@ __global__ void __launch_bounds__(256) render_kernel(const DevScene S, const Ren
   T.tmax = 0.f;
   T.cur = kDone;
   T.sp = 0;
-  T.leaf_off = 0;
-  T.leaf_cnt = 0;
   T.any = 0;
   T.occluded = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
@@ -678,8 +677,6 @@ __global__ void __launch_bounds__(256) intersect_kernel(const DevScene S, const 
   T.tmax = 0.f;
   T.cur = kDone;
   T.sp = 0;
-  T.leaf_off = 0;
-  T.leaf_cnt = 0;
   T.any = 0;
   T.occluded = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
