@@ -125,17 +125,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or pbrt_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: pbrt_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; PBRT_DIST_BACKEND=gloo lets several ranks share one GPU (test boxes with a single device)
+    backend = os.environ.get("PBRT_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s): RCCL needs one GPU per rank")
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     (kind, n, res), integrator, depth, spp, descr = WORKLOADS[args.workload]
     if args.spp:
         spp = tuple(args.spp)
     t0 = time.time()
     sd = make_scene_data(kind, n, res)
-    scene = pbrt_amd.Scene(sd, device=local_rank)
+    scene = pbrt_amd.Scene(sd, device=device_index)
     info = scene.info()
     build_s = time.time() - t0
     kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=0)
@@ -163,7 +171,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     total_samples = res * res * spp[0] * spp[1]

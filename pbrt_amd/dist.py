@@ -45,8 +45,11 @@ def gather_film(local_slab, xres, yres, crop, rank, world_size, group=None):
     import torch
     import torch.distributed as dist
     n = max_slab_slots(xres, yres, crop, world_size)
-    send = torch.zeros(n, 4, dtype=torch.float32, device=local_slab.device)
-    send[: local_slab.shape[0]] = local_slab
+    dev = local_slab.device
+    if world_size > 1 and dist.get_backend(group) == "gloo":
+        dev = torch.device("cpu")  # gloo cannot gather device tensors: stage through the host
+    send = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+    send[: local_slab.shape[0]] = local_slab.to(dev)
     if world_size == 1:
         return assemble_film([send], xres, yres, crop, 1)
     recv = [torch.empty_like(send) for _ in range(world_size)] if rank == 0 else None
