@@ -79,7 +79,10 @@ typedef struct {
 
 #define PBRT_HIP_INTEGRATOR_PATH 0   /* Integrator "path" (default name, api.rs:239) */
 #define PBRT_HIP_INTEGRATOR_DIRECT 1 /* Integrator "directlighting" */
-#define PBRT_HIP_FLAG_COUNTERS 1u    /* also count nodes visited / triangles tested (slower) */
+#define PBRT_HIP_FLAG_COUNTERS 1u    /* count nodes visited / triangles tested of the canonical walk:
+                                        runs the exact-order instantiation of the kernel, equal to the oracle's counters */
+#define PBRT_HIP_FLAG_WALK_COUNTERS 2u /* count what the production kernel itself does instead: nodes_visited = 64-byte
+                                        child-pair records fetched, tris_tested = triangles tested */
 
 typedef struct {
   uint32_t integrator;

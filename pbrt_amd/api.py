@@ -15,6 +15,7 @@ MATTE, MIRROR = 0, 1
 LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
 FLAG_COUNTERS = 1
+FLAG_WALK_COUNTERS = 2
 
 
 def _fp(a):
@@ -218,9 +219,10 @@ class Scene:
 
     def render(self, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
                counters=False):
-        """-> (film[h, w, 4] float32 {X, Y, Z, weight}, stats dict)."""
+        """-> (film[h, w, 4] float32 {X, Y, Z, weight}, stats dict).  counters: False, True (canonical
+        walk, equal to the oracle's counters) or "walk" (what the production kernel itself fetches / tests)."""
         r = make_render_desc(RenderDesc, integrator, max_depth, spp, seed, rank, world_size,
-                             FLAG_COUNTERS if counters else 0)
+                             FLAG_WALK_COUNTERS if counters == "walk" else (FLAG_COUNTERS if counters else 0))
         w, h = self.sd.crop_size()
         film = np.zeros((h, w, 4), np.float32)
         st = Stats()
@@ -230,7 +232,7 @@ class Scene:
     def render_device(self, d_slab_ptr, stream_ptr=None, **kw):
         """Asynchronous render into a device slab (e.g. a torch tensor's data_ptr())."""
         counters = kw.pop("counters", False)
-        r = make_render_desc(RenderDesc, flags=FLAG_COUNTERS if counters else 0, **kw)
+        r = make_render_desc(RenderDesc, flags=FLAG_WALK_COUNTERS if counters == "walk" else (FLAG_COUNTERS if counters else 0), **kw)
         check(lib().pbrt_hip_render_device(self._h, C.byref(r), C.c_void_p(d_slab_ptr), C.c_void_p(stream_ptr or 0)),
               "pbrt_hip_render_device")
 

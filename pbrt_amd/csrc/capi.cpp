@@ -393,13 +393,13 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.counters = s->d_counters.p;
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
-    const bool counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) != 0;
+    const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);
     if (counters) HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 5 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
     HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
-    s->pending_counters = counters;
+    s->pending_counters = counters != 0;
     // samples = pixels of this rank's super-tiles that lie inside the film
     uint64_t px = 0;
     for (uint32_t j = 0; j < sh.n_local; j++) {

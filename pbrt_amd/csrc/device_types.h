@@ -56,7 +56,7 @@ struct RayBatch {
 
 // launchers (kernels.hip)
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         bool counters, hipStream_t stream);
+                         int counters /* 0 none, 1 exact walk, 2 production walk */, hipStream_t stream);
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);

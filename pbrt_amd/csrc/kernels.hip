@@ -198,7 +198,7 @@ __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt
       T.sp--;
       const uint32_t ref = stk[T.sp * 64u];
       const float tn = stkt[T.sp * 64u];
-      cn++;
+      cn++;  // EXACT implies counting
       if (tn <= fminf(T.h.t, T.tmax) * kBoxPad) return ref;
     }
     return kDone;
@@ -253,7 +253,7 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 
 //     lanes keep their state and resume on the next call.
 // `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
 // caller once its walk is over.
-template <bool EXACT>
+template <bool EXACT, bool COUNT>
 __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, const bool alive,
                                          const TravTuning tune, unsigned long long &cn, unsigned long long &ct) {
   const V3 o = T.o, d = T.d;
@@ -286,6 +286,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const bool far_first = axis == 0u ? negx : (axis == 1u ? negy : negz);  // child 1 is the near one
       const uint32_t ref_near = far_first ? q3.y : q3.x, ref_far = far_first ? q3.x : q3.y;
       const bool hit_near = far_first ? hit1 : hit0, hit_far = far_first ? hit0 : hit1;
+      if (COUNT && !EXACT) cn++;  // production walk: one 64-byte fetch
       if (EXACT) {
         cn++;  // the near child is visited now; the far one when it is popped
         stk[T.sp * 64u] = ref_far;
@@ -312,7 +313,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const float4 a = *reinterpret_cast<const float4 *>(tris + slot * 48u);
           const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
           const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
-          if (EXACT) ct++;
+          if (COUNT) ct++;
           // Moeller-Trumbore, operation order of DESIGN.md 3.5
           const V3 p0 = xyz(a);
           const V3 e1 = xyz(b) - p0, e2 = xyz(c) - p0;
@@ -436,13 +437,16 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3 };
 #define PBRT_RENDER_WAVES_PER_SIMD 4
 #endif
 
-template <bool SPH, bool COUNT, int STACK>
+// COUNT: accumulate ray / visit counters.  EXACT (needs COUNT): walk the tree in exactly the oracle's
+// order so that the counters are the oracle's; COUNT without EXACT counts the production walk itself
+// (64-byte fetches and triangle tests).
+template <bool SPH, bool COUNT, bool EXACT, int STACK>
 __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel(const DevScene S, const RenderParams R) {
   __shared__ uint32_t lds_stack[4][STACK][64];
-  __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];  // entry distances: exact walk only
+  __shared__ float lds_tn[EXACT ? 4 : 1][EXACT ? STACK : 1][64];  // entry distances: exact walk only
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *stk = &lds_stack[wave][0][lane];
-  float *stkt = &lds_tn[COUNT ? wave : 0][0][lane];
+  float *stkt = &lds_tn[EXACT ? wave : 0][0][lane];
 
   // block -> (local super-tile, 16x16 tile inside it); wave -> 8x8 quadrant; lane -> pixel
   const int32_t W = S.cx1 - S.cx0, H = S.cy1 - S.cy0;
@@ -632,10 +636,10 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
           if (COUNT) c_cam++;
         }
       }
-      if (launch) trav_begin<COUNT>(S, T, ro, rd, rtmax, launch_any, c_nodes);
+      if (launch) trav_begin<EXACT>(S, T, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
-    trav_run<COUNT>(S, T, stk, stkt, state != ST_DONE, tune, c_nodes, c_tris);
+    trav_run<EXACT, COUNT>(S, T, stk, stkt, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
   if (valid) {
@@ -703,7 +707,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(const DevScene S, const 
       }
     }
     if (__ballot(have) == 0ull) break;
-    trav_run<COUNT>(S, T, stk, stkt, have, tune, cn, ct);
+    trav_run<COUNT, COUNT>(S, T, stk, stkt, have, tune, cn, ct);
   }
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -741,23 +745,27 @@ __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int
 
 }  // namespace
 
-template <bool SPH, bool COUNT>
+template <bool SPH, bool COUNT, bool EXACT>
 static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t depth,
                                   hipStream_t st) {
   const dim3 grid(n_local_super * 16u), block(256);
-  if (depth <= 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, 32>), grid, block, 0, st, S, R);
-  else hipLaunchKernelGGL((render_kernel<SPH, COUNT, 64>), grid, block, 0, st, S, R);
+  if (depth <= 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);
+  else hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
   return hipGetLastError();
 }
 
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         bool counters, hipStream_t stream) {
+                         int counters, hipStream_t stream) {
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
-  if (sph) return counters ? launch_render_t<true, true>(S, R, n_local_super, bvh_depth, stream)
-                           : launch_render_t<true, false>(S, R, n_local_super, bvh_depth, stream);
-  return counters ? launch_render_t<false, true>(S, R, n_local_super, bvh_depth, stream)
-                  : launch_render_t<false, false>(S, R, n_local_super, bvh_depth, stream);
+  if (counters == 1)
+    return sph ? launch_render_t<true, true, true>(S, R, n_local_super, bvh_depth, stream)
+               : launch_render_t<false, true, true>(S, R, n_local_super, bvh_depth, stream);
+  if (counters == 2)
+    return sph ? launch_render_t<true, true, false>(S, R, n_local_super, bvh_depth, stream)
+               : launch_render_t<false, true, false>(S, R, n_local_super, bvh_depth, stream);
+  return sph ? launch_render_t<true, false, false>(S, R, n_local_super, bvh_depth, stream)
+             : launch_render_t<false, false, false>(S, R, n_local_super, bvh_depth, stream);
 }
 
 template <bool SPH, bool COUNT>

@@ -15,3 +15,9 @@ sd = scenes.random_mesh_scene(n, res, res)
 with pbrt_amd.Scene(sd) as sc:
     film, st = sc.render(max_depth=8, spp=spp, seed=0)
     print(wl, spp, "kernel_ms", st["kernel_ms"], "Msamples/s", st["samples"] / st["kernel_ms"] / 1e3)
+    if os.environ.get("PROBE_COUNTERS"):
+        _, ex = sc.render(max_depth=8, spp=spp, seed=0, counters=True)
+        _, wk = sc.render(max_depth=8, spp=spp, seed=0, counters="walk")
+        rays = ex["camera_rays"] + ex["bounce_rays"] + ex["shadow_rays"]
+        print("exact: nodes/ray %.1f tris/ray %.2f | production walk: fetches/ray %.1f tris/ray %.2f" % (
+            ex["nodes_visited"] / rays, ex["tris_tested"] / rays, wk["nodes_visited"] / rays, wk["tris_tested"] / rays))
