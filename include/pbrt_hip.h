@@ -160,6 +160,27 @@ int pbrt_hip_write_image(const char *name, const float *rgb, int32_t width, int3
 /* Transform::look_at (transform.rs:485-520): m = world->camera, m_inv = camera->world */
 void pbrt_hip_look_at(const float pos[3], const float look[3], const float up[3], float m[16], float m_inv[16]);
 
+/* ---- scene ingestion: the reference's parser + API state machine, completed for this path ----
+ * (parser.rs:205-317 handles 12 of 37 directive arms; api.rs stores no geometry.)  Host only.
+ * Status codes: 0 ok; PBRT_HIP_ERR_INVALID with last_error() = "<kind>: <detail>", kind in
+ * {Eof, UnterminatedString, MixedParameters, Unquoted, Syntax, NotImplemented, Io} (parser.rs:31-58). */
+typedef struct pbrt_hip_loaded pbrt_hip_loaded;
+int pbrt_hip_load_file(const char *path, pbrt_hip_loaded **out);
+int pbrt_hip_load_string(const char *text, size_t len, const char *base_dir /* for Include, may be NULL */,
+                         pbrt_hip_loaded **out);
+void pbrt_hip_loaded_free(pbrt_hip_loaded *loaded);
+/* desc / render are filled with pointers INTO `loaded` (valid until it is freed); filename = Film "string filename" */
+int pbrt_hip_loaded_get(const pbrt_hip_loaded *loaded, pbrt_hip_scene_desc *desc, pbrt_hip_render_desc *render,
+                        char *filename, size_t filename_cap);
+/* warnings (ignored directives / parameters, api.rs:291-332 "log and continue"), '\n'-separated; returns their count */
+int pbrt_hip_loaded_warnings(const pbrt_hip_loaded *loaded, char *buf, size_t cap);
+/* CTM (current_transform[0].m) when parsing stopped, and the directive names stored by the option setters
+ * (api.rs:778-820) as "camera sampler integrator filter accelerator film" */
+int pbrt_hip_loaded_state(const pbrt_hip_loaded *loaded, float ctm[16], char *names, size_t names_cap);
+/* the tokenizer alone (parser.rs:61-170): tokens '\n'-separated into buf; returns the token count, or
+ * -(1 + count) when the stream ends in an error (EOF / newline inside a quoted string) after `count` tokens */
+int pbrt_hip_tokenize(const char *text, size_t len, char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,13 @@ SYMBOLS = {
     "pbrt_hip_film_to_rgb": (None, [_pf, _i64, _f, _pf]),
     "pbrt_hip_write_image": (C.c_int, [C.c_char_p, _pf, _i32, _i32]),
     "pbrt_hip_look_at": (None, [_pf, _pf, _pf, _pf, _pf]),
+    "pbrt_hip_load_file": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "pbrt_hip_load_string": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(_vp)]),
+    "pbrt_hip_loaded_free": (None, [_vp]),
+    "pbrt_hip_loaded_get": (C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(RenderDesc), C.c_char_p, C.c_size_t]),
+    "pbrt_hip_loaded_warnings": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "pbrt_hip_loaded_state": (C.c_int, [_vp, _pf, C.c_char_p, C.c_size_t]),
+    "pbrt_hip_tokenize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
 }
 
 _lib = None

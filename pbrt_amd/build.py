@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpbrt_hip.so")
-SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "kernels.hip"]
+SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

@@ -16,6 +16,7 @@
 #include "bvh_build.hpp"
 #include "device_types.h"
 #include "host_math.hpp"
+#include "scene_parser.hpp"
 
 using namespace pbrt_hip;
 
@@ -620,6 +621,126 @@ void pbrt_hip_film_to_rgb(const float *film, int64_t n, float scale, float *rgb)
 
 void pbrt_hip_look_at(const float pos[3], const float look[3], const float up[3], float m[16], float m_inv[16]) {
   look_at(pos, look, up, m, m_inv);
+}
+
+}  // extern "C"
+
+// ---- scene ingestion (scene_parser.cpp) ----
+struct pbrt_hip_loaded {
+  pbrt_hip::LoadedScene s;
+};
+
+namespace {
+const char *parse_error_name(pbrt_hip::ParseError e) {
+  switch (e) {
+    case pbrt_hip::ParseError::Eof: return "Eof";
+    case pbrt_hip::ParseError::UnterminatedString: return "UnterminatedString";
+    case pbrt_hip::ParseError::MixedParameters: return "MixedParameters";
+    case pbrt_hip::ParseError::Unquoted: return "Unquoted";
+    case pbrt_hip::ParseError::Syntax: return "Syntax";
+    case pbrt_hip::ParseError::NotImplemented: return "NotImplemented";
+    case pbrt_hip::ParseError::Io: return "Io";
+    default: return "None";
+  }
+}
+size_t copy_out(const std::string &s, char *buf, size_t cap) {
+  if (buf && cap) {
+    size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return s.size();
+}
+}  // namespace
+
+extern "C" {
+
+int pbrt_hip_load_string(const char *text, size_t len, const char *base_dir, pbrt_hip_loaded **out) {
+  if (!text || !out) return fail(PBRT_HIP_ERR_INVALID, "load_string: null argument");
+  *out = nullptr;
+  try {
+    std::unique_ptr<pbrt_hip_loaded> l(new pbrt_hip_loaded());
+    std::string msg;
+    pbrt_hip::ParseError e = pbrt_hip::parse_scene(text, len, base_dir ? base_dir : "", &l->s, &msg);
+    if (e != pbrt_hip::ParseError::None) return fail(PBRT_HIP_ERR_INVALID, std::string(parse_error_name(e)) + ": " + msg);
+    *out = l.release();
+    return PBRT_HIP_OK;
+  } catch (const std::exception &e) {
+    return fail(PBRT_HIP_ERR_INTERNAL, e.what());
+  }
+}
+
+int pbrt_hip_load_file(const char *path, pbrt_hip_loaded **out) {
+  if (!path || !out) return fail(PBRT_HIP_ERR_INVALID, "load_file: null argument");
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(PBRT_HIP_ERR_INVALID, std::string("Io: cannot open '") + path + "'");  // api.rs:392-395
+  std::string text;
+  char buf[65536];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+  std::fclose(f);
+  std::string p(path);
+  size_t slash = p.rfind('/');
+  std::string dir = slash == std::string::npos ? "" : p.substr(0, slash);
+  return pbrt_hip_load_string(text.data(), text.size(), dir.c_str(), out);
+}
+
+void pbrt_hip_loaded_free(pbrt_hip_loaded *l) { delete l; }
+
+int pbrt_hip_loaded_get(const pbrt_hip_loaded *l, pbrt_hip_scene_desc *d, pbrt_hip_render_desc *r, char *filename,
+                        size_t cap) {
+  if (!l) return fail(PBRT_HIP_ERR_INVALID, "loaded_get: null scene");
+  const pbrt_hip::LoadedScene &s = l->s;
+  if (d) {
+    std::memset(d, 0, sizeof *d);
+    d->P = s.P.data(); d->idx = s.idx.data(); d->mat_id = s.mat_id.data();
+    d->mats = s.mats.data(); d->lights = s.lights.data(); d->spheres = s.spheres.data();
+    d->n_verts = (uint32_t)(s.P.size() / 3); d->n_tris = (uint32_t)s.mat_id.size(); d->n_mats = (uint32_t)s.mats.size();
+    d->n_lights = (uint32_t)s.lights.size(); d->n_spheres = (uint32_t)s.spheres.size();
+    std::memcpy(d->cam_to_world, s.cam_to_world, 64);
+    d->fov = s.fov; d->xres = s.xres; d->yres = s.yres;
+    std::memcpy(d->crop, s.crop, 16);
+  }
+  if (r) {
+    std::memset(r, 0, sizeof *r);
+    r->integrator = s.integrator; r->max_depth = s.max_depth; r->spp_x = s.spp_x; r->spp_y = s.spp_y;
+    r->seed = 0; r->rank = 0; r->world_size = 1;
+  }
+  copy_out(s.filename, filename, cap);
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_loaded_warnings(const pbrt_hip_loaded *l, char *buf, size_t cap) {
+  if (!l) return 0;
+  std::string all;
+  for (const std::string &w : l->s.warnings) { all += w; all += '\n'; }
+  copy_out(all, buf, cap);
+  return (int)l->s.warnings.size();
+}
+
+int pbrt_hip_loaded_state(const pbrt_hip_loaded *l, float ctm[16], char *names, size_t cap) {
+  if (!l) return fail(PBRT_HIP_ERR_INVALID, "loaded_state: null scene");
+  const pbrt_hip::LoadedScene &s = l->s;
+  if (ctm) std::memcpy(ctm, s.final_ctm, 64);
+  copy_out(s.camera_name + " " + s.sampler_name + " " + s.integrator_name + " " + s.filter_name + " " +
+               s.accelerator_name + " " + s.film_name, names, cap);
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_tokenize(const char *text, size_t len, char *buf, size_t cap) {
+  if (!text) return -1;
+  pbrt_hip::Tokenizer t(text, len);
+  std::string tok, all;
+  int n = 0;
+  pbrt_hip::ParseError e;
+  while (t.next(&tok, &e)) {
+    if (e != pbrt_hip::ParseError::None) { copy_out(all, buf, cap); return -(1 + n); }
+    all += tok;
+    all += '\n';
+    n++;
+  }
+  copy_out(all, buf, cap);
+  return n;
 }
 
 }  // extern "C"

@@ -1,0 +1,146 @@
+"""Scene ingestion: the C++ tokenizer / parameter lists / API state machine
+against the reference's own parser and api tests (src/core/parser.rs:778-880, src/core/api.rs:979-1045)
+and against BASELINE config C0's scene.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import pbrt_amd
+from pbrt_amd import loader
+from pbrt_amd._lib import PbrtHipError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+C0 = os.path.join(ROOT, "scenes", "c0_check_sphere.pbrt")
+
+
+def test_tokenizer():  # parser.rs:778-791
+    toks, ok = loader.tokenize('Sampler "halton" "integer pixelsamples" 128')
+    assert ok and toks == ["Sampler", '"halton"', '"integer pixelsamples"', "128"]
+    toks, ok = loader.tokenize('Sampler "128')  # EOF inside a quoted string -> Error::EOF after "Sampler"
+    assert not ok and toks == ["Sampler"]
+    toks, ok = loader.tokenize('"a\nb"')  # parser.rs:80 UnterminatedString
+    assert not ok
+    toks, ok = loader.tokenize("Shape [1 2]# trailing comment\n  Next")  # brackets split, comments are tokens
+    assert ok and toks == ["Shape", "[", "1", "2", "]", "# trailing comment", "Next"]
+    assert loader.tokenize("") == ([], True)
+
+
+def test_parser_accepts_the_reference_parser_test_input():  # parser.rs:793-800
+    ls = loader.load_string('Sampler "halton" "integer pixelsamples" 128')
+    assert ls.names["sampler"] == "halton" and ls.spp == (16, 8) and ls.spp[0] * ls.spp[1] == 128
+
+
+def test_param_lists():  # parser.rs:803-866: the three basic_param_list_entrypoint cases, seen through their effects
+    ls = loader.load_string('Camera "perspective" "float fov" 45')
+    assert ls.names["camera"] == "perspective" and ls.scene.fov == 45.0
+    mesh = ('WorldBegin Shape "trianglemesh" "integer indices" [ 0 1 2 2 3 0 ] "point P" '
+            '[-0.5 -0.5 0.5 -0.5 -0.5 -0.5 0.5 -0.5 -0.5 0.5 -0.5 0.5] WorldEnd')
+    ls = loader.load_string(mesh)
+    assert ls.scene.idx.tolist() == [[0, 1, 2], [2, 3, 0]]
+    assert ls.scene.P.tolist() == [[-0.5, -0.5, 0.5], [-0.5, -0.5, -0.5], [0.5, -0.5, -0.5], [0.5, -0.5, 0.5]]
+    tex = ('WorldBegin Texture "t" "spectrum" "imagemap"\n "string filename" ["textures/BeoCom.png"]\n'
+           ' "float scale" [1.000000]\n "vector v1" [0.500000 0.000000 0.000000]\n WorldEnd')
+    ls = loader.load_string(tex)  # parses; image maps are out of scope -> one warning, no error
+    assert any("imagemap" in w for w in ls.warnings)
+
+
+def test_param_errors():  # parser.rs:31-58 Error kinds
+    for text, kind in [('Camera "perspective" "float fov" [45 "x"]', "MixedParameters"),
+                       ("Camera perspective", "Unquoted"), ("Bogus 1 2 3", "Syntax"), ("LookAt 1 2 x", "Syntax"),
+                       ('ObjectBegin "a"', "NotImplemented"), ('Include "does/not/exist.pbrt"', "Io"),
+                       ('Camera "perspective" "float fov" [45', "Eof"), ("LookAt 1 2 3", "Eof")]:
+        with pytest.raises(PbrtHipError) as e:
+            loader.load_string(text)
+        assert e.value.code == -1 and f" {kind}:" in str(e.value), (text, str(e.value))
+
+
+def test_named_coordinate_systems():  # api.rs:979-1020
+    ls = loader.load_string('Identity Scale 2 2 2 CoordinateSystem "two" Identity Scale 3 3 3')
+    assert np.array_equal(ls.ctm, np.diag([3, 3, 3, 1]).astype(np.float32))
+    ls = loader.load_string('Identity Scale 2 2 2 CoordinateSystem "two" Identity Scale 3 3 3 CoordSysTransform "two"')
+    assert np.array_equal(ls.ctm, np.diag([2, 2, 2, 1]).astype(np.float32))
+    ls = loader.load_string('Scale 2 2 2 CoordSysTransform "nope"')  # api.rs:727-730: warn, keep the CTM
+    assert np.array_equal(ls.ctm, np.diag([2, 2, 2, 1]).astype(np.float32)) and any("nope" in w for w in ls.warnings)
+
+
+def test_attribute_and_transform_stacks():  # api.rs:1022-1045 + :481-522
+    ls = loader.load_string("WorldBegin AttributeBegin ActiveTransform StartTime Translate 1 2 3 AttributeEnd Scale 2 2 2")
+    assert np.array_equal(ls.ctm, np.diag([2, 2, 2, 1]).astype(np.float32))  # translate popped, active bits restored
+    ls = loader.load_string("WorldBegin TransformBegin Translate 1 2 3 TransformEnd Translate 0 0 5")
+    assert np.array_equal(ls.ctm[:3, 3], np.array([0, 0, 5], np.float32))
+    ls = loader.load_string("WorldBegin AttributeEnd TransformEnd")  # unmatched: logged and ignored (api.rs:497-500)
+    assert sum("Unmatched" in w for w in ls.warnings) == 2
+    ls = loader.load_string("AttributeBegin")  # verify_world!: outside the world block -> ignored
+    assert any("world block" in w for w in ls.warnings)
+    ls = loader.load_string('WorldBegin Camera "perspective"')  # verify_options!
+    assert any("options block" in w for w in ls.warnings)
+
+
+def test_ctm_ops_match_the_transform_doctests():  # transform.rs:360-443,524-538 through the directives
+    ls = loader.load_string("Translate 2 4 6")
+    assert np.array_equal(ls.ctm, np.array([[1, 0, 0, 2], [0, 1, 0, 4], [0, 0, 1, 6], [0, 0, 0, 1]], np.float32))
+    ls = loader.load_string("Rotate 180 0 0 1")
+    c, s = np.float32(np.cos(np.float32(np.pi))), np.float32(np.sin(np.float32(np.pi)))
+    assert np.allclose(ls.ctm, np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]), atol=1e-7)
+    ls = loader.load_string("Transform [1 0 0 0  0 1 0 0  0 0 1 0  7 8 9 1] ConcatTransform [2 0 0 0 0 2 0 0 0 0 2 0 0 0 0 1]")
+    assert np.array_equal(ls.ctm, np.array([[2, 0, 0, 7], [0, 2, 0, 8], [0, 0, 2, 9], [0, 0, 0, 1]], np.float32))
+
+
+def test_defaults():  # api.rs:231-241 names; pbrt-v3 parameter defaults
+    ls = loader.load_string("WorldBegin WorldEnd")
+    assert ls.names == {"camera": "perspective", "sampler": "halton", "integrator": "path", "filter": "box",
+                        "accelerator": "bvh", "film": "image"}
+    assert ls.max_depth == 5 and ls.scene.fov == 90.0 and (ls.scene.xres, ls.scene.yres) == (1280, 720)
+    assert ls.scene.idx.shape == (0, 3) and np.array_equal(ls.scene.cam_to_world, np.eye(4, dtype=np.float32))
+
+
+def _expect_check_sphere(ls, res):
+    sd = ls.scene
+    assert (sd.xres, sd.yres) == res and sd.fov == 45.0 and ls.spp == (16, 8) and ls.max_depth == 5
+    assert ls.filename == "simple.png" and ls.integrator == pbrt_amd.INTEGRATOR_PATH
+    assert sd.P.tolist() == [[-20, -20, -1], [20, -20, -1], [20, 20, -1], [-20, 20, -1]]  # Translate 0 0 -1 applied
+    assert sd.idx.tolist() == [[0, 1, 2], [0, 2, 3]] and sd.mat_id.tolist() == [1, 1]
+    assert sd.spheres.tolist() == [[0, 0, 0, 1, 0]]
+    assert np.allclose(sd.materials, [[1, .9, .9, .9, 0, 0, 0], [0, .45, .45, .45, 0, 0, 0]])  # mirror; matte mean(tex1, tex2)
+    assert sd.lights[0].tolist() == pytest.approx([2, 0, 0, 0, .4, .45, .5])
+    d = np.array([-30, 40, 99]) / np.linalg.norm([-30, 40, 99])  # from - to, "point to" defaults to (0, 0, 1) as in pbrt-v3
+    assert sd.lights[1, 0] == 1 and np.allclose(sd.lights[1, 1:4], d, atol=1e-6)
+    r, g, b = sd.lights[1, 4:7]
+    assert 1.0 < r < 1.25 and 0.45 < g < 0.62 and 0.1 < b < 0.25  # 3000 K normalised blackbody x 1.5: warm white
+    want_c2w = pbrt_amd.look_at((3, 4, 1.5), (.5, .5, 0), (0, 0, 1))[1]  # camera_to_world = CTM^-1 (api.rs:813-820)
+    assert np.array_equal(sd.cam_to_world, want_c2w)
+    assert len(ls.warnings) == 1 and "checkerboard" in ls.warnings[0]
+
+
+def test_c0_scene_loads():
+    _expect_check_sphere(loader.load_file(C0), (400, 400))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/scenes/check-sphere.pbrt"), reason="reference tree not mounted")
+def test_reference_scene_files_load():
+    """The reference's own scene files: its parser stops at line 14 / 20 of this one."""
+    _expect_check_sphere(loader.load_file("/root/reference/scenes/check-sphere.pbrt"), (400, 400))
+    _expect_check_sphere(loader.load_file("/root/reference/src/core/testdata/scene1.pbrt"), (400, 300))
+    ls = loader.load_file("/root/reference/scenes/paramset-lookup.pbrt")
+    assert ls.scene.idx.shape[0] == 0
+
+
+def test_area_light_material_and_orientation():
+    text = ('WorldBegin AttributeBegin AreaLightSource "diffuse" "rgb L" [3 2 1] Material "matte" "rgb Kd" [0 0 0] '
+            'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0] AttributeEnd '
+            'Scale 1 1 -1 Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0] '
+            'ReverseOrientation Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0] '
+            'LightSource "point" "point from" [1 2 3] "rgb I" [2 2 2] "rgb scale" [.5 .5 .5] WorldEnd')
+    sd = loader.load_string(text).scene
+    assert sd.materials.tolist() == [[0, 0, 0, 0, 3, 2, 1], [0, .5, .5, .5, 0, 0, 0]]  # area light popped with the attribute
+    assert sd.mat_id.tolist() == [0, 1, 1]
+    assert sd.idx.tolist() == [[0, 1, 2], [3, 5, 4], [6, 7, 8]]  # mirrored CTM flips winding; ReverseOrientation flips it back
+    assert sd.lights.tolist() == [[0, 1, 2, -3, 1, 1, 1]]  # point light through the CTM, I * scale
+
+
+def test_include(tmp_path):
+    (tmp_path / "geo.pbrt").write_text('Shape "sphere" "float radius" 2\n')
+    (tmp_path / "main.pbrt").write_text('WorldBegin\nInclude "geo.pbrt"\nWorldEnd\n')
+    sd = loader.load_file(tmp_path / "main.pbrt").scene
+    assert sd.spheres.tolist() == [[0, 0, 0, 2, 0]]
