@@ -81,17 +81,47 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
   const size_t n = b.nodes.size();
   if (n == 0) return true;
   if (b.order.size() > (1u << 24)) { *why = "more than 2^24 triangles (leaf references hold a 24-bit slot)"; return false; }
+  // Record numbering.  The memory system past L2 serves random requests in 128-byte lines at a rate
+  // that does not depend on how many of the 128 bytes are used (tools/ubench/gather_wide.hip), so
+  // the two 64-byte records of SIBLING interior nodes are placed in one line: fetching the near
+  // child's record brings the far one along.  Sibling pairs start at even indices; groups follow
+  // each other in depth-first order.  PBRT_HIP_NODE_LAYOUT=dfs restores plain depth-first numbering.
   std::vector<uint32_t> interior_index(n, 0);
   uint32_t n_int = 0;
-  for (size_t i = 0; i < n; i++)
-    if ((b.nodes[i].count_axis & 0xffffu) == 0) interior_index[i] = n_int++;
+  const char *layout = std::getenv("PBRT_HIP_NODE_LAYOUT");
+  if (layout && std::string(layout) == "dfs") {
+    for (size_t i = 0; i < n; i++)
+      if ((b.nodes[i].count_axis & 0xffffu) == 0) interior_index[i] = n_int++;
+  } else if ((b.nodes[0].count_axis & 0xffffu) == 0) {
+    std::vector<uint32_t> todo = {0};
+    interior_index[0] = 0;
+    n_int = 2;  // the root has its line to itself
+    while (!todo.empty()) {
+      const uint32_t p = todo.back();
+      todo.pop_back();
+      const uint32_t c0 = p + 1, c1 = b.nodes[p].offset;
+      const bool i0 = (b.nodes[c0].count_axis & 0xffffu) == 0, i1 = (b.nodes[c1].count_axis & 0xffffu) == 0;
+      if (i0 && i1) {
+        n_int = (n_int + 1u) & ~1u;
+        interior_index[c0] = n_int;
+        interior_index[c1] = n_int + 1;
+        n_int += 2;
+      } else if (i0) {
+        interior_index[c0] = n_int++;
+      } else if (i1) {
+        interior_index[c1] = n_int++;
+      }
+      if (i1) todo.push_back(c1);
+      if (i0) todo.push_back(c0);
+    }
+  }
   auto ref_of = [&](uint32_t i) -> uint32_t {
     const BvhNode &c = b.nodes[i];
     const uint32_t cnt = c.count_axis & 0xffffu;
     return cnt ? (kLeafRef | (cnt << 24) | c.offset) : interior_index[i];
   };
   auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-  out->q.resize(4 * (size_t)n_int);
+  out->q.assign(4 * (size_t)n_int, make_uint4(0u, 0u, 0u, 0u));
   for (size_t i = 0; i < n; i++) {
     const BvhNode &p = b.nodes[i];
     if (p.count_axis & 0xffffu) continue;
@@ -138,6 +168,7 @@ struct pbrt_hip_scene {
   DevBuf<uint4> d_nodes;
   DevBuf<float4> d_tris, d_mats, d_lights, d_spheres;
   DevBuf<float4> d_slab, d_film;          // scratch of pbrt_hip_render()
+  DevBuf<float4> d_lane_state;            // per-lane path state records of the render kernel
   DevBuf<unsigned long long> d_counters;  // 5
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t stream = nullptr;  // own stream of pbrt_hip_render()
@@ -149,7 +180,7 @@ struct pbrt_hip_scene {
   ~pbrt_hip_scene() {
     d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release();
     d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
-    d_slab.release(); d_film.release(); d_counters.release();
+    d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -392,6 +423,11 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.inv_ny = 1.0f / (float)r->spp_y;
     R.slab = (float4 *)d_slab;
     R.counters = s->d_counters.p;
+    {
+      const size_t need = (size_t)sh.n_local * 64 * 320;  // float4 records: 64 workgroups per super-tile x 5 x 64
+      if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
+      R.lane_state = s->d_lane_state.p;
+    }
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);

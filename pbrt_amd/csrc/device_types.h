@@ -41,6 +41,7 @@ struct RenderParams {
   float4 *slab;
   unsigned long long *counters;  // 5: camera, bounce, shadow rays, nodes visited, triangles tested
   uint32_t min_walkers, min_parked;  // traversal scheduling thresholds (kernels.hip trav_run)
+  float4 *lane_state;                // 5 x 64 float4 per workgroup: path state parked in HBM (kernels.hip PathState)
 };
 
 struct RayBatch {

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "device_types.h"
 
 namespace pbrt_hip {
@@ -34,6 +36,8 @@ constexpr float kInvPi = 0.31830988618379067154f;
 constexpr float kPiOver4 = 0.78539816339744830961f;
 constexpr float kOneMinusEps = 0x1.fffffep-1f;  // 1 - f32::EPSILON, core/rng.rs:19
 constexpr uint32_t kNoPrim = 0xffffffffu;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct V3 {
   float x, y, z;
@@ -259,6 +263,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
   const V3 o = T.o, d = T.d;
   const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
   const bool negx = inv.x < 0.f, negy = inv.y < 0.f, negz = inv.z < 0.f;
+  const uint32_t negbits = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
   const char *nodes = reinterpret_cast<const char *>(S.nodes);
   const char *tris = reinterpret_cast<const char *>(S.tris);
   for (;;) {
@@ -275,17 +280,25 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const uint4 q2 = *reinterpret_cast<const uint4 *>(nodes + off + 32u);
       const uint4 q3 = *reinterpret_cast<const uint4 *>(nodes + off + 48u);
       const float tfar = fminf(T.h.t, T.tmax);
-      float tn0, tn1;
-      const bool hit0 = box_test(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z),
-                                 __uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y), o, inv, negx,
-                                 negy, negz, tfar, tn0);
-      const bool hit1 = box_test(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x),
-                                 __uint_as_float(q2.y), __uint_as_float(q2.z), __uint_as_float(q2.w), o, inv, negx,
-                                 negy, negz, tfar, tn1);
-      const uint32_t axis = q3.z;
-      const bool far_first = axis == 0u ? negx : (axis == 1u ? negy : negz);  // child 1 is the near one
+      // The slab test of DESIGN.md 3.4 for child 0 and child 1 side by side: element 0 / 1 of each
+      // float2 belongs to child 0 / 1, so the six subtractions and six multiplications of the two
+      // boxes are six packed instructions (v_pk_add_f32 / v_pk_mul_f32, IEEE per element: the
+      // same bits as the scalar form).
+      const f32x2 lx = {__uint_as_float(q0.x), __uint_as_float(q1.z)}, hx = {__uint_as_float(q0.w), __uint_as_float(q2.y)};
+      const f32x2 ly = {__uint_as_float(q0.y), __uint_as_float(q1.w)}, hy = {__uint_as_float(q1.x), __uint_as_float(q2.z)};
+      const f32x2 lz = {__uint_as_float(q0.z), __uint_as_float(q2.x)}, hz = {__uint_as_float(q1.y), __uint_as_float(q2.w)};
+      const f32x2 nx = ((negx ? hx : lx) - o.x) * inv.x, fx = ((negx ? lx : hx) - o.x) * inv.x;
+      const f32x2 ny = ((negy ? hy : ly) - o.y) * inv.y, fy = ((negy ? ly : hy) - o.y) * inv.y;
+      const f32x2 nz = ((negz ? hz : lz) - o.z) * inv.z, fz = ((negz ? lz : hz) - o.z) * inv.z;
+      const float tn0 = fmaxf(fmaxf(nx.x, ny.x), fmaxf(nz.x, kRayTMin));
+      const float tn1 = fmaxf(fmaxf(nx.y, ny.y), fmaxf(nz.y, kRayTMin));
+      const float tf0 = fminf(fminf(fx.x, fy.x), fminf(fz.x, tfar));
+      const float tf1 = fminf(fminf(fx.y, fy.y), fminf(fz.y, tfar));
+      const bool hit0 = tn0 <= tf0 * kBoxPad, hit1 = tn1 <= tf1 * kBoxPad;
+      const bool far_first = ((negbits >> q3.z) & 1u) != 0u;  // child 1 is the near one
       const uint32_t ref_near = far_first ? q3.y : q3.x, ref_far = far_first ? q3.x : q3.y;
-      const bool hit_near = far_first ? hit1 : hit0, hit_far = far_first ? hit0 : hit1;
+      const bool hit_near = (far_first && hit1) || (!far_first && hit0);
+      const bool hit_far = (far_first && hit0) || (!far_first && hit1);
       if (COUNT && !EXACT) cn++;  // production walk: one 64-byte fetch
       if (EXACT) {
         cn++;  // the near child is visited now; the far one when it is popped
@@ -434,30 +447,68 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3 };
 
 // waves per SIMD the register allocator must leave room for (launch_bounds' 2nd argument)
 #ifndef PBRT_RENDER_WAVES_PER_SIMD
-#define PBRT_RENDER_WAVES_PER_SIMD 4
+#define PBRT_RENDER_WAVES_PER_SIMD 5
 #endif
+
+// Path state of one pixel while its lane is busy walking the BVH: five 16-byte records per lane in
+// HBM, laid out [record][lane] per wave so that a wave's access is one coalesced 1 KB transaction.
+// It is loaded and stored only in the service stage (once per ray, against ~76 gather steps), which
+// keeps these 20 dwords out of the registers that are live across the traversal loop.
+struct PathState {
+  V3 sum;      // Film contrib_sum of this pixel so far
+  V3 L, beta;  // radiance and throughput of the sample in flight
+  V3 wi_next;  // prepared bounce direction (taken after the shadow ray returns)
+  V3 Lpend;    // beta * Ld, added if the shadow ray is unoccluded
+  Pcg rng;     // rng.inc is recomputed from the pixel, only the state is stored
+  uint32_t s, bounces;
+  bool specular, cont;
+};
+__device__ __forceinline__ void path_store(float4 *rec, const PathState &P) {
+  rec[0] = make_float4(P.sum.x, P.sum.y, P.sum.z, P.L.x);
+  rec[64] = make_float4(P.L.y, P.L.z, P.beta.x, P.beta.y);
+  rec[128] = make_float4(P.beta.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
+  rec[192] = make_float4(P.Lpend.x, P.Lpend.y, P.Lpend.z,
+                         __uint_as_float(P.s | (P.bounces << 20) | (P.specular ? 1u << 30 : 0u) | (P.cont ? 1u << 31 : 0u)));
+  rec[256] = make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)), 0.f, 0.f);
+}
+__device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
+  const float4 a = rec[0], b = rec[64], c = rec[128], d = rec[192], e = rec[256];
+  P.sum = {a.x, a.y, a.z};
+  P.L = {a.w, b.x, b.y};
+  P.beta = {b.z, b.w, c.x};
+  P.wi_next = {c.y, c.z, c.w};
+  P.Lpend = {d.x, d.y, d.z};
+  const uint32_t w = __float_as_uint(d.w);
+  P.s = w & 0xfffffu;
+  P.bounces = (w >> 20) & 0x3ffu;
+  P.specular = (w >> 30) & 1u;
+  P.cont = (w >> 31) & 1u;
+  P.rng.state = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
+}
 
 // COUNT: accumulate ray / visit counters.  EXACT (needs COUNT): walk the tree in exactly the oracle's
 // order so that the counters are the oracle's; COUNT without EXACT counts the production walk itself
 // (64-byte fetches and triangle tests).
+// One workgroup = one wavefront = one 8x8 pixel tile; 64 workgroups per 64x64 super-tile.
 template <bool SPH, bool COUNT, bool EXACT, int STACK>
-__global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel(const DevScene S, const RenderParams R) {
-  __shared__ uint32_t lds_stack[4][STACK][64];
-  __shared__ float lds_tn[EXACT ? 4 : 1][EXACT ? STACK : 1][64];  // entry distances: exact walk only
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t *stk = &lds_stack[wave][0][lane];
-  float *stkt = &lds_tn[EXACT ? wave : 0][0][lane];
+__global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) render_kernel(const DevScene S, const RenderParams R) {
+  __shared__ uint32_t lds_stack[STACK][64];
+  __shared__ float lds_tn[EXACT ? STACK : 1][64];  // entry distances: exact walk only
+  const uint32_t lane = threadIdx.x;
+  uint32_t *stk = &lds_stack[0][lane];
+  float *stkt = &lds_tn[0][lane];
 
-  // block -> (local super-tile, 16x16 tile inside it); wave -> 8x8 quadrant; lane -> pixel
+  // block -> (local super-tile, 8x8 tile inside it, row-major); lane -> pixel
   const int32_t W = S.cx1 - S.cx0, H = S.cy1 - S.cy0;
   const uint32_t stx = (uint32_t)(W + 63) >> 6;
-  const uint32_t jsup = blockIdx.x >> 4, sub = blockIdx.x & 15u;
+  const uint32_t jsup = blockIdx.x >> 6, sub = blockIdx.x & 63u;
   const uint32_t tsup = R.rank + jsup * R.world;
-  const uint32_t pxs = (sub & 3u) * 16u + (wave & 1u) * 8u + (lane & 7u);
-  const uint32_t pys = (sub >> 2) * 16u + (wave >> 1) * 8u + (lane >> 3);
+  const uint32_t pxs = (sub & 7u) * 8u + (lane & 7u);
+  const uint32_t pys = (sub >> 3) * 8u + (lane >> 3);
   const int32_t xr = (int32_t)((tsup % stx) * 64u + pxs), yr = (int32_t)((tsup / stx) * 64u + pys);
   const bool valid = xr < W && yr < H;
   const int32_t px = S.cx0 + xr, py = S.cy0 + yr;
+  const uint64_t pixel_seq = R.seed * (uint64_t)S.xres * (uint64_t)S.yres + (uint64_t)py * (uint64_t)S.xres + (uint64_t)px;
 
   const uint32_t spp = R.spp_x * R.spp_y;
   const uint32_t nL = S.n_lights;
@@ -465,14 +516,22 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
   const bool direct_only = R.integrator == 1u;
   const TravTuning tune = {R.min_walkers, R.min_parked};
 
-  Pcg rng;
-  pcg_seq(rng, R.seed * (uint64_t)S.xres * (uint64_t)S.yres + (uint64_t)py * (uint64_t)S.xres + (uint64_t)px);
-
-  V3 sum = {0.f, 0.f, 0.f};
-  V3 L = {0.f, 0.f, 0.f}, beta = {1.f, 1.f, 1.f};
-  V3 wi_next = {0.f, 0.f, 0.f}, Lpend = {0.f, 0.f, 0.f};
-  uint32_t s = 0, bounces = 0, state = valid ? ST_NEW : ST_DONE;
-  bool specular = false, cont = false;
+  float4 *rec = R.lane_state + (size_t)blockIdx.x * 320u + lane;
+  {
+    PathState P0;
+    P0.sum = {0.f, 0.f, 0.f};
+    P0.L = {0.f, 0.f, 0.f};
+    P0.beta = {1.f, 1.f, 1.f};
+    P0.wi_next = {0.f, 0.f, 0.f};
+    P0.Lpend = {0.f, 0.f, 0.f};
+    pcg_seq(P0.rng, pixel_seq);
+    P0.s = 0;
+    P0.bounces = 0;
+    P0.specular = false;
+    P0.cont = false;
+    path_store(rec, P0);
+  }
+  uint32_t state = valid ? ST_NEW : ST_DONE;
   unsigned long long c_cam = 0, c_bounce = 0, c_shadow = 0, c_nodes = 0, c_tris = 0;
   Trav T;
   T.o = mk(0.f, 0.f, 0.f);
@@ -487,6 +546,9 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
   for (;;) {
     // ---- service stage: lanes whose walk is over consume the result and launch the next ray ----
     if (state != ST_DONE && T.cur == kDone) {
+      PathState P;
+      path_load(rec, P);
+      P.rng.inc = (pixel_seq << 1) | 1u;
       bool launch = false, launch_any = false;
       V3 ro = T.o, rd = T.d;
       float rtmax = kInf;
@@ -494,7 +556,7 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
         if (SPH) trav_spheres(S, T);
         bool advance = false;  // take the prepared bounce (or end the sample)
         if (state == ST_SHADOW) {
-          if (!T.occluded) L = L + Lpend;
+          if (!T.occluded) P.L = P.L + P.Lpend;
           advance = true;
         } else {
           const HitRec h = T.h;
@@ -523,17 +585,17 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
             m0 = S.mats[2 * mid];
             m1 = S.mats[2 * mid + 1];
           }
-          if (bounces == 0 || specular) {
+          if (P.bounces == 0 || P.specular) {
             if (hit) {
               const V3 le = xyz(m1);
-              if ((le.x > 0.f || le.y > 0.f || le.z > 0.f) && dot(ng, wo) > 0.f) L = L + beta * le;
+              if ((le.x > 0.f || le.y > 0.f || le.z > 0.f) && dot(ng, wo) > 0.f) P.L = P.L + P.beta * le;
             } else if (S.has_inf) {
-              L = L + beta * mk(S.le_inf[0], S.le_inf[1], S.le_inf[2]);
+              P.L = P.L + P.beta * mk(S.le_inf[0], S.le_inf[1], S.le_inf[2]);
             }
           }
-          cont = false;
+          P.cont = false;
           bool need_shadow = false;
-          if (hit && bounces < R.max_depth) {
+          if (hit && P.bounces < R.max_depth) {
             const V3 nf = dot(ng, wo) < 0.f ? -ng : ng;
             const V3 po = p + nf * kSpawnEps;
             const V3 k = {m0.y, m0.z, m0.w};
@@ -542,37 +604,37 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
             bool alive = true;
             if (__float_as_uint(m0.x) == 0u) {  // matte
               if (nL > 0u) {
-                const float xi = pcg_float(rng), u1 = pcg_float(rng), u2 = pcg_float(rng);
+                const float xi = pcg_float(P.rng), u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
                 uint32_t li = (uint32_t)(xi * nLf);
                 if (li > nL - 1u) li = nL - 1u;
                 V3 Ld;
                 if (sample_light(S, li, po, nf, k, u1, u2, nLf, Ld, sh_d, sh_tmax)) {
                   need_shadow = true;
-                  Lpend = beta * Ld;
+                  P.Lpend = P.beta * Ld;
                 }
               }
               if (direct_only) {
                 alive = false;
               } else {
-                const float u1 = pcg_float(rng), u2 = pcg_float(rng);
-                const float z = cosine_about(nf, u1, u2, wi_next);
+                const float u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
+                const float z = cosine_about(nf, u1, u2, P.wi_next);
                 if (z == 0.f) alive = false;
-                else { beta = beta * k; specular = false; }
+                else { P.beta = P.beta * k; P.specular = false; }
               }
             } else {  // mirror
               const float c = dot(wo, nf);
-              wi_next = -wo + nf * (2.0f * c);
-              beta = beta * k;
-              specular = true;
+              P.wi_next = -wo + nf * (2.0f * c);
+              P.beta = P.beta * k;
+              P.specular = true;
             }
-            if (alive && beta.x == 0.f && beta.y == 0.f && beta.z == 0.f) alive = false;
-            if (alive && bounces > 3u) {
-              const float mx = fmaxf(beta.x, fmaxf(beta.y, beta.z));
+            if (alive && P.beta.x == 0.f && P.beta.y == 0.f && P.beta.z == 0.f) alive = false;
+            if (alive && P.bounces > 3u) {
+              const float mx = fmaxf(P.beta.x, fmaxf(P.beta.y, P.beta.z));
               const float q = fmaxf(0.05f, 1.0f - mx);
-              if (pcg_float(rng) < q) alive = false;
-              else beta = beta / (1.0f - q);
+              if (pcg_float(P.rng) < q) alive = false;
+              else P.beta = P.beta / (1.0f - q);
             }
-            cont = alive;
+            P.cont = alive;
             ro = po;  // shadow ray and bounce ray both leave from the offset point
             if (need_shadow) {
               rd = sh_d;
@@ -586,14 +648,14 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
           if (!need_shadow) advance = true;
         }
         if (advance) {
-          bool go = cont;
+          bool go = P.cont;
           if (go) {
-            bounces++;
-            // a ray at the depth limit can only collect emission, and only after a specular bounce
-            if (bounces >= R.max_depth && !specular) go = false;
+            P.bounces++;
+            // a ray at the depth limit can only collect emission, and only after a P.specular bounce
+            if (P.bounces >= R.max_depth && !P.specular) go = false;
           }
           if (go) {
-            rd = wi_next;
+            rd = P.wi_next;
             rtmax = kInf;
             state = ST_CLOSEST;
             launch = true;
@@ -601,22 +663,29 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
             if (COUNT) c_bounce++;
           } else {
             // radiance sanitising of SamplerIntegrator::Render, then FilmTile::AddSample (box filter)
-            const float y = (0.212671f * L.x + 0.715160f * L.y) + 0.072169f * L.z;
-            if (isnan(L.x) || isnan(L.y) || isnan(L.z) || y < -1e-5f || isinf(y)) L = {0.f, 0.f, 0.f};
-            sum = sum + L;
-            s++;
+            const float y = (0.212671f * P.L.x + 0.715160f * P.L.y) + 0.072169f * P.L.z;
+            if (isnan(P.L.x) || isnan(P.L.y) || isnan(P.L.z) || y < -1e-5f || isinf(y)) P.L = {0.f, 0.f, 0.f};
+            P.sum = P.sum + P.L;
+            P.s++;
             state = ST_NEW;
           }
-          cont = false;
+          P.cont = false;
         }
       }
       if (state == ST_NEW) {
-        if (s == spp) {
+        if (P.s == spp) {
           state = ST_DONE;
+          // Film::merge_film_tile (core/film.rs:313-326): xyz = rgb_to_xyz(contrib_sum), weight = spp
+          float4 o;
+          o.x = 0.412453f * P.sum.x + 0.357580f * P.sum.y + 0.180423f * P.sum.z;
+          o.y = 0.212671f * P.sum.x + 0.715160f * P.sum.y + 0.072169f * P.sum.z;
+          o.z = 0.019334f * P.sum.x + 0.119193f * P.sum.y + 0.950227f * P.sum.z;
+          o.w = (float)spp;
+          R.slab[(size_t)jsup * 4096u + pys * 64u + pxs] = o;
         } else {
           // stratified camera sample and PerspectiveCamera ray (3.2)
-          const uint32_t sx = s % R.spp_x, sy = s / R.spp_x;
-          const float u1 = pcg_float(rng), u2 = pcg_float(rng);
+          const uint32_t sx = P.s % R.spp_x, sy = P.s / R.spp_x;
+          const float u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
           const float jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
           const float jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
           const float fx = (float)px + jx, fy = (float)py + jy;
@@ -626,31 +695,23 @@ __global__ void __launch_bounds__(256, PBRT_RENDER_WAVES_PER_SIMD) render_kernel
                 (S.c2w[8] * dc.x + S.c2w[9] * dc.y) + S.c2w[10] * dc.z};
           ro = {S.c2w[3], S.c2w[7], S.c2w[11]};
           rtmax = kInf;
-          L = {0.f, 0.f, 0.f};
-          beta = {1.f, 1.f, 1.f};
-          specular = false;
-          bounces = 0;
+          P.L = {0.f, 0.f, 0.f};
+          P.beta = {1.f, 1.f, 1.f};
+          P.specular = false;
+          P.bounces = 0;
           state = ST_CLOSEST;
           launch = true;
           launch_any = false;
           if (COUNT) c_cam++;
         }
       }
+      path_store(rec, P);
       if (launch) trav_begin<EXACT>(S, T, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
     trav_run<EXACT, COUNT>(S, T, stk, stkt, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
-  if (valid) {
-    // Film::merge_film_tile (core/film.rs:313-326): xyz = rgb_to_xyz(contrib_sum), weight = spp
-    float4 o;
-    o.x = 0.412453f * sum.x + 0.357580f * sum.y + 0.180423f * sum.z;
-    o.y = 0.212671f * sum.x + 0.715160f * sum.y + 0.072169f * sum.z;
-    o.z = 0.019334f * sum.x + 0.119193f * sum.y + 0.950227f * sum.z;
-    o.w = (float)spp;
-    R.slab[(size_t)jsup * 4096u + pys * 64u + pxs] = o;
-  }
   if (COUNT) {
     unsigned long long v[5] = {c_cam, c_bounce, c_shadow, c_nodes, c_tris};
     for (int i = 0; i < 5; i++) {
@@ -748,9 +809,14 @@ __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int
 template <bool SPH, bool COUNT, bool EXACT>
 static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t depth,
                                   hipStream_t st) {
-  const dim3 grid(n_local_super * 16u), block(256);
-  if (depth <= 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);
-  else hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
+  const dim3 grid(n_local_super * 64u), block(64);
+  // the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
+  const uint32_t need = depth > 0 ? depth - 1 : 0;
+  if (need > 40) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
+  else if (need > 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 40>), grid, block, 0, st, S, R);
+  else if (need > 26) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);
+  else if (need > 20) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 26>), grid, block, 0, st, S, R);
+  else hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 20>), grid, block, 0, st, S, R);
   return hipGetLastError();
 }
 

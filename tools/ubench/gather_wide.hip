@@ -1,0 +1,43 @@
+// Microbenchmark: random record gathers of 64 / 128 / 256 bytes per lane (own-lane dwordx4 loads) from tables of
+// different sizes: is the limit past L2 a REQUEST rate (records/s flat) or a BYTE rate (TB/s flat)?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+__device__ __forceinline__ uint32_t hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <int NQ>  // NQ x 16 bytes per record
+__global__ void __launch_bounds__(64) gather(const char *tab, uint32_t nrec, int iters, float *out) {
+  uint32_t seed = blockIdx.x * 64u + threadIdx.x;
+  float acc = 0.f;
+  for (int it = 0; it < iters; it++) {
+    seed = hash(seed + it);
+    const uint4 *p = reinterpret_cast<const uint4 *>(tab + (size_t)(seed % nrec) * (NQ * 16));
+    uint4 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) v[q] = p[q];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc += __uint_as_float(v[q].x ^ v[q].w);
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+template <int NQ>
+void run(const char *tab, size_t bytes, float *out) {
+  const uint32_t nrec = (uint32_t)(bytes / (NQ * 16));
+  const int blocks = 256 * 24, iters = 1000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(gather<NQ>, dim3(blocks), dim3(64), 0, 0, tab, nrec, 8, out);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(gather<NQ>, dim3(blocks), dim3(64), 0, 0, tab, nrec, iters, out);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double recs = (double)blocks * 64 * iters;
+  printf("table %5zu MB  record %3d B  %8.2f ms  %7.2f Grec/s  %6.2f TB/s\n", bytes >> 20, NQ * 16, ms, recs / ms / 1e6, recs * NQ * 16 / ms / 1e9);
+}
+int main() {
+  char *tab; float *out;
+  const size_t cap = (size_t)2048 << 20;
+  hipMalloc(&tab, cap); hipMalloc(&out, 64); hipMemset(tab, 1, cap);
+  for (size_t mb : {2, 16, 48, 112, 512, 2048}) {
+    run<2>(tab, mb << 20, out); run<4>(tab, mb << 20, out); run<8>(tab, mb << 20, out); run<16>(tab, mb << 20, out);
+  }
+  return 0;
+}
