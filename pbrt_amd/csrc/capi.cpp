@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
@@ -65,7 +66,7 @@ uint32_t tuning(const char *name, uint32_t dflt) {
   long x = std::strtol(v, nullptr, 10);
   return x < 0 ? 0u : (x > 64 ? 64u : (uint32_t)x);
 }
-constexpr uint32_t kMinWalkers = 32, kMinParked = 8;
+constexpr uint32_t kMinWalkers = 32, kMinParked = 12;
 
 constexpr uint32_t kLeafRef = 0x80000000u;
 
@@ -137,6 +138,92 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
   return true;
 }
 
+// 4-wide, QUANTISED form of the same tree for the production walk.  Every quad node is a binary
+// interior node collapsed with its interior children (2..4 children); the children's boxes are
+// stored as 8-bit coordinates on the node's own grid (origin = the node's lower corner, one
+// power-of-two cell size per axis), rounded outwards, so a node with four children is 64 bytes:
+//   {origin.x origin.y origin.z  ex | ey<<8 | ez<<16}      ex.. = biased exponent byte of the cell size
+//   {qlo.x[4]  qlo.y[4]  qlo.z[4]  qhi.x[4]}               one byte per child
+//   {qhi.y[4]  qhi.z[4]  0  0}
+//   {ref[4]}
+// plane = fmaf((float)q, cell, origin): the builder checks with the same fmaf that every decoded
+// box contains the true one, so the walk visits a superset of the exact walk's nodes and the
+// RESULT is unchanged (tie rule of DESIGN.md 3.4).  Why: the loop is bound by the bytes it moves
+// from L2 to L1, and this form moves ~2.9 KB per ray instead of ~4.9 KB.
+// Unused child slots: qlo = 255, qhi = 0 (inverted, never hit), ref 0xffffffff.
+struct QuadNodes {
+  std::vector<uint4> q;  // 4 per node
+  uint32_t depth = 0;    // levels of the quad tree (the walk stacks at most 3 * depth entries)
+};
+void make_quad_nodes(const Bvh &b, QuadNodes *out) {
+  if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
+  auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  auto as_f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+  struct Item { uint32_t node, quad, level; };
+  std::vector<Item> todo = {{0u, 0u, 1u}};
+  out->q.assign(4, make_uint4(0, 0, 0, 0));
+  while (!todo.empty()) {
+    const Item it = todo.back();
+    todo.pop_back();
+    if (it.level > out->depth) out->depth = it.level;
+    uint32_t kids[4];
+    int nk = 0;
+    const uint32_t two[2] = {it.node + 1, b.nodes[it.node].offset};
+    for (uint32_t c : two) {
+      if ((b.nodes[c].count_axis & 0xffffu) == 0) { kids[nk++] = c + 1; kids[nk++] = b.nodes[c].offset; }
+      else kids[nk++] = c;
+    }
+    const BvhNode &me = b.nodes[it.node];
+    uint32_t ebyte[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++) {
+      const float origin = me.lo[a], extent = me.hi[a] - me.lo[a];
+      // smallest power-of-two cell with 255 cells covering the extent (bumped while rounding pushes a plane past 255)
+      int e = -126;
+      if (extent > 0.f) {
+        std::frexp(extent / 255.0f, &e);  // extent/255 = m * 2^e, m in [0.5, 1)  =>  2^e >= extent/255
+        if (e < -126) e = -126;
+      }
+      for (;; e++) {
+        const float cell = std::ldexp(1.0f, e);
+        bool ok = true;
+        uint32_t lo_bytes = 0, hi_bytes = 0;
+        for (int k = 0; k < 4 && ok; k++) {
+          if (k >= nk) { lo_bytes |= 255u << (8 * k); continue; }
+          const BvhNode &c = b.nodes[kids[k]];
+          int ql = (int)std::floor((c.lo[a] - origin) / cell), qh = (int)std::ceil((c.hi[a] - origin) / cell);
+          if (ql < 0) ql = 0;
+          if (qh < 0) qh = 0;
+          while (ql > 0 && std::fmaf((float)ql, cell, origin) > c.lo[a]) ql--;
+          while (qh <= 255 && std::fmaf((float)qh, cell, origin) < c.hi[a]) qh++;
+          if (ql > 255 || qh > 255 || std::fmaf((float)ql, cell, origin) > c.lo[a]) { ok = false; break; }
+          lo_bytes |= (uint32_t)ql << (8 * k);
+          hi_bytes |= (uint32_t)qh << (8 * k);
+        }
+        if (ok) { ebyte[a] = (uint32_t)(e + 127); qlo[a] = lo_bytes; qhi[a] = hi_bytes; break; }
+      }
+    }
+    uint32_t ref[4];
+    for (int k = 0; k < 4; k++) {
+      if (k >= nk) { ref[k] = 0xffffffffu; continue; }
+      const BvhNode &c = b.nodes[kids[k]];
+      const uint32_t cnt = c.count_axis & 0xffffu;
+      if (cnt) {
+        ref[k] = kLeafRef | (cnt << 24) | c.offset;
+      } else {
+        ref[k] = (uint32_t)(out->q.size() / 4);
+        out->q.resize(out->q.size() + 4, make_uint4(0, 0, 0, 0));
+        todo.push_back({kids[k], ref[k], it.level + 1});
+      }
+    }
+    uint4 *q = &out->q[4 * (size_t)it.quad];
+    q[0] = make_uint4(as_u(me.lo[0]), as_u(me.lo[1]), as_u(me.lo[2]), ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16));
+    q[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+    q[2] = make_uint4(qhi[1], qhi[2], 0u, 0u);
+    q[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
+    (void)as_f;
+  }
+}
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
@@ -165,7 +252,9 @@ struct pbrt_hip_scene {
   DevBuf<float> d_P;
   DevBuf<uint32_t> d_idx, d_order;
   DevBuf<uint16_t> d_mat_id;
-  DevBuf<uint4> d_nodes;
+  DevBuf<uint4> d_nodes, d_quads;
+  DevBuf<uint32_t> d_stack_overflow;  // per-lane spill area of the quad walk's stack beyond its LDS part
+  uint32_t quad_depth = 0;
   DevBuf<float4> d_tris, d_mats, d_lights, d_spheres;
   DevBuf<float4> d_slab, d_film;          // scratch of pbrt_hip_render()
   DevBuf<float4> d_lane_state;            // per-lane path state records of the render kernel
@@ -178,7 +267,7 @@ struct pbrt_hip_scene {
   uint64_t device_bytes = 0;
 
   ~pbrt_hip_scene() {
-    d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release();
+    d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release(); d_quads.release(); d_stack_overflow.release();
     d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
     d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release();
     if (ev0) (void)hipEventDestroy(ev0);
@@ -308,7 +397,11 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(s->d_idx.alloc(3 * (size_t)nt));
     HIP_TRY(s->d_mat_id.alloc(nt));
     HIP_TRY(s->d_order.alloc(nt));
+    QuadNodes quads;
+    make_quad_nodes(s->bvh, &quads);
+    s->quad_depth = quads.depth;
     HIP_TRY(s->d_nodes.alloc(pairs.q.size()));
+    HIP_TRY(s->d_quads.alloc(quads.q.size()));
     HIP_TRY(s->d_tris.alloc(3 * (size_t)nt));
     HIP_TRY(s->d_mats.alloc(mats.size()));
     HIP_TRY(s->d_lights.alloc(lights.size()));
@@ -326,17 +419,20 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(up(s->d_mat_id.p, d->mat_id, s->d_mat_id.n * 2));
     HIP_TRY(up(s->d_order.p, s->bvh.order.data(), s->d_order.n * 4));
     HIP_TRY(up(s->d_nodes.p, pairs.q.data(), pairs.q.size() * 16));
+    HIP_TRY(up(s->d_quads.p, quads.q.data(), quads.q.size() * 16));
     HIP_TRY(up(s->d_mats.p, mats.data(), mats.size() * 16));
     HIP_TRY(up(s->d_lights.p, lights.data(), lights.size() * 16));
     HIP_TRY(up(s->d_spheres.p, spheres.data(), spheres.size() * 16));
     HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order.p, nt, s->d_tris.p, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    s->device_bytes = s->d_P.n * 4 + s->d_idx.n * 4 + s->d_mat_id.n * 2 + s->d_order.n * 4 + s->d_nodes.n * 16 +
+    s->device_bytes = s->d_P.n * 4 + s->d_idx.n * 4 + s->d_mat_id.n * 2 + s->d_order.n * 4 + s->d_nodes.n * 16 + s->d_quads.n * 16 +
                       s->d_tris.n * 16 + s->d_mats.n * 16 + s->d_lights.n * 16 + s->d_spheres.n * 16;
 
     // --- kernel argument block ---
     DevScene &D = s->dev;
     D.nodes = s->d_nodes.p;
+    D.quads = s->d_quads.p;
+    D.quad_stack_need = 3u * quads.depth;
     D.tris = s->d_tris.p;
     D.mats = s->d_mats.p;
     D.lights = s->d_lights.p;
@@ -427,6 +523,14 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       const size_t need = (size_t)sh.n_local * 64 * 320;  // float4 records: 64 workgroups per super-tile x 5 x 64
       if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
       R.lane_state = s->d_lane_state.p;
+    }
+    {
+      // the quad walk keeps kQuadLdsStack entries per lane in LDS; deeper entries (rare) spill here
+      const uint32_t extra = s->dev.quad_stack_need > kQuadLdsStack ? s->dev.quad_stack_need - kQuadLdsStack : 0;
+      const size_t need = (size_t)sh.n_local * 64 * 64 * extra;
+      if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); HIP_TRY(s->d_stack_overflow.alloc(need)); }
+      R.stack_overflow = s->d_stack_overflow.p;
+      R.stack_overflow_entries = extra;
     }
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
@@ -573,6 +677,14 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
   if (counters) {
     RB_TRY(hipMemsetAsync(s->d_counters.p, 0, 2 * sizeof(unsigned long long), s->stream));
     B.counters = s->d_counters.p;
+  }
+  {
+    // launch_intersect uses at most 4096 workgroups of 4 waves
+    const uint32_t extra = s->dev.quad_stack_need > kQuadLdsStack ? s->dev.quad_stack_need - kQuadLdsStack : 0;
+    const size_t need = (size_t)4096 * 4 * 64 * extra;
+    if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); RB_TRY(s->d_stack_overflow.alloc(need)); }
+    B.stack_overflow = s->d_stack_overflow.p;
+    B.stack_overflow_entries = extra;
   }
   RB_TRY(launch_intersect(s->dev, B, any, s->bvh.depth, s->stream));
   if (any) {

@@ -16,8 +16,12 @@
 
 namespace pbrt_hip {
 
+constexpr uint32_t kQuadLdsStack = 32;  // LDS entries per lane of the quad walk's stack
+
 struct DevScene {
   const uint4 *nodes;
+  const uint4 *quads;  // 4 x 16 B per quantised quad node (capi.cpp QuadNodes)
+  uint32_t quad_stack_need;
   const float4 *tris;
   const float4 *mats;
   const float4 *lights;
@@ -42,6 +46,8 @@ struct RenderParams {
   unsigned long long *counters;  // 5: camera, bounce, shadow rays, nodes visited, triangles tested
   uint32_t min_walkers, min_parked;  // traversal scheduling thresholds (kernels.hip trav_run)
   float4 *lane_state;                // 5 x 64 float4 per workgroup: path state parked in HBM (kernels.hip PathState)
+  uint32_t *stack_overflow;          // [workgroup][entry][lane]: stack entries beyond the LDS part
+  uint32_t stack_overflow_entries;
 };
 
 struct RayBatch {
@@ -53,6 +59,8 @@ struct RayBatch {
   uint8_t *occluded;
   unsigned long long *counters;  // 2: nodes, tris (may be null)
   uint32_t min_walkers, min_parked;
+  uint32_t *stack_overflow;
+  uint32_t stack_overflow_entries;
 };
 
 // launchers (kernels.hip)

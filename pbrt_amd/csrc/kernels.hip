@@ -196,7 +196,7 @@ __device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx,
 // popped node with the current tfar (the far-plane part of that test can only have loosened).
 // Otherwise entries are bare refs and a popped node is simply processed (a superset walk).
 template <bool EXACT>
-__device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt, unsigned long long &cn) {
+__device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf, unsigned long long &cn) {
   if (EXACT) {
     while (T.sp != 0u) {
       T.sp--;
@@ -209,7 +209,23 @@ __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt
   }
   if (T.sp == 0u) return kDone;
   T.sp--;
-  return stk[T.sp * 64u];
+  return T.sp < kQuadLdsStack ? stk[T.sp * 64u] : ovf[(T.sp - kQuadLdsStack) * 64u];
+}
+// production walk: the first kQuadLdsStack entries of a lane's stack live in LDS, deeper ones (rare:
+// the bound is 3 entries per level of the quad tree) in a per-lane HBM area
+__device__ __forceinline__ void trav_push(Trav &T, uint32_t *stk, uint32_t *ovf, uint32_t ref) {
+  if (T.sp < kQuadLdsStack) stk[T.sp * 64u] = ref;
+  else ovf[(T.sp - kQuadLdsStack) * 64u] = ref;
+  T.sp++;
+}
+__device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
+  const bool sw = kb < ka;
+  const float k = sw ? kb : ka;
+  const uint32_t r = sw ? rb : ra;
+  kb = sw ? ka : kb;
+  rb = sw ? ra : rb;
+  ka = k;
+  ra = r;
 }
 
 __device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) { T.cur = ref; }
@@ -237,7 +253,7 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 
     float tn;
     if (box_test(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, inv,
                  inv.x < 0.f, inv.y < 0.f, inv.z < 0.f, tmax, tn))
-      trav_enter(T, S.root_ref);
+      trav_enter(T, (!EXACT && !(S.root_ref & kLeafRef)) ? 0u : S.root_ref);
   }
 }
 
@@ -258,13 +274,15 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 
 // `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
 // caller once its walk is over.
 template <bool EXACT, bool COUNT>
-__device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, const bool alive,
-                                         const TravTuning tune, unsigned long long &cn, unsigned long long &ct) {
+__device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf,
+                                         const bool alive, const TravTuning tune, unsigned long long &cn,
+                                         unsigned long long &ct) {
   const V3 o = T.o, d = T.d;
   const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
   const bool negx = inv.x < 0.f, negy = inv.y < 0.f, negz = inv.z < 0.f;
   const uint32_t negbits = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
   const char *nodes = reinterpret_cast<const char *>(S.nodes);
+  const char *quads = reinterpret_cast<const char *>(S.quads);
   const char *tris = reinterpret_cast<const char *>(S.tris);
   for (;;) {
     const bool walking = T.cur != kDone;
@@ -272,7 +290,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     if (mwalk == 0ull) break;
     if ((uint32_t)__popcll(mwalk) < tune.min_walkers && __ballot(!walking && alive) != 0ull) break;
 
-    if (walking && !trav_parked(T)) {
+    if (EXACT && walking && !trav_parked(T)) {
       // ---- one step: both children of interior node T.cur ----
       const uint32_t off = T.cur * 64u;
       const uint4 q0 = *reinterpret_cast<const uint4 *>(nodes + off);
@@ -299,17 +317,59 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const uint32_t ref_near = far_first ? q3.y : q3.x, ref_far = far_first ? q3.x : q3.y;
       const bool hit_near = (far_first && hit1) || (!far_first && hit0);
       const bool hit_far = (far_first && hit0) || (!far_first && hit1);
-      if (COUNT && !EXACT) cn++;  // production walk: one 64-byte fetch
       if (EXACT) {
         cn++;  // the near child is visited now; the far one when it is popped
         stk[T.sp * 64u] = ref_far;
         stkt[T.sp * 64u] = hit_far ? (far_first ? tn0 : tn1) : __builtin_nanf("");
         T.sp++;
-      } else if (hit_far) {
-        stk[T.sp * 64u] = ref_far;
-        T.sp++;
       }
-      trav_enter(T, hit_near ? ref_near : trav_pop<EXACT>(T, stk, stkt, cn));
+      trav_enter(T, hit_near ? ref_near : trav_pop<EXACT>(T, stk, stkt, ovf, cn));
+    }
+
+    if (!EXACT && walking && !trav_parked(T)) {
+      // ---- one step of the production walk: the four children of quantised quad node T.cur (64 bytes) ----
+      const uint32_t off = T.cur * 64u;
+      const uint4 W0 = *reinterpret_cast<const uint4 *>(quads + off);
+      const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
+      const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
+      const uint4 W3 = *reinterpret_cast<const uint4 *>(quads + off + 48u);
+      if (COUNT) cn++;  // one 64-byte fetch
+      const float tfar = fminf(T.h.t, T.tmax);
+      const float ox = __uint_as_float(W0.x), oy = __uint_as_float(W0.y), oz = __uint_as_float(W0.z);
+      const float cx = __uint_as_float((W0.w & 0xffu) << 23), cy = __uint_as_float(((W0.w >> 8) & 0xffu) << 23);
+      const float cz = __uint_as_float(((W0.w >> 16) & 0xffu) << 23);
+      // near / far planes by the sign of the inverse direction: one select per axis serves all four
+      // children (a dword holds the four children's bytes of one plane)
+      const uint32_t bnx = negx ? W1.w : W1.x, bfx = negx ? W1.x : W1.w;
+      const uint32_t bny = negy ? W2.x : W1.y, bfy = negy ? W1.y : W2.x;
+      const uint32_t bnz = negz ? W2.y : W1.z, bfz = negz ? W1.z : W2.y;
+      float key[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // decode (plane = fmaf(q, cell, origin), the builder's own formula), then the slab test of 3.4
+        const float pnx = __fmaf_rn((float)((bnx >> (8 * k)) & 0xffu), cx, ox), pfx = __fmaf_rn((float)((bfx >> (8 * k)) & 0xffu), cx, ox);
+        const float pny = __fmaf_rn((float)((bny >> (8 * k)) & 0xffu), cy, oy), pfy = __fmaf_rn((float)((bfy >> (8 * k)) & 0xffu), cy, oy);
+        const float pnz = __fmaf_rn((float)((bnz >> (8 * k)) & 0xffu), cz, oz), pfz = __fmaf_rn((float)((bfz >> (8 * k)) & 0xffu), cz, oz);
+        const float tnx = (pnx - o.x) * inv.x, tfx = (pfx - o.x) * inv.x;
+        const float tny = (pny - o.y) * inv.y, tfy = (pfy - o.y) * inv.y;
+        const float tnz = (pnz - o.z) * inv.z, tfz = (pfz - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, kRayTMin));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tfar));
+        key[k] = tn <= tf * kBoxPad ? tn : kInf;
+      }
+      // sort the children by entry distance (missed ones to the back): nearest first, the others
+      // stacked so that the nearer pops first.  Order affects only speed (tie rule of 3.4).
+      float k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3];
+      uint32_t r0 = W3.x, r1 = W3.y, r2 = W3.z, r3 = W3.w;
+      cswap(k0, r0, k1, r1);
+      cswap(k2, r2, k3, r3);
+      cswap(k0, r0, k2, r2);
+      cswap(k1, r1, k3, r3);
+      cswap(k1, r1, k2, r2);
+      if (k3 < kInf) trav_push(T, stk, ovf, r3);
+      if (k2 < kInf) trav_push(T, stk, ovf, r2);
+      if (k1 < kInf) trav_push(T, stk, ovf, r1);
+      trav_enter(T, k0 < kInf ? r0 : trav_pop<EXACT>(T, stk, stkt, ovf, cn));
     }
 
     // ---- leaf flush (wave-uniform decision) ----
@@ -358,7 +418,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           T.cur = kDone;
           T.sp = 0u;
         } else {
-          trav_enter(T, trav_pop<EXACT>(T, stk, stkt, cn));
+          trav_enter(T, trav_pop<EXACT>(T, stk, stkt, ovf, cn));
         }
       }
     }
@@ -447,7 +507,7 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3 };
 
 // waves per SIMD the register allocator must leave room for (launch_bounds' 2nd argument)
 #ifndef PBRT_RENDER_WAVES_PER_SIMD
-#define PBRT_RENDER_WAVES_PER_SIMD 5
+#define PBRT_RENDER_WAVES_PER_SIMD 4
 #endif
 
 // Path state of one pixel while its lane is busy walking the BVH: five 16-byte records per lane in
@@ -492,11 +552,12 @@ __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
 // One workgroup = one wavefront = one 8x8 pixel tile; 64 workgroups per 64x64 super-tile.
 template <bool SPH, bool COUNT, bool EXACT, int STACK>
 __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) render_kernel(const DevScene S, const RenderParams R) {
-  __shared__ uint32_t lds_stack[STACK][64];
+  __shared__ uint32_t lds_stack[EXACT ? STACK : kQuadLdsStack][64];
   __shared__ float lds_tn[EXACT ? STACK : 1][64];  // entry distances: exact walk only
   const uint32_t lane = threadIdx.x;
   uint32_t *stk = &lds_stack[0][lane];
   float *stkt = &lds_tn[0][lane];
+  uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u + lane;
 
   // block -> (local super-tile, 8x8 tile inside it, row-major); lane -> pixel
   const int32_t W = S.cx1 - S.cx0, H = S.cy1 - S.cy0;
@@ -709,7 +770,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
       if (launch) trav_begin<EXACT>(S, T, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
-    trav_run<EXACT, COUNT>(S, T, stk, stkt, state != ST_DONE, tune, c_nodes, c_tris);
+    trav_run<EXACT, COUNT>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
   if (COUNT) {
@@ -726,11 +787,12 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
 // walk is over writes its result and pulls its next ray while the other lanes keep walking.
 template <bool SPH, bool COUNT, int STACK>
 __global__ void __launch_bounds__(256) intersect_kernel(const DevScene S, const RayBatch B, const int any_hit) {
-  __shared__ uint32_t lds_stack[4][STACK][64];
+  __shared__ uint32_t lds_stack[4][COUNT ? STACK : kQuadLdsStack][64];
   __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *stk = &lds_stack[wave][0][lane];
   float *stkt = &lds_tn[COUNT ? wave : 0][0][lane];
+  uint32_t *ovf = B.stack_overflow + ((size_t)blockIdx.x * 4u + wave) * B.stack_overflow_entries * 64u + lane;
   const TravTuning tune = {B.min_walkers, B.min_parked};
   unsigned long long cn = 0, ct = 0;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -768,7 +830,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(const DevScene S, const 
       }
     }
     if (__ballot(have) == 0ull) break;
-    trav_run<COUNT, COUNT>(S, T, stk, stkt, have, tune, cn, ct);
+    trav_run<COUNT, COUNT>(S, T, stk, stkt, ovf, have, tune, cn, ct);
   }
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -811,7 +873,7 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
                                   hipStream_t st) {
   const dim3 grid(n_local_super * 64u), block(64);
   // the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
-  const uint32_t need = depth > 0 ? depth - 1 : 0;
+  const uint32_t need = EXACT ? (depth > 0 ? depth - 1 : 0) : 0;  // the production walk has its own fixed LDS part
   if (need > 40) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
   else if (need > 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 40>), grid, block, 0, st, S, R);
   else if (need > 26) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);
