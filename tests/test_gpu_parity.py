@@ -28,7 +28,7 @@ def test_native_library_is_the_one_loaded(gpu):
     assert "pbrt_amd/lib/libpbrt_hip.so" in maps
 
 
-@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere"])
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere", "ties"])
 def test_intersect_matches_oracle(gpu, oracle, name):
     sd = SMALL_SCENES[name]()
     o, d, tmax = random_rays(200_000 if name != "mesh20k" else 400_000, 21)
@@ -77,6 +77,7 @@ RENDER_CASES = [
     ("check_sphere", INTEGRATOR_PATH, 5, (2, 2), 9),
     ("sphere", INTEGRATOR_DIRECT, 5, (4, 4), 0),
     ("check_sphere", INTEGRATOR_DIRECT, 5, (2, 1), 4),
+    ("ties", INTEGRATOR_PATH, 8, (3, 2), 5),  # duplicated / coplanar / degenerate geometry: the tie rule decides
 ]
 
 

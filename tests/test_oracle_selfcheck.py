@@ -135,3 +135,24 @@ def test_stratification(oracle):
         jx = (np.float32(s % nx) + u[2 * s]) * (np.float32(1) / np.float32(nx))
         jy = (np.float32(s // nx) + u[2 * s + 1]) * (np.float32(1) / np.float32(ny))
         assert (s % nx) / nx <= jx < (s % nx + 1) / nx and (s // nx) / ny <= jy < (s // nx + 1) / ny
+
+
+def test_tie_rule_on_duplicated_geometry(oracle):
+    """Equal-t hits go to the lower primitive id, with or without the BVH."""
+    sd = SMALL_SCENES["ties"]()
+    sc = oracle.OracleScene(sd)
+    o, d, tmax = random_rays(6000, 31)
+    # rays aimed straight at the coplanar quads and along their plane's normal
+    o2 = np.tile(np.array([[0.2, 0.2, 1.5]], np.float32), (200, 1))
+    o2[:, :2] += np.random.default_rng(1).uniform(-0.9, 0.9, (200, 2)).astype(np.float32)
+    d2 = np.tile(np.array([[0, 0, -1]], np.float32), (200, 1))
+    o, d, tmax = np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmax, np.full(200, np.inf, np.float32)])
+    a = sc.intersect(o, d, tmax)
+    b = sc.intersect(o, d, tmax, brute_force=True)
+    for x, y, w in zip(a[:4], b[:4], ("t", "prim", "b1", "b2")):
+        assert_bit_equal(x, y, f"ties {w}")
+    hit = a[1] != 0xFFFFFFFF
+    n = 314  # 300 random + 14 box / light triangles: ids >= n are the duplicates
+    assert hit.sum() > 1000 and (a[1][hit] < n).sum() > 500
+    dup_hit = hit & (a[1] >= n) & (a[1] < 2 * n)
+    assert not dup_hit.any()  # a duplicate never wins against its original

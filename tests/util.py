@@ -47,3 +47,32 @@ SMALL_SCENES = {
     "sphere": lambda: scenes.sphere_scene(64, 64),
     "check_sphere": lambda: scenes.check_sphere_scene(64, 48),
 }
+
+
+def tie_scene(xres=48, yres=48):
+    """Geometry built to produce EXACT ties and degenerate cases: every triangle of a small random
+    mesh duplicated (same vertices, different primitive id and material), two coplanar overlapping
+    quads, zero-area and needle triangles, a triangle lying in an axis-aligned bounding plane."""
+    from pbrt_amd.api import MATTE, MIRROR, SceneData
+    base = scenes.random_mesh_scene(300, xres, yres)
+    n = base.idx.shape[0]
+    P = [base.P]
+    idx = [base.idx, base.idx.copy()]                    # exact duplicates: equal t, lower id must win
+    mat = [base.mat_id, ((base.mat_id.astype(np.int64) + 7) % 250).astype(np.uint16)]
+    extra_v = np.array([
+        [-0.8, -0.8, -0.5], [0.8, -0.8, -0.5], [0.8, 0.8, -0.5], [-0.8, 0.8, -0.5],   # quad A at z=-0.5
+        [-0.4, -0.4, -0.5], [1.2, -0.4, -0.5], [1.2, 1.2, -0.5], [-0.4, 1.2, -0.5],   # quad B, coplanar, overlapping
+        [0.1, 0.1, 0.3], [0.1, 0.1, 0.3], [0.1, 0.1, 0.3],                             # zero-area (a point)
+        [0.0, 0.0, 0.6], [0.5, 0.5, 0.6], [1.0, 1.0, 0.6],                             # zero-area (collinear)
+        [-1.0, 0.2, 0.9], [1.0, 0.2, 0.9], [0.0, 0.2000001, 0.9],                      # needle
+    ], np.float32)
+    b = base.P.shape[0]
+    extra_i = np.array([[b, b + 1, b + 2], [b, b + 2, b + 3], [b + 4, b + 5, b + 6], [b + 4, b + 6, b + 7],
+                        [b + 8, b + 9, b + 10], [b + 11, b + 12, b + 13], [b + 14, b + 15, b + 16]], np.uint32)
+    extra_m = np.array([1, 1, 5, 5, 2, 3, 4], np.uint16)  # quad A matte, quad B mirror (id 5 is a mirror)
+    return SceneData(P=np.concatenate(P + [extra_v]), idx=np.concatenate(idx + [extra_i]),
+                     mat_id=np.concatenate(mat + [extra_m]), materials=base.materials, cam_to_world=base.cam_to_world,
+                     fov=base.fov, xres=xres, yres=yres).normalized()
+
+
+SMALL_SCENES["ties"] = tie_scene
