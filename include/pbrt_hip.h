@@ -157,6 +157,9 @@ void pbrt_hip_film_tile_bounds(int32_t xres, int32_t yres, const float crop[4], 
 void pbrt_hip_film_to_rgb(const float *film_xyzw, int64_t n_pixels, float scale, float *rgb);
 /* imageio::write_image (imageio.rs:235-283): ".png" (8-bit sRGB via to_byte, imageio.rs:66-68) or ".pfm" */
 int pbrt_hip_write_image(const char *name, const float *rgb, int32_t width, int32_t height);
+/* imageio::read_image (imageio.rs:87-184): ".png" (8-bit, value = byte / 255) or ".pfm".  Call with rgb == NULL to get
+ * the size, then with a width*height*3 buffer (width / height must then hold that size). */
+int pbrt_hip_read_image(const char *name, float *rgb, int32_t *width, int32_t *height);
 /* Transform::look_at (transform.rs:485-520): m = world->camera, m_inv = camera->world */
 void pbrt_hip_look_at(const float pos[3], const float look[3], const float up[3], float m[16], float m_inv[16]);
 

@@ -70,6 +70,7 @@ SYMBOLS = {
     "pbrt_hip_film_tile_bounds": (None, [_i32, _i32, _pf, _f, _f, _pi32, _pi32]),
     "pbrt_hip_film_to_rgb": (None, [_pf, _i64, _f, _pf]),
     "pbrt_hip_write_image": (C.c_int, [C.c_char_p, _pf, _i32, _i32]),
+    "pbrt_hip_read_image": (C.c_int, [C.c_char_p, _pf, _pi32, _pi32]),
     "pbrt_hip_look_at": (None, [_pf, _pf, _pf, _pf, _pf]),
     "pbrt_hip_load_file": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "pbrt_hip_load_string": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(_vp)]),

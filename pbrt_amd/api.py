@@ -155,6 +155,15 @@ def write_image(name, rgb):
     check(lib().pbrt_hip_write_image(str(name).encode(), _fp(rgb), w, h), "pbrt_hip_write_image")
 
 
+def read_image(name):
+    """imageio::read_image (imageio.rs:87-184): -> (h, w, 3) float32."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    check(lib().pbrt_hip_read_image(str(name).encode(), None, C.byref(w), C.byref(h)), "pbrt_hip_read_image")
+    rgb = np.zeros((h.value, w.value, 3), np.float32)
+    check(lib().pbrt_hip_read_image(str(name).encode(), _fp(rgb), C.byref(w), C.byref(h)), "pbrt_hip_read_image")
+    return rgb
+
+
 def bvh_build_host(P, idx):
     """The host BVH builder alone (no device): returns (nodes[n,8] uint32 view, order, depth)."""
     P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)

@@ -175,3 +175,44 @@ def test_png_pfm_roundtrip(tmp_path, oracle):  # imageio.rs:325-390
     assert np.array_equal(data, rgb)  # exact round trip, imageio.rs:363-389
     with pytest.raises(pbrt_amd._lib.PbrtHipError):
         pbrt_amd.write_image(tmp_path / "t.exr", rgb)  # imageio.rs:272: unimplemented
+
+
+def _reference_test_image():  # imageio.rs:298-309: 64x64, (x/64, y/64, 1)
+    y, x = np.mgrid[0:64, 0:64]
+    return np.stack([x / 64.0, y / 64.0, np.ones_like(x, float)], axis=-1).astype(np.float32)
+
+
+def test_roundtrip_png(tmp_path, oracle):  # imageio.rs:325-361
+    img = _reference_test_image()
+    name = tmp_path / "imageio-roundtrip.png"
+    pbrt_amd.write_image(name, img)
+    got = pbrt_amd.read_image(name)
+    want = np.vectorize(oracle.to_byte, otypes=[np.uint8])(img).astype(np.float32) / np.float32(255)
+    assert got.shape == (64, 64, 3) and np.array_equal(got, want)
+
+
+def test_roundtrip_pfm(tmp_path):  # imageio.rs:363-390
+    img = _reference_test_image()
+    name = tmp_path / "imageio-roundtrip.pfm"
+    pbrt_amd.write_image(name, img)
+    got = pbrt_amd.read_image(name)
+    assert np.array_equal(got, img)
+
+
+def test_png_reader_decodes_compressed_filtered_files(tmp_path):
+    """Files from another encoder (PIL: dynamic Huffman blocks, all five row filters), RGB / RGBA / grey."""
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    smooth = (np.add.outer(np.arange(97), np.arange(131)) % 256).astype(np.uint8)
+    for mode, arr in [("RGB", rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)),
+                      ("RGB", np.stack([smooth, smooth[::-1], smooth // 2], -1)),
+                      ("RGBA", rng.integers(0, 256, (17, 23, 4), dtype=np.uint8)), ("L", smooth)]:
+        name = tmp_path / f"t_{mode}_{arr.shape[0]}.png"
+        Image.fromarray(arr, mode).save(name, optimize=True)
+        got = pbrt_amd.read_image(name)
+        ref = np.asarray(Image.open(name).convert("RGB")).astype(np.float32) / np.float32(255)
+        assert np.array_equal(got, ref), mode
+    with pytest.raises(pbrt_amd._lib.PbrtHipError):
+        pbrt_amd.read_image(tmp_path / "missing.png")
+    with pytest.raises(pbrt_amd._lib.PbrtHipError):
+        pbrt_amd.read_image(tmp_path / "x.tga")  # imageio.rs:180
