@@ -146,8 +146,8 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
 //   {qlo.x[4]  qlo.y[4]  qlo.z[4]  qhi.x[4]}               one byte per child
 //   {qhi.y[4]  qhi.z[4]  0  0}
 //   {ref[4]}
-// plane = fmaf((float)q, cell, origin): the builder checks with the same fmaf that every decoded
-// box contains the true one, so the walk visits a superset of the exact walk's nodes and the
+// plane = origin + q * cell (a real number): the builder checks in exact (double) arithmetic that
+// every decoded box contains the true one, so the walk visits a superset of the exact walk's nodes and the
 // RESULT is unchanged (tie rule of DESIGN.md 3.4).  Why: the loop is bound by the bytes it moves
 // from L2 to L1, and this form moves ~2.9 KB per ray instead of ~4.9 KB.
 // Unused child slots: qlo = 255, qhi = 0 (inverted, never hit), ref 0xffffffff.
@@ -193,9 +193,11 @@ void make_quad_nodes(const Bvh &b, QuadNodes *out) {
           int ql = (int)std::floor((c.lo[a] - origin) / cell), qh = (int)std::ceil((c.hi[a] - origin) / cell);
           if (ql < 0) ql = 0;
           if (qh < 0) qh = 0;
-          while (ql > 0 && std::fmaf((float)ql, cell, origin) > c.lo[a]) ql--;
-          while (qh <= 255 && std::fmaf((float)qh, cell, origin) < c.hi[a]) qh++;
-          if (ql > 255 || qh > 255 || std::fmaf((float)ql, cell, origin) > c.lo[a]) { ok = false; break; }
+          // enclosure checked in exact arithmetic: origin + q * cell fits a double without rounding
+          const double o64 = origin, c64 = cell;
+          while (ql > 0 && o64 + ql * c64 > (double)c.lo[a]) ql--;
+          while (qh <= 255 && o64 + qh * c64 < (double)c.hi[a]) qh++;
+          if (ql > 255 || qh > 255 || o64 + ql * c64 > (double)c.lo[a]) { ok = false; break; }
           lo_bytes |= (uint32_t)ql << (8 * k);
           hi_bytes |= (uint32_t)qh << (8 * k);
         }

@@ -16,7 +16,7 @@
 
 namespace pbrt_hip {
 
-constexpr uint32_t kQuadLdsStack = 32;  // LDS entries per lane of the quad walk's stack
+constexpr uint32_t kQuadLdsStack = 40;  // LDS entries per lane of the quad walk's stack
 
 struct DevScene {
   const uint4 *nodes;

@@ -24,6 +24,11 @@
 
 #include "device_types.h"
 
+// node steps of the production walk between two scheduling checks (trav_run)
+#ifndef PBRT_STEPS_PER_CHECK
+#define PBRT_STEPS_PER_CHECK 2
+#endif
+
 namespace pbrt_hip {
 namespace {
 
@@ -195,7 +200,7 @@ __device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx,
 // as visited and re-tests `tn <= tfar * pad`, which is equivalent to the oracle's slab test of the
 // popped node with the current tfar (the far-plane part of that test can only have loosened).
 // Otherwise entries are bare refs and a popped node is simply processed (a superset walk).
-template <bool EXACT>
+template <bool EXACT, bool OVF>
 __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf, unsigned long long &cn) {
   if (EXACT) {
     while (T.sp != 0u) {
@@ -209,12 +214,15 @@ __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt
   }
   if (T.sp == 0u) return kDone;
   T.sp--;
+  if (!OVF) return stk[T.sp * 64u];
   return T.sp < kQuadLdsStack ? stk[T.sp * 64u] : ovf[(T.sp - kQuadLdsStack) * 64u];
 }
-// production walk: the first kQuadLdsStack entries of a lane's stack live in LDS, deeper ones (rare:
-// the bound is 3 entries per level of the quad tree) in a per-lane HBM area
+// production walk: kQuadLdsStack entries of a lane's stack live in LDS.  The walk stacks at most 3
+// entries per level of the quad tree; only for trees deeper than that allows (OVF) do the deeper
+// entries go to a per-lane HBM area.
+template <bool OVF>
 __device__ __forceinline__ void trav_push(Trav &T, uint32_t *stk, uint32_t *ovf, uint32_t ref) {
-  if (T.sp < kQuadLdsStack) stk[T.sp * 64u] = ref;
+  if (!OVF || T.sp < kQuadLdsStack) stk[T.sp * 64u] = ref;
   else ovf[(T.sp - kQuadLdsStack) * 64u] = ref;
   T.sp++;
 }
@@ -273,7 +281,7 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 
 //     lanes keep their state and resume on the next call.
 // `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
 // caller once its walk is over.
-template <bool EXACT, bool COUNT>
+template <bool EXACT, bool COUNT, bool OVF>
 __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf,
                                          const bool alive, const TravTuning tune, unsigned long long &cn,
                                          unsigned long long &ct) {
@@ -323,10 +331,14 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         stkt[T.sp * 64u] = hit_far ? (far_first ? tn0 : tn1) : __builtin_nanf("");
         T.sp++;
       }
-      trav_enter(T, hit_near ? ref_near : trav_pop<EXACT>(T, stk, stkt, ovf, cn));
+      trav_enter(T, hit_near ? ref_near : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
     }
 
-    if (!EXACT && walking && !trav_parked(T)) {
+    // production walk: PBRT_STEPS_PER_CHECK node steps between two scheduling checks (a lane that parks or
+    // finishes in the first one idles through the rest; the checks cost about a fifth of a step)
+#pragma unroll
+    for (int rep = 0; !EXACT && rep < PBRT_STEPS_PER_CHECK; rep++)
+    if (T.cur != kDone && !trav_parked(T)) {
       // ---- one step of the production walk: the four children of quantised quad node T.cur (64 bytes) ----
       const uint32_t off = T.cur * 64u;
       const uint4 W0 = *reinterpret_cast<const uint4 *>(quads + off);
@@ -335,9 +347,22 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const uint4 W3 = *reinterpret_cast<const uint4 *>(quads + off + 48u);
       if (COUNT) cn++;  // one 64-byte fetch
       const float tfar = fminf(T.h.t, T.tmax);
-      const float ox = __uint_as_float(W0.x), oy = __uint_as_float(W0.y), oz = __uint_as_float(W0.z);
-      const float cx = __uint_as_float((W0.w & 0xffu) << 23), cy = __uint_as_float(((W0.w >> 8) & 0xffu) << 23);
-      const float cz = __uint_as_float(((W0.w >> 16) & 0xffu) << 23);
+      // Node-relative slab test.  A decoded plane is the REAL number origin + q * cell (the builder
+      // checks in exact arithmetic that these planes enclose the true box), so
+      //     t = (origin + q*cell - o) * inv = q * (cell*inv) - (o - origin)*inv = fma(q, ci, -gi):
+      // one cvt + one fma per plane.  ci = cell * inv is exact (cell is a power of two); the two
+      // roundings inside gi = fl(fl(o - origin) * inv) are absolute errors <= 2 eps |gi| in t, covered by
+      // the margin m = 3 eps |gi|: near planes subtract gi + m, far planes gi - m, so every computed
+      // t_near / t_far lies outside the true one and the walk stays a superset of the exact walk; the
+      // fma's own relative rounding is what the (1 + 2 gamma_3) pad of DESIGN.md 3.4 is for.  An
+      // infinite inv (ray parallel to the slab) yields NaN or +-inf, which fmin / fmax ignore or keep
+      // conservative.
+      const float gx = (o.x - __uint_as_float(W0.x)) * inv.x, gy = (o.y - __uint_as_float(W0.y)) * inv.y;
+      const float gz = (o.z - __uint_as_float(W0.z)) * inv.z;
+      const float mx = fabsf(gx) * 0x1.8p-22f, my = fabsf(gy) * 0x1.8p-22f, mz = fabsf(gz) * 0x1.8p-22f;
+      const float gnx = -(gx + mx), gfx = -(gx - mx), gny = -(gy + my), gfy = -(gy - my), gnz = -(gz + mz), gfz = -(gz - mz);
+      const float cix = __uint_as_float((W0.w & 0xffu) << 23) * inv.x, ciy = __uint_as_float(((W0.w >> 8) & 0xffu) << 23) * inv.y;
+      const float ciz = __uint_as_float(((W0.w >> 16) & 0xffu) << 23) * inv.z;
       // near / far planes by the sign of the inverse direction: one select per axis serves all four
       // children (a dword holds the four children's bytes of one plane)
       const uint32_t bnx = negx ? W1.w : W1.x, bfx = negx ? W1.x : W1.w;
@@ -346,13 +371,9 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       float key[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        // decode (plane = fmaf(q, cell, origin), the builder's own formula), then the slab test of 3.4
-        const float pnx = __fmaf_rn((float)((bnx >> (8 * k)) & 0xffu), cx, ox), pfx = __fmaf_rn((float)((bfx >> (8 * k)) & 0xffu), cx, ox);
-        const float pny = __fmaf_rn((float)((bny >> (8 * k)) & 0xffu), cy, oy), pfy = __fmaf_rn((float)((bfy >> (8 * k)) & 0xffu), cy, oy);
-        const float pnz = __fmaf_rn((float)((bnz >> (8 * k)) & 0xffu), cz, oz), pfz = __fmaf_rn((float)((bfz >> (8 * k)) & 0xffu), cz, oz);
-        const float tnx = (pnx - o.x) * inv.x, tfx = (pfx - o.x) * inv.x;
-        const float tny = (pny - o.y) * inv.y, tfy = (pfy - o.y) * inv.y;
-        const float tnz = (pnz - o.z) * inv.z, tfz = (pfz - o.z) * inv.z;
+        const float tnx = __fmaf_rn((float)((bnx >> (8 * k)) & 0xffu), cix, gnx), tfx = __fmaf_rn((float)((bfx >> (8 * k)) & 0xffu), cix, gfx);
+        const float tny = __fmaf_rn((float)((bny >> (8 * k)) & 0xffu), ciy, gny), tfy = __fmaf_rn((float)((bfy >> (8 * k)) & 0xffu), ciy, gfy);
+        const float tnz = __fmaf_rn((float)((bnz >> (8 * k)) & 0xffu), ciz, gnz), tfz = __fmaf_rn((float)((bfz >> (8 * k)) & 0xffu), ciz, gfz);
         const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, kRayTMin));
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tfar));
         key[k] = tn <= tf * kBoxPad ? tn : kInf;
@@ -366,10 +387,10 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       cswap(k0, r0, k2, r2);
       cswap(k1, r1, k3, r3);
       cswap(k1, r1, k2, r2);
-      if (k3 < kInf) trav_push(T, stk, ovf, r3);
-      if (k2 < kInf) trav_push(T, stk, ovf, r2);
-      if (k1 < kInf) trav_push(T, stk, ovf, r1);
-      trav_enter(T, k0 < kInf ? r0 : trav_pop<EXACT>(T, stk, stkt, ovf, cn));
+      if (k3 < kInf) trav_push<OVF>(T, stk, ovf, r3);
+      if (k2 < kInf) trav_push<OVF>(T, stk, ovf, r2);
+      if (k1 < kInf) trav_push<OVF>(T, stk, ovf, r1);
+      trav_enter(T, k0 < kInf ? r0 : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
     }
 
     // ---- leaf flush (wave-uniform decision) ----
@@ -418,7 +439,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           T.cur = kDone;
           T.sp = 0u;
         } else {
-          trav_enter(T, trav_pop<EXACT>(T, stk, stkt, ovf, cn));
+          trav_enter(T, trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
         }
       }
     }
@@ -550,6 +571,8 @@ __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
 // order so that the counters are the oracle's; COUNT without EXACT counts the production walk itself
 // (64-byte fetches and triangle tests).
 // One workgroup = one wavefront = one 8x8 pixel tile; 64 workgroups per 64x64 super-tile.
+// STACK: LDS entries of the exact walk; for the production walk it only says whether the HBM overflow
+// area is compiled in (STACK != 0).
 template <bool SPH, bool COUNT, bool EXACT, int STACK>
 __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) render_kernel(const DevScene S, const RenderParams R) {
   __shared__ uint32_t lds_stack[EXACT ? STACK : kQuadLdsStack][64];
@@ -770,7 +793,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
       if (launch) trav_begin<EXACT>(S, T, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
-    trav_run<EXACT, COUNT>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
+    trav_run<EXACT, COUNT, (!EXACT && STACK != 0)>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
   if (COUNT) {
@@ -830,7 +853,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(const DevScene S, const 
       }
     }
     if (__ballot(have) == 0ull) break;
-    trav_run<COUNT, COUNT>(S, T, stk, stkt, ovf, have, tune, cn, ct);
+    trav_run<COUNT, COUNT, !COUNT>(S, T, stk, stkt, ovf, have, tune, cn, ct);
   }
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -873,7 +896,12 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
                                   hipStream_t st) {
   const dim3 grid(n_local_super * 64u), block(64);
   // the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
-  const uint32_t need = EXACT ? (depth > 0 ? depth - 1 : 0) : 0;  // the production walk has its own fixed LDS part
+  if (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
+    if (S.quad_stack_need > kQuadLdsStack) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
+    else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, 0, st, S, R);
+    return hipGetLastError();
+  }
+  const uint32_t need = depth > 0 ? depth - 1 : 0;
   if (need > 40) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
   else if (need > 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 40>), grid, block, 0, st, S, R);
   else if (need > 26) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);

@@ -28,13 +28,14 @@ def test_native_library_is_the_one_loaded(gpu):
     assert "pbrt_amd/lib/libpbrt_hip.so" in maps
 
 
-@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere", "ties"])
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere", "ties", "deep"])
 def test_intersect_matches_oracle(gpu, oracle, name):
     sd = SMALL_SCENES[name]()
     o, d, tmax = random_rays(200_000 if name != "mesh20k" else 400_000, 21)
     ref = oracle.OracleScene(sd)
     rt, rp, rb1, rb2, rc = ref.intersect(o, d, tmax)
     with gpu.Scene(sd) as sc:
+        sc_depth = sc.info()["depth"]
         t, prim, b1, b2, cnt = sc.intersect(o, d, tmax, counters=True)
         occ = sc.occluded(o, d, tmax)
         t2 = sc.intersect(o, d, tmax)[0]  # the non-counting instantiation
@@ -45,7 +46,9 @@ def test_intersect_matches_oracle(gpu, oracle, name):
     assert_bit_equal(t2, rt, "t (no counters)")
     assert cnt == rc, f"nodes visited / triangles tested {cnt} vs oracle {rc}"  # identical traversal
     assert_bit_equal(occ, ref.occluded(o, d, tmax), "occluded")
-    assert (prim != 0xFFFFFFFF).mean() > 0.05
+    assert (prim != 0xFFFFFFFF).mean() > (0.05 if name != "deep" else 0.0005)
+    if name == "deep":
+        assert sc_depth >= 39  # quad depth >= 20: stack bound 60 > 40 LDS entries -> the overflow variant runs
 
 
 def test_intersect_edge_cases(gpu, oracle):
@@ -78,6 +81,7 @@ RENDER_CASES = [
     ("sphere", INTEGRATOR_DIRECT, 5, (4, 4), 0),
     ("check_sphere", INTEGRATOR_DIRECT, 5, (2, 1), 4),
     ("ties", INTEGRATOR_PATH, 8, (3, 2), 5),  # duplicated / coplanar / degenerate geometry: the tie rule decides
+    ("deep", INTEGRATOR_PATH, 6, (2, 2), 6),  # a very deep tree: 64-entry exact stack, HBM overflow of the production stack
 ]
 
 

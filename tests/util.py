@@ -76,3 +76,22 @@ def tie_scene(xres=48, yres=48):
 
 
 SMALL_SCENES["ties"] = tie_scene
+
+
+def deep_tree_scene(xres=32, yres=32, k=400):
+    """Triangles whose positions AND sizes shrink geometrically (x_i = 2^(-i/2)): the 16-bucket SAH
+    peels a handful off per level, so the tree runs into the depth guard (39 levels for k = 400) --
+    the case that needs the 64-entry LDS stack of the exact walk and the HBM overflow area of the
+    production walk's stack (3 entries per quad level > 40 LDS entries)."""
+    from pbrt_amd.api import LIGHT_INFINITE, MATTE, SceneData, look_at
+    i = np.arange(k)
+    x = (0.5 ** (i / 2.0)).astype(np.float32)
+    z = (i / k * 0.5).astype(np.float32)
+    P = np.concatenate([np.stack([x, x * 0, z], 1), np.stack([x * 1.2, x * 0, z], 1), np.stack([x, x * 0.2, z], 1)]).astype(np.float32)
+    idx = np.stack([i, k + i, 2 * k + i], 1).astype(np.uint32)
+    return SceneData(P=P, idx=idx, mat_id=np.zeros(k, np.uint16), materials=np.array([[MATTE, .6, .5, .4, 0, 0, 0]], np.float32),
+                     lights=np.array([[LIGHT_INFINITE, 0, 0, 0, 1, 1, 1]], np.float32),
+                     cam_to_world=look_at((0.3, 0.05, 2.0), (0.3, 0.05, 0), (0, 1, 0))[1], fov=40, xres=xres, yres=yres).normalized()
+
+
+SMALL_SCENES["deep"] = deep_tree_scene
