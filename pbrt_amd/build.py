@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpbrt_hip.so")
+CLI_PATH = os.path.join(LIB_DIR, "pbrt")  # the C++ command line (csrc/pbrt_main.cpp)
 SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
@@ -44,6 +45,12 @@ def build_hip(force=False, verbose=False, extra_flags=()):
         subprocess.run(cmd, check=True)
         objs.append(obj)
     cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    # the command-line binary links the library by relative rpath so that it runs from the snapshot
+    cmd = [HIPCC, "-O2", "-std=c++17", os.path.join(CSRC, "pbrt_main.cpp"), "-o", CLI_PATH, "-L", LIB_DIR, "-lpbrt_hip",
+           "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -233,3 +233,25 @@ def test_cli_renders_c0(gpu, tmp_path):
     from PIL import Image
     img = np.asarray(Image.open(out))
     assert img.shape == (64, 64, 3) and img.std() > 10
+
+
+def test_native_cli_renders_c0(gpu, tmp_path):
+    """pbrt_amd/lib/pbrt: the C++ command line (csrc/pbrt_main.cpp, flags of src/bin/pbrt.rs:24-44)."""
+    import os
+    import subprocess
+    from pbrt_amd.build import CLI_PATH
+    scene = tmp_path / "s.pbrt"
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "c0_check_sphere.pbrt")).read()
+    scene.write_text(text.replace("[400]", "[64]"))
+    out = tmp_path / "o.pfm"
+    r = subprocess.run([CLI_PATH, "-v", "--quick", "-n", "4", "-o", str(out), str(scene)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "checkerboard" in r.stderr and "wrote" in r.stderr  # -v shows the parser's warning and the summary
+    img = gpu.read_image(out)
+    assert img.shape == (64, 64, 3) and img.std() > 0.05
+    from pbrt_amd import loader
+    ls = loader.load_string(scene.read_text())
+    with gpu.Scene(ls.scene) as sc:
+        film, _ = sc.render(integrator=ls.integrator, max_depth=ls.max_depth, spp=(ls.spp[0] // 2, ls.spp[1] // 2))
+    assert_bit_equal(img, gpu.film_to_rgb(film), "CLI image vs library render")  # PFM is lossless
+    assert subprocess.run([CLI_PATH, "-q", str(tmp_path / "missing.pbrt")], capture_output=True).returncode == 1

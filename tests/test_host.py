@@ -186,3 +186,12 @@ def test_scene_generators_are_deterministic_and_shaped():
     assert np.cross(e1, e2)[2] < 0  # the ceiling light faces down
     c = scenes.random_mesh_scene(5000, 32, 32, seed=99)
     assert not np.array_equal(a.P, c.P)
+
+
+def test_native_cli_usage():
+    import subprocess
+    from pbrt_amd.build import CLI_PATH
+    r = subprocess.run([CLI_PATH, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--outfile" in r.stderr and "--nthreads" in r.stderr and "--quick" in r.stderr
+    assert subprocess.run([CLI_PATH], capture_output=True).returncode == 1  # no scene files
+    assert subprocess.run([CLI_PATH, "--bogus"], capture_output=True).returncode == 2
