@@ -255,3 +255,34 @@ def test_native_cli_renders_c0(gpu, tmp_path):
         film, _ = sc.render(integrator=ls.integrator, max_depth=ls.max_depth, spp=(ls.spp[0] // 2, ls.spp[1] // 2))
     assert_bit_equal(img, gpu.film_to_rgb(film), "CLI image vs library render")  # PFM is lossless
     assert subprocess.run([CLI_PATH, "-q", str(tmp_path / "missing.pbrt")], capture_output=True).returncode == 1
+
+
+def test_full_size_properties_c3(gpu, oracle):
+    """BASELINE config C3's full frame (1M triangles, 2048x2048) at 2 spp: every pixel gets exactly spp
+    samples, finite, idempotent; three 16x16 windows of that frame against the oracle."""
+    sd = scenes.random_mesh_scene(1_000_000, 2048, 2048)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(max_depth=8, spp=(2, 1), seed=0)
+        again, _ = sc.render(max_depth=8, spp=(2, 1), seed=0)
+    assert film.shape == (2048, 2048, 4) and (film[..., 3] == 2).all() and np.isfinite(film).all()
+    assert_bit_equal(film, again, "idempotence")
+    assert st["samples"] == 2048 * 2048 * 2
+    for (x0, y0) in [(0, 0), (1024, 1024), (2032, 2032)]:
+        crop = (x0 / 2048, (x0 + 16) / 2048, y0 / 2048, (y0 + 16) / 2048)
+        win = scenes.random_mesh_scene(1_000_000, 2048, 2048, crop=crop)
+        ref, _ = oracle.OracleScene(win).render(max_depth=8, spp=(2, 1), seed=0)
+        assert_bit_equal(film[y0:y0 + 16, x0:x0 + 16], ref, f"window at {x0},{y0}")
+
+
+def test_c4_window_at_full_spp(gpu, oracle):
+    """BASELINE config C4 (Cornell-style box, 4096x4096, 64x64 = 4096 spp, maxdepth 16): an 8x8 window at the
+    full sample count, bit for bit (262k paths of depth up to 16 through the longest RNG streams of any config)."""
+    crop = (0.5, 0.5 + 8 / 4096, 0.25, 0.25 + 8 / 4096)
+    sd = scenes.cornell_scene(4096, 4096, crop=crop)
+    ref, rst = oracle.OracleScene(sd).render(max_depth=16, spp=(64, 64), seed=0)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(max_depth=16, spp=(64, 64), seed=0, counters=True)
+    assert film.shape == (8, 8, 4) and (film[..., 3] == 4096).all()
+    assert_bit_equal(film, ref, "C4 window")
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+        assert st[k] == rst[k]
