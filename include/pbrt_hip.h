@@ -115,10 +115,18 @@ void pbrt_hip_scene_destroy(pbrt_hip_scene *scene);
 int pbrt_hip_scene_info(const pbrt_hip_scene *scene, uint32_t *n_nodes, uint32_t *depth, uint32_t *n_lights,
                         uint64_t *device_bytes);
 int pbrt_hip_scene_export_bvh(const pbrt_hip_scene *scene, uint32_t *nodes /* 8 words each */, uint32_t *order);
+/* the production walk's own structure: number of 64-byte quantised 4-wide nodes, and the most stack entries a
+ * walk can hold (<= 40 live in LDS, deeper ones in an HBM overflow area) */
+int pbrt_hip_scene_walk_info(const pbrt_hip_scene *scene, uint32_t *quad_nodes, uint32_t *stack_need);
 /* host-only variant for CPU-side tests of the builder: no device is touched */
 int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
                             uint32_t *nodes /* 8*(2*n_tris) words cap */, uint32_t *order, uint32_t *n_nodes,
                             uint32_t *depth);
+
+/* host-only: the production walk's quantised 4-wide tree from a triangle soup, for CPU-side
+ * tests of its invariants.  quads: 16 words per node (cap_nodes nodes of room); split_leaves as the library default. */
+int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
+                             uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need);
 
 /* ---- the hot path ---- */
 /* Render this rank's super-tiles and return the assembled film in HOST memory:

@@ -56,7 +56,9 @@ SYMBOLS = {
     "pbrt_hip_scene_destroy": (None, [_vp]),
     "pbrt_hip_scene_info": (C.c_int, [_vp, _pu32, _pu32, _pu32, _pu64]),
     "pbrt_hip_scene_export_bvh": (C.c_int, [_vp, _pu32, _pu32]),
+    "pbrt_hip_scene_walk_info": (C.c_int, [_vp, _pu32, _pu32]),
     "pbrt_hip_bvh_build_host": (C.c_int, [_pf, _u32, _pu32, _u32, _pu32, _pu32, _pu32, _pu32]),
+    "pbrt_hip_quad_build_host": (C.c_int, [_pf, _u32, _pu32, _u32, C.c_int, _pu32, _u32, _pu32, _pu32]),
     "pbrt_hip_render": (C.c_int, [_vp, C.POINTER(RenderDesc), _pf, C.POINTER(Stats)]),
     "pbrt_hip_render_device": (C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp]),
     "pbrt_hip_render_wait": (C.c_int, [_vp, C.POINTER(Stats)]),

@@ -177,6 +177,18 @@ def bvh_build_host(P, idx):
     return nodes[:nn.value].copy(), order[:nt].copy(), depth.value
 
 
+def quad_build_host(P, idx, split_leaves=True):
+    """The production walk's quantised 4-wide tree alone (no device): (quads[n, 16] uint32, stack_need)."""
+    P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    cap = 2 * idx.shape[0] + 4
+    quads = np.zeros((cap, 16), np.uint32)
+    nq, need = C.c_uint32(), C.c_uint32()
+    check(lib().pbrt_hip_quad_build_host(_fp(P), P.shape[0], _u32p(idx), idx.shape[0], int(split_leaves), _u32p(quads), cap,
+                                         C.byref(nq), C.byref(need)), "pbrt_hip_quad_build_host")
+    return quads[:nq.value].copy(), need.value
+
+
 def slab_pixel_index(xres, yres, crop, rank, world_size):
     n = lib().pbrt_hip_slab_floats(xres, yres, (C.c_float * 4)(*crop), rank, world_size)
     if n < 0:
@@ -217,7 +229,10 @@ class Scene:
         nn, depth, nl, nb = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
         check(lib().pbrt_hip_scene_info(self._h, C.byref(nn), C.byref(depth), C.byref(nl), C.byref(nb)),
               "pbrt_hip_scene_info")
-        return {"n_nodes": nn.value, "depth": depth.value, "n_lights": nl.value, "device_bytes": nb.value}
+        qn, need = C.c_uint32(), C.c_uint32()
+        check(lib().pbrt_hip_scene_walk_info(self._h, C.byref(qn), C.byref(need)), "pbrt_hip_scene_walk_info")
+        return {"n_nodes": nn.value, "depth": depth.value, "n_lights": nl.value, "device_bytes": nb.value,
+                "quad_nodes": qn.value, "quad_stack_need": need.value}
 
     def export_bvh(self):
         i = self.info()

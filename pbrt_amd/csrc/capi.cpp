@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <exception>
 #include <limits>
 #include <memory>
@@ -66,7 +67,7 @@ uint32_t tuning(const char *name, uint32_t dflt) {
   long x = std::strtol(v, nullptr, 10);
   return x < 0 ? 0u : (x > 64 ? 64u : (uint32_t)x);
 }
-constexpr uint32_t kMinWalkers = 32, kMinParked = 12;
+constexpr uint32_t kMinWalkers = 32, kMinParked = 8;
 
 constexpr uint32_t kLeafRef = 0x80000000u;
 
@@ -152,28 +153,64 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
 // from L2 to L1, and this form moves ~2.9 KB per ray instead of ~4.9 KB.
 // Unused child slots: qlo = 255, qhi = 0 (inverted, never hit), ref 0xffffffff.
 struct QuadNodes {
-  std::vector<uint4> q;  // 4 per node
-  uint32_t depth = 0;    // levels of the quad tree (the walk stacks at most 3 * depth entries)
+  std::vector<uint4> q;     // 4 per node
+  uint32_t stack_need = 0;  // most entries the walk can hold: max over root-to-leaf paths of sum(children - 1)
 };
-void make_quad_nodes(const Bvh &b, QuadNodes *out) {
+// A child of a quad node while it is being assembled: a node of the binary tree, or (split_leaves) one
+// triangle of a leaf that was expanded into a quad node of single-triangle children.
+struct QuadChild {
+  float lo[3], hi[3];
+  uint32_t ref;        // final ref (leaf) or 0 with `node` / `leaf_node` set
+  uint32_t node;       // binary interior node to recurse into, or 0xffffffff
+  uint32_t leaf_node;  // binary leaf to expand into its own quad node, or 0xffffffff
+};
+void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, QuadNodes *out) {
   if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
   auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-  auto as_f = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
-  struct Item { uint32_t node, quad, level; };
-  std::vector<Item> todo = {{0u, 0u, 1u}};
+  struct Item { uint32_t node, quad, path; bool is_leaf; };  // path = stack entries held above this node
+  std::vector<Item> todo = {{0u, 0u, 0u, false}};
   out->q.assign(4, make_uint4(0, 0, 0, 0));
   while (!todo.empty()) {
     const Item it = todo.back();
     todo.pop_back();
-    if (it.level > out->depth) out->depth = it.level;
-    uint32_t kids[4];
-    int nk = 0;
-    const uint32_t two[2] = {it.node + 1, b.nodes[it.node].offset};
-    for (uint32_t c : two) {
-      if ((b.nodes[c].count_axis & 0xffffu) == 0) { kids[nk++] = c + 1; kids[nk++] = b.nodes[c].offset; }
-      else kids[nk++] = c;
-    }
     const BvhNode &me = b.nodes[it.node];
+    QuadChild kids[4];
+    int nk = 0;
+    auto add_node = [&](uint32_t c) {
+      const BvhNode &n = b.nodes[c];
+      QuadChild k;
+      for (int a = 0; a < 3; a++) { k.lo[a] = n.lo[a]; k.hi[a] = n.hi[a]; }
+      const uint32_t cnt = n.count_axis & 0xffffu;
+      k.ref = cnt ? (kLeafRef | (cnt << 24) | n.offset) : 0u;
+      k.node = cnt ? 0xffffffffu : c;
+      // a leaf of 2..4 triangles becomes a quad node of single triangles: their boxes are then tested in
+      // the node step and each leaf pass tests exactly one triangle per parked lane
+      k.leaf_node = (split_leaves && cnt >= 2 && cnt <= 4) ? c : 0xffffffffu;
+      kids[nk++] = k;
+    };
+    if (it.is_leaf) {  // expand a leaf: one child per triangle, boxed by its own bounds
+      const uint32_t cnt = me.count_axis & 0xffffu;
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t t = b.order[me.offset + j];
+        QuadChild k;
+        for (int a = 0; a < 3; a++) {
+          const float v0 = P[3 * idx[3 * t] + a], v1 = P[3 * idx[3 * t + 1] + a], v2 = P[3 * idx[3 * t + 2] + a];
+          k.lo[a] = std::min(v0, std::min(v1, v2));
+          k.hi[a] = std::max(v0, std::max(v1, v2));
+        }
+        k.ref = kLeafRef | (1u << 24) | (me.offset + j);
+        k.node = k.leaf_node = 0xffffffffu;
+        kids[nk++] = k;
+      }
+    } else {
+      const uint32_t two[2] = {it.node + 1, me.offset};
+      for (uint32_t c : two) {
+        if ((b.nodes[c].count_axis & 0xffffu) == 0) { add_node(c + 1); add_node(b.nodes[c].offset); }
+        else add_node(c);
+      }
+    }
+    const uint32_t path = it.path + (uint32_t)(nk - 1);
+    if (path > out->stack_need) out->stack_need = path;
     uint32_t ebyte[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
     for (int a = 0; a < 3; a++) {
       const float origin = me.lo[a], extent = me.hi[a] - me.lo[a];
@@ -189,7 +226,7 @@ void make_quad_nodes(const Bvh &b, QuadNodes *out) {
         uint32_t lo_bytes = 0, hi_bytes = 0;
         for (int k = 0; k < 4 && ok; k++) {
           if (k >= nk) { lo_bytes |= 255u << (8 * k); continue; }
-          const BvhNode &c = b.nodes[kids[k]];
+          const QuadChild &c = kids[k];
           int ql = (int)std::floor((c.lo[a] - origin) / cell), qh = (int)std::ceil((c.hi[a] - origin) / cell);
           if (ql < 0) ql = 0;
           if (qh < 0) qh = 0;
@@ -207,14 +244,15 @@ void make_quad_nodes(const Bvh &b, QuadNodes *out) {
     uint32_t ref[4];
     for (int k = 0; k < 4; k++) {
       if (k >= nk) { ref[k] = 0xffffffffu; continue; }
-      const BvhNode &c = b.nodes[kids[k]];
-      const uint32_t cnt = c.count_axis & 0xffffu;
-      if (cnt) {
-        ref[k] = kLeafRef | (cnt << 24) | c.offset;
+      const QuadChild &c = kids[k];
+      if (c.node == 0xffffffffu && c.leaf_node == 0xffffffffu) {
+        ref[k] = c.ref;
       } else {
         ref[k] = (uint32_t)(out->q.size() / 4);
         out->q.resize(out->q.size() + 4, make_uint4(0, 0, 0, 0));
-        todo.push_back({kids[k], ref[k], it.level + 1});
+        // below child k the walk holds the entries of this path minus the ones already popped: bound by path
+        if (c.node != 0xffffffffu) todo.push_back({c.node, ref[k], path, false});
+        else todo.push_back({c.leaf_node, ref[k], path, true});
       }
     }
     uint4 *q = &out->q[4 * (size_t)it.quad];
@@ -222,7 +260,6 @@ void make_quad_nodes(const Bvh &b, QuadNodes *out) {
     q[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
     q[2] = make_uint4(qhi[1], qhi[2], 0u, 0u);
     q[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
-    (void)as_f;
   }
 }
 
@@ -256,7 +293,6 @@ struct pbrt_hip_scene {
   DevBuf<uint16_t> d_mat_id;
   DevBuf<uint4> d_nodes, d_quads;
   DevBuf<uint32_t> d_stack_overflow;  // per-lane spill area of the quad walk's stack beyond its LDS part
-  uint32_t quad_depth = 0;
   DevBuf<float4> d_tris, d_mats, d_lights, d_spheres;
   DevBuf<float4> d_slab, d_film;          // scratch of pbrt_hip_render()
   DevBuf<float4> d_lane_state;            // per-lane path state records of the render kernel
@@ -301,6 +337,28 @@ int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *id
     *depth = b.depth;
     if (nodes && !b.nodes.empty()) std::memcpy(nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode));
     if (order && !b.order.empty()) std::memcpy(order, b.order.data(), b.order.size() * 4);
+    return PBRT_HIP_OK;
+  } catch (const std::exception &e) {
+    return fail(PBRT_HIP_ERR_INTERNAL, e.what());
+  }
+}
+
+int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
+                             uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need) {
+  try {
+    if ((n_tris && (!P || !idx)) || !n_quads || !stack_need) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: null argument");
+    for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
+      if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: vertex index out of range");
+    Bvh b;
+    build_bvh(P, idx, n_tris, &b);
+    QuadNodes q;
+    make_quad_nodes(b, P, idx, split_leaves != 0, &q);
+    *n_quads = (uint32_t)(q.q.size() / 4);
+    *stack_need = q.stack_need;
+    if (quads) {
+      if (*n_quads > cap_nodes) return fail(PBRT_HIP_ERR_LIMIT, "quad_build_host: output too small");
+      if (!q.q.empty()) std::memcpy(quads, q.q.data(), q.q.size() * 16);
+    }
     return PBRT_HIP_OK;
   } catch (const std::exception &e) {
     return fail(PBRT_HIP_ERR_INTERNAL, e.what());
@@ -400,8 +458,10 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(s->d_mat_id.alloc(nt));
     HIP_TRY(s->d_order.alloc(nt));
     QuadNodes quads;
-    make_quad_nodes(s->bvh, &quads);
-    s->quad_depth = quads.depth;
+    {
+      const char *sl = std::getenv("PBRT_HIP_SPLIT_LEAVES");
+      make_quad_nodes(s->bvh, d->P, d->idx, !(sl && sl[0] == '0'), &quads);
+    }
     HIP_TRY(s->d_nodes.alloc(pairs.q.size()));
     HIP_TRY(s->d_quads.alloc(quads.q.size()));
     HIP_TRY(s->d_tris.alloc(3 * (size_t)nt));
@@ -434,7 +494,7 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     DevScene &D = s->dev;
     D.nodes = s->d_nodes.p;
     D.quads = s->d_quads.p;
-    D.quad_stack_need = 3u * quads.depth;
+    D.quad_stack_need = quads.stack_need;
     D.tris = s->d_tris.p;
     D.mats = s->d_mats.p;
     D.lights = s->d_lights.p;
@@ -483,6 +543,13 @@ int pbrt_hip_scene_info(const pbrt_hip_scene *s, uint32_t *n_nodes, uint32_t *de
   if (depth) *depth = s->bvh.depth;
   if (n_lights) *n_lights = s->n_lights;
   if (device_bytes) *device_bytes = s->device_bytes;
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_scene_walk_info(const pbrt_hip_scene *s, uint32_t *quad_nodes, uint32_t *stack_need) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "walk_info: null scene");
+  if (quad_nodes) *quad_nodes = (uint32_t)(s->d_quads.n / 4);
+  if (stack_need) *stack_need = s->dev.quad_stack_need;
   return PBRT_HIP_OK;
 }
 

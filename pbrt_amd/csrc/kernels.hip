@@ -378,6 +378,10 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tfar));
         key[k] = tn <= tf * kBoxPad ? tn : kInf;
       }
+      // an unused child slot (ref kDone) must never be taken: its inverted box does not exclude it on an axis where
+      // the node is flat or the ray is parallel to the slab
+      if (W3.z == kDone) key[2] = kInf;  // (slots 0 and 1 are always used: every node has >= 2 children)
+      if (W3.w == kDone) key[3] = kInf;
       // order the children by entry distance (missed ones count as +inf): nearest first, the others
       // stacked.  Order affects only speed (tie rule of 3.4); a full sort of the rest was 1 % slower.
       float k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3];

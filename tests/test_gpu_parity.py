@@ -35,7 +35,7 @@ def test_intersect_matches_oracle(gpu, oracle, name):
     ref = oracle.OracleScene(sd)
     rt, rp, rb1, rb2, rc = ref.intersect(o, d, tmax)
     with gpu.Scene(sd) as sc:
-        sc_depth = sc.info()["depth"]
+        sc_depth, sc_need = sc.info()["depth"], sc.info()["quad_stack_need"]
         t, prim, b1, b2, cnt = sc.intersect(o, d, tmax, counters=True)
         occ = sc.occluded(o, d, tmax)
         t2 = sc.intersect(o, d, tmax)[0]  # the non-counting instantiation
@@ -48,7 +48,7 @@ def test_intersect_matches_oracle(gpu, oracle, name):
     assert_bit_equal(occ, ref.occluded(o, d, tmax), "occluded")
     assert (prim != 0xFFFFFFFF).mean() > (0.05 if name != "deep" else 0.0005)
     if name == "deep":
-        assert sc_depth >= 39  # quad depth >= 20: stack bound 60 > 40 LDS entries -> the overflow variant runs
+        assert sc_depth >= 39 and sc_need > 40  # more than the 40 LDS entries -> the overflow variant runs
 
 
 def test_intersect_edge_cases(gpu, oracle):

@@ -195,3 +195,60 @@ def test_native_cli_usage():
     assert r.returncode == 0 and "--outfile" in r.stderr and "--nthreads" in r.stderr and "--quick" in r.stderr
     assert subprocess.run([CLI_PATH], capture_output=True).returncode == 1  # no scene files
     assert subprocess.run([CLI_PATH, "--bogus"], capture_output=True).returncode == 2
+
+
+def _check_quads(quads, need, P, idx, order):
+    """Decode the quantised 4-wide tree and check its invariants: every decoded child box encloses
+    everything below it (exact arithmetic), every leaf slot is reachable exactly once, and no walk can
+    hold more stack entries than `need`."""
+    f = quads.view(np.float32)
+    tri_lo = P[idx[order]].min(1).astype(np.float64)
+    tri_hi = P[idx[order]].max(1).astype(np.float64)
+    seen = np.zeros(len(order), int)
+    worst = 0
+
+    def visit(q, held):
+        nonlocal worst
+        origin = f[q, 0:3].astype(np.float64)
+        eb = int(quads[q, 3])
+        cell = np.array([2.0 ** (((eb >> (8 * a)) & 0xFF) - 127) for a in range(3)])
+        qlo = [quads[q, 4 + a] for a in range(3)]
+        qhi = [quads[q, 7], quads[q, 8], quads[q, 9]]
+        refs = quads[q, 12:16]
+        kids = [k for k in range(4) if refs[k] != 0xFFFFFFFF]
+        held += len(kids) - 1
+        worst = max(worst, held)
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        for k in range(4):
+            blo = np.array([origin[a] + ((int(qlo[a]) >> (8 * k)) & 0xFF) * cell[a] for a in range(3)])
+            bhi = np.array([origin[a] + ((int(qhi[a]) >> (8 * k)) & 0xFF) * cell[a] for a in range(3)])
+            if k not in kids:
+                assert k >= 1 and (blo >= bhi).all()  # unused slots come last; inverted box wherever the node has extent
+                continue
+            r = int(refs[k])
+            if r & 0x80000000:
+                cnt, first = (r >> 24) & 0x7F, r & 0xFFFFFF
+                assert cnt >= 1
+                seen[first:first + cnt] += 1
+                tlo, thi = tri_lo[first:first + cnt].min(0), tri_hi[first:first + cnt].max(0)
+            else:
+                tlo, thi = visit(r, held)
+            assert (blo <= tlo).all() and (bhi >= thi).all(), (q, k, blo, tlo, bhi, thi)
+            lo_all, hi_all = np.minimum(lo_all, tlo), np.maximum(hi_all, thi)
+        return lo_all, hi_all
+
+    visit(0, 0)
+    assert (seen == 1).all(), f"{(seen != 1).sum()} leaf slots not reached exactly once"
+    assert worst <= need, (worst, need)
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "ties", "deep"])
+def test_quantised_quad_tree_invariants(name, split):
+    import sys
+    sys.setrecursionlimit(10000)
+    sd = SMALL_SCENES[name]()
+    nodes, order, depth = pbrt_amd.bvh_build_host(sd.P, sd.idx)
+    quads, need = pbrt_amd.quad_build_host(sd.P, sd.idx, split_leaves=split)
+    assert len(quads) > 0 and need >= 1
+    _check_quads(quads, need, sd.P, sd.idx, order)
