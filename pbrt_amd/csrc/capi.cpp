@@ -165,6 +165,7 @@ struct QuadChild {
   uint32_t leaf_node;  // binary leaf to expand into its own quad node, or 0xffffffff
 };
 void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, QuadNodes *out) {
+  static const bool greedy = !(std::getenv("PBRT_HIP_GREEDY_COLLAPSE") && std::getenv("PBRT_HIP_GREEDY_COLLAPSE")[0] == '0');
   if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
   auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
   struct Item { uint32_t node, quad, path; bool is_leaf; };  // path = stack entries held above this node
@@ -188,25 +189,57 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
       k.leaf_node = (split_leaves && cnt >= 2 && cnt <= 4) ? c : 0xffffffffu;
       kids[nk++] = k;
     };
+    auto tri_child = [&](uint32_t slot) {
+      const uint32_t t = b.order[slot];
+      QuadChild k;
+      for (int a = 0; a < 3; a++) {
+        const float v0 = P[3 * idx[3 * t] + a], v1 = P[3 * idx[3 * t + 1] + a], v2 = P[3 * idx[3 * t + 2] + a];
+        k.lo[a] = std::min(v0, std::min(v1, v2));
+        k.hi[a] = std::max(v0, std::max(v1, v2));
+      }
+      k.ref = kLeafRef | (1u << 24) | slot;
+      k.node = k.leaf_node = 0xffffffffu;
+      return k;
+    };
     if (it.is_leaf) {  // expand a leaf: one child per triangle, boxed by its own bounds
       const uint32_t cnt = me.count_axis & 0xffffu;
-      for (uint32_t j = 0; j < cnt; j++) {
-        const uint32_t t = b.order[me.offset + j];
-        QuadChild k;
-        for (int a = 0; a < 3; a++) {
-          const float v0 = P[3 * idx[3 * t] + a], v1 = P[3 * idx[3 * t + 1] + a], v2 = P[3 * idx[3 * t + 2] + a];
-          k.lo[a] = std::min(v0, std::min(v1, v2));
-          k.hi[a] = std::max(v0, std::max(v1, v2));
-        }
-        k.ref = kLeafRef | (1u << 24) | (me.offset + j);
-        k.node = k.leaf_node = 0xffffffffu;
-        kids[nk++] = k;
-      }
+      for (uint32_t j = 0; j < cnt; j++) kids[nk++] = tri_child(me.offset + j);
     } else {
-      const uint32_t two[2] = {it.node + 1, me.offset};
-      for (uint32_t c : two) {
-        if ((b.nodes[c].count_axis & 0xffffu) == 0) { add_node(c + 1); add_node(b.nodes[c].offset); }
-        else add_node(c);
+      // Greedy collapse: start from the two children of the binary node and keep opening the child with the
+      // largest surface area (an interior node into its two children, a small leaf into its triangles) while
+      // the result still fits four slots.
+      add_node(it.node + 1);
+      add_node(me.offset);
+      auto area = [](const QuadChild &k) {
+        const float dx = k.hi[0] - k.lo[0], dy = k.hi[1] - k.lo[1], dz = k.hi[2] - k.lo[2];
+        return (dx * dy + dx * dz) + dy * dz;
+      };
+      for (;;) {
+        int best = -1;
+        float best_area = -1.f;
+        for (int k = 0; k < nk; k++) {
+          const QuadChild &c = kids[k];
+          const uint32_t grow = c.node != 0xffffffffu ? 1u : (c.leaf_node != 0xffffffffu ? (b.nodes[c.leaf_node].count_axis & 0xffffu) - 1u : 99u);
+          if (greedy && (uint32_t)nk + grow <= 4u && area(c) > best_area) { best = k; best_area = area(c); }
+        }
+        if (best < 0) break;
+        const QuadChild c = kids[best];
+        kids[best] = kids[--nk];
+        if (c.node != 0xffffffffu) {
+          add_node(c.node + 1);
+          add_node(b.nodes[c.node].offset);
+        } else {
+          const BvhNode &lf = b.nodes[c.leaf_node];
+          for (uint32_t j = 0; j < (lf.count_axis & 0xffffu); j++) kids[nk++] = tri_child(lf.offset + j);
+        }
+      }
+      if (!greedy) {  // the plain collapse: both children opened once
+        nk = 0;
+        const uint32_t two[2] = {it.node + 1, me.offset};
+        for (uint32_t c : two) {
+          if ((b.nodes[c].count_axis & 0xffffu) == 0) { add_node(c + 1); add_node(b.nodes[c].offset); }
+          else add_node(c);
+        }
       }
     }
     const uint32_t path = it.path + (uint32_t)(nk - 1);
