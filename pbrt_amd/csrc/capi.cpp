@@ -61,13 +61,13 @@ Shard make_shard(int32_t xres, int32_t yres, const float crop[4], uint32_t rank,
 // Scheduling thresholds of the traversal loop (kernels.hip trav_run).  They change only how lanes
 // are interleaved, never a result; PBRT_HIP_MIN_WALKERS / PBRT_HIP_MIN_PARKED override them for
 // tuning runs.
-uint32_t tuning(const char *name, uint32_t dflt) {
+uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
   const char *v = std::getenv(name);
   if (!v || !*v) return dflt;
   long x = std::strtol(v, nullptr, 10);
-  return x < 0 ? 0u : (x > 64 ? 64u : (uint32_t)x);
+  return x < 0 ? 0u : (x > cap ? (uint32_t)cap : (uint32_t)x);
 }
-constexpr uint32_t kMinWalkers = 32, kMinParked = 8;
+constexpr uint32_t kMinWalkers = 32, kMinParked = 8, kRenderWorkgroups = 4096;
 
 constexpr uint32_t kLeafRef = 0x80000000u;
 
@@ -501,7 +501,7 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(s->d_mats.alloc(mats.size()));
     HIP_TRY(s->d_lights.alloc(lights.size()));
     HIP_TRY(s->d_spheres.alloc(spheres.size()));
-    HIP_TRY(s->d_counters.alloc(5));
+    HIP_TRY(s->d_counters.alloc(6));  // [5] is the render kernel's pixel hand-out counter
     HIP_TRY(hipStreamCreate(&s->stream));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
@@ -621,15 +621,20 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.inv_ny = 1.0f / (float)r->spp_y;
     R.slab = (float4 *)d_slab;
     R.counters = s->d_counters.p;
+    // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once
+    // (256 CUs x 16: the LDS stack allows 4 per SIMD), each lane drawing pixel after pixel from the rank's list.
+    R.n_pixels = sh.n_local * 4096u;
+    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", kRenderWorkgroups, 1 << 20)));
+    R.next_pixel = reinterpret_cast<uint32_t *>(s->d_counters.p + 5);
     {
-      const size_t need = (size_t)sh.n_local * 64 * 320;  // float4 records: 64 workgroups per super-tile x 5 x 64
+      const size_t need = (size_t)R.n_workgroups * 320;  // float4 records: 64 workgroups per super-tile x 5 x 64
       if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
       R.lane_state = s->d_lane_state.p;
     }
     {
       // the quad walk keeps kQuadLdsStack entries per lane in LDS; deeper entries (rare) spill here
       const uint32_t extra = s->dev.quad_stack_need > kQuadLdsStack ? s->dev.quad_stack_need - kQuadLdsStack : 0;
-      const size_t need = (size_t)sh.n_local * 64 * 64 * extra;
+      const size_t need = (size_t)R.n_workgroups * 64 * extra;
       if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); HIP_TRY(s->d_stack_overflow.alloc(need)); }
       R.stack_overflow = s->d_stack_overflow.p;
       R.stack_overflow_entries = extra;
@@ -637,7 +642,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);
-    if (counters) HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 5 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 6 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
     HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
     HIP_TRY(hipEventRecord(s->ev1, st));

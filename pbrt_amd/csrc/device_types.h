@@ -48,6 +48,9 @@ struct RenderParams {
   float4 *lane_state;                // 5 x 64 float4 per workgroup: path state parked in HBM (kernels.hip PathState)
   uint32_t *stack_overflow;          // [workgroup][entry][lane]: stack entries beyond the LDS part
   uint32_t stack_overflow_entries;
+  uint32_t *next_pixel;   // hand-out counter of the render kernel's pixel list (zeroed before the launch)
+  uint32_t n_pixels;      // n_local_super * 4096
+  uint32_t n_workgroups;  // one-wave workgroups launched: what the device holds at once, not one per tile
 };
 
 struct RayBatch {

@@ -240,6 +240,13 @@ __device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) { T.cur = ref;
 __device__ __forceinline__ bool trav_parked(const Trav &T) { return T.cur != kDone && (T.cur & kLeafRef) != 0u; }
 __device__ __forceinline__ uint32_t trav_leaf_cnt(const Trav &T) { return trav_parked(T) ? (T.cur >> 24) & 0x7fu : 0u; }
 
+#ifdef PBRT_PHASE_PROBE
+__shared__ unsigned long long s_probe[8];
+__device__ unsigned long long g_probe[8];
+#define PROBE_ADD(i_, v_) do { if (threadIdx.x == 0) s_probe[i_] += (v_); } while (0)
+#else
+#define PROBE_ADD(i_, v_) do { } while (0)
+#endif
 template <bool EXACT>
 __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 d, float tmax, bool any,
                                            unsigned long long &cn) {
@@ -337,7 +344,8 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     // production walk: PBRT_STEPS_PER_CHECK node steps between two scheduling checks (a lane that parks or
     // finishes in the first one idles through the rest; the checks cost about a fifth of a step)
 #pragma unroll
-    for (int rep = 0; !EXACT && rep < PBRT_STEPS_PER_CHECK; rep++)
+    for (int rep = 0; !EXACT && rep < PBRT_STEPS_PER_CHECK; rep++) {
+    { const unsigned long long ma = __ballot(T.cur != kDone && !trav_parked(T)); if (ma) { PROBE_ADD(0, 1); PROBE_ADD(1, __popcll(ma)); } }
     if (T.cur != kDone && !trav_parked(T)) {
       // ---- one step of the production walk: the four children of quantised quad node T.cur (64 bytes) ----
       const uint32_t off = T.cur * 64u;
@@ -394,6 +402,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       if (k1 < kInf) trav_push<OVF>(T, stk, ovf, r1);
       trav_enter(T, k0 < kInf ? r0 : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
     }
+    }
 
     // ---- leaf flush (wave-uniform decision) ----
     const bool parked = trav_parked(T);
@@ -404,6 +413,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       bool stop = false;  // any-hit ray found its hit
       for (uint32_t i = 0;; i++) {
         if (__ballot(cnt > i && !stop) == 0ull) break;
+        PROBE_ADD(2, 1); PROBE_ADD(3, __popcll(__ballot(cnt > i && !stop)));
         if (cnt > i && !stop) {
           const uint32_t slot = first + i;
           const float4 a = *reinterpret_cast<const float4 *>(tris + slot * 48u);
@@ -526,7 +536,7 @@ __device__ __forceinline__ bool sample_light(const DevScene &S, uint32_t li, V3 
   }
 }
 
-enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3 };
+enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FETCH = 4 };
 
 // waves per SIMD the register allocator must leave room for (launch_bounds' 2nd argument)
 #ifndef PBRT_RENDER_WAVES_PER_SIMD
@@ -584,17 +594,18 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   float *stkt = &lds_tn[0][lane];
   uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u + lane;
 
-  // block -> (local super-tile, 8x8 tile inside it, row-major); lane -> pixel
+  // Pixels are handed out dynamically (see the fetch step of the service stage): pixel number `pix` of this
+  // rank is pixel (pix & 63) of 8x8 block ((pix >> 6) & 63) of local super-tile (pix >> 12), both row-major,
+  // which is also its place in the slab.
   const int32_t W = S.cx1 - S.cx0, H = S.cy1 - S.cy0;
   const uint32_t stx = (uint32_t)(W + 63) >> 6;
-  const uint32_t jsup = blockIdx.x >> 6, sub = blockIdx.x & 63u;
-  const uint32_t tsup = R.rank + jsup * R.world;
-  const uint32_t pxs = (sub & 7u) * 8u + (lane & 7u);
-  const uint32_t pys = (sub >> 3) * 8u + (lane >> 3);
-  const int32_t xr = (int32_t)((tsup % stx) * 64u + pxs), yr = (int32_t)((tsup / stx) * 64u + pys);
-  const bool valid = xr < W && yr < H;
-  const int32_t px = S.cx0 + xr, py = S.cy0 + yr;
-  const uint64_t pixel_seq = R.seed * (uint64_t)S.xres * (uint64_t)S.yres + (uint64_t)py * (uint64_t)S.xres + (uint64_t)px;
+  const uint64_t seq0 = R.seed * (uint64_t)S.xres * (uint64_t)S.yres;
+  uint32_t pix = 0;
+  auto pixel_xy = [&](uint32_t q, int32_t &xr, int32_t &yr) {
+    const uint32_t tsup = R.rank + (q >> 12) * R.world;
+    xr = (int32_t)((tsup % stx) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u));
+    yr = (int32_t)((tsup / stx) * 64u + ((q >> 9) & 7u) * 8u + ((q >> 3) & 7u));
+  };
 
   const uint32_t spp = R.spp_x * R.spp_y;
   const uint32_t nL = S.n_lights;
@@ -603,21 +614,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   const TravTuning tune = {R.min_walkers, R.min_parked};
 
   float4 *rec = R.lane_state + (size_t)blockIdx.x * 320u + lane;
-  {
-    PathState P0;
-    P0.sum = {0.f, 0.f, 0.f};
-    P0.L = {0.f, 0.f, 0.f};
-    P0.beta = {1.f, 1.f, 1.f};
-    P0.wi_next = {0.f, 0.f, 0.f};
-    P0.Lpend = {0.f, 0.f, 0.f};
-    pcg_seq(P0.rng, pixel_seq);
-    P0.s = 0;
-    P0.bounces = 0;
-    P0.specular = false;
-    P0.cont = false;
-    path_store(rec, P0);
-  }
-  uint32_t state = valid ? ST_NEW : ST_DONE;
+  uint32_t state = ST_FETCH;
   unsigned long long c_cam = 0, c_bounce = 0, c_shadow = 0, c_nodes = 0, c_tris = 0;
   Trav T;
   T.o = mk(0.f, 0.f, 0.f);
@@ -629,15 +626,22 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   T.occluded = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
 
+#ifdef PBRT_PHASE_PROBE
+  if (lane < 8) s_probe[lane] = 0;
+#endif
   for (;;) {
     // ---- service stage: lanes whose walk is over consume the result and launch the next ray ----
-    if (state != ST_DONE && T.cur == kDone) {
-      PathState P;
+    { const unsigned long long ms = __ballot(state != ST_DONE && T.cur == kDone); if (ms) { PROBE_ADD(4, 1); PROBE_ADD(5, __popcll(ms)); } }
+    const bool serve = state != ST_DONE && T.cur == kDone;
+    PathState P;
+    bool launch = false, launch_any = false;
+    V3 ro = T.o, rd = T.d;
+    float rtmax = kInf;
+    int32_t xr = 0, yr = 0;
+    if (serve && state != ST_FETCH) {
       path_load(rec, P);
-      P.rng.inc = (pixel_seq << 1) | 1u;
-      bool launch = false, launch_any = false;
-      V3 ro = T.o, rd = T.d;
-      float rtmax = kInf;
+      pixel_xy(pix, xr, yr);
+      P.rng.inc = ((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) << 1) | 1u;
       if (state != ST_NEW) {
         if (SPH) trav_spheres(S, T);
         bool advance = false;  // take the prepared bounce (or end the sample)
@@ -758,23 +762,59 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
           P.cont = false;
         }
       }
-      if (state == ST_NEW) {
-        if (P.s == spp) {
+      if (state == ST_NEW && P.s == spp) {
+        // Film::merge_film_tile (core/film.rs:313-326): xyz = rgb_to_xyz(contrib_sum), weight = spp
+        float4 o;
+        o.x = 0.412453f * P.sum.x + 0.357580f * P.sum.y + 0.180423f * P.sum.z;
+        o.y = 0.212671f * P.sum.x + 0.715160f * P.sum.y + 0.072169f * P.sum.z;
+        o.z = 0.019334f * P.sum.x + 0.119193f * P.sum.y + 0.950227f * P.sum.z;
+        o.w = (float)spp;
+        R.slab[(size_t)(pix >> 12) * 4096u + (((pix >> 9) & 7u) * 8u + ((pix >> 3) & 7u)) * 64u + ((pix >> 6) & 7u) * 8u + (pix & 7u)] = o;
+        state = ST_FETCH;  // this lane takes another pixel
+      }
+    }
+    // ---- fetch: lanes without a pixel draw the next ones of this rank's pixel list (wave-uniform; one
+    // atomic per wave and round).  A pixel stays with its lane for all its samples, so its RNG stream, sample
+    // order and film sum are those of DESIGN.md 3.1 whichever lane happens to take it; what the dynamic
+    // hand-out removes is the idling of lanes whose pixels have short paths (sky) beside long ones. ----
+    for (;;) {
+      const unsigned long long mw = __ballot(state == ST_FETCH);
+      if (mw == 0ull) break;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(R.next_pixel, (uint32_t)__popcll(mw));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (state == ST_FETCH) {
+        const uint32_t q = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+        if (q >= R.n_pixels) {
           state = ST_DONE;
-          // Film::merge_film_tile (core/film.rs:313-326): xyz = rgb_to_xyz(contrib_sum), weight = spp
-          float4 o;
-          o.x = 0.412453f * P.sum.x + 0.357580f * P.sum.y + 0.180423f * P.sum.z;
-          o.y = 0.212671f * P.sum.x + 0.715160f * P.sum.y + 0.072169f * P.sum.z;
-          o.z = 0.019334f * P.sum.x + 0.119193f * P.sum.y + 0.950227f * P.sum.z;
-          o.w = (float)spp;
-          R.slab[(size_t)jsup * 4096u + pys * 64u + pxs] = o;
         } else {
+          pixel_xy(q, xr, yr);
+          if (xr < W && yr < H) {  // (pixels of a ragged super-tile outside the image are skipped)
+            pix = q;
+            P.sum = {0.f, 0.f, 0.f};
+            P.L = {0.f, 0.f, 0.f};
+            P.beta = {1.f, 1.f, 1.f};
+            P.wi_next = {0.f, 0.f, 0.f};
+            P.Lpend = {0.f, 0.f, 0.f};
+            pcg_seq(P.rng, seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr));
+            P.s = 0;
+            P.bounces = 0;
+            P.specular = false;
+            P.cont = false;
+            state = ST_NEW;
+          }
+        }
+      }
+    }
+    if (serve && state != ST_DONE) {
+      if (state == ST_NEW) {
+        if (true) {
           // stratified camera sample and PerspectiveCamera ray (3.2)
           const uint32_t sx = P.s % R.spp_x, sy = P.s / R.spp_x;
           const float u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
           const float jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
           const float jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
-          const float fx = (float)px + jx, fy = (float)py + jy;
+          const float fx = (float)(S.cx0 + xr) + jx, fy = (float)(S.cy0 + yr) + jy;
           const V3 dc = unit(mk(fx * S.cam_ax + S.cam_bx, fy * S.cam_ay + S.cam_by, 1.0f));
           rd = {(S.c2w[0] * dc.x + S.c2w[1] * dc.y) + S.c2w[2] * dc.z,
                 (S.c2w[4] * dc.x + S.c2w[5] * dc.y) + S.c2w[6] * dc.z,
@@ -798,6 +838,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
     trav_run<EXACT, COUNT, (!EXACT && STACK != 0)>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
+#ifdef PBRT_PHASE_PROBE
+  if (lane < 8) atomicAdd(&g_probe[lane], s_probe[lane]);
+#endif
   if (COUNT) {
     unsigned long long v[5] = {c_cam, c_bounce, c_shadow, c_nodes, c_tris};
     for (int i = 0; i < 5; i++) {
@@ -808,6 +851,13 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   }
 }
 
+#ifdef PBRT_PHASE_PROBE
+__global__ void probe_dump() {
+  printf("PROBE step waves %llu lanes %llu | flush waves %llu lanes %llu | service waves %llu lanes %llu\n", g_probe[0], g_probe[1],
+         g_probe[2], g_probe[3], g_probe[4], g_probe[5]);
+  for (int i = 0; i < 8; i++) g_probe[i] = 0;
+}
+#endif
 // The traversal loop alone over a ray batch, as persistent waves with dynamic fetch: a lane whose
 // walk is over writes its result and pulls its next ray while the other lanes keep walking.
 template <bool SPH, bool COUNT, int STACK>
@@ -896,7 +946,7 @@ __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int
 template <bool SPH, bool COUNT, bool EXACT>
 static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t depth,
                                   hipStream_t st) {
-  const dim3 grid(n_local_super * 64u), block(64);
+  const dim3 grid(R.n_workgroups), block(64);
   // the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
   if (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
     if (S.quad_stack_need > kQuadLdsStack) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
@@ -916,6 +966,14 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
                          int counters, hipStream_t stream) {
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
+#ifdef PBRT_PHASE_PROBE
+  if (counters == 0) {
+    hipError_t e = sph ? launch_render_t<true, false, false>(S, R, n_local_super, bvh_depth, stream)
+                       : launch_render_t<false, false, false>(S, R, n_local_super, bvh_depth, stream);
+    probe_dump<<<1, 1, 0, stream>>>();
+    return e;
+  }
+#endif
   if (counters == 1)
     return sph ? launch_render_t<true, true, true>(S, R, n_local_super, bvh_depth, stream)
                : launch_render_t<false, true, true>(S, R, n_local_super, bvh_depth, stream);
