@@ -291,7 +291,8 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
     uint4 *q = &out->q[4 * (size_t)it.quad];
     q[0] = make_uint4(as_u(me.lo[0]), as_u(me.lo[1]), as_u(me.lo[2]), ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16));
     q[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
-    q[2] = make_uint4(qhi[1], qhi[2], 0u, 0u);
+    // the three cell sizes once more as bf16 (a power of two is exact in it): the kernel decodes each with one shift / mask
+    q[2] = make_uint4(qhi[1], qhi[2], (ebyte[0] << 7) | (ebyte[1] << 23), ebyte[2] << 7);
     q[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
   }
 }
@@ -633,7 +634,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     }
     {
       // the quad walk keeps kQuadLdsStack entries per lane in LDS; deeper entries (rare) spill here
-      const uint32_t extra = s->dev.quad_stack_need > kQuadLdsStack ? s->dev.quad_stack_need - kQuadLdsStack : 0;
+      const uint32_t extra = s->dev.quad_stack_need + 1u > kQuadLdsStack ? s->dev.quad_stack_need + 1u - kQuadLdsStack : 0;  // + 1: sentinel
       const size_t need = (size_t)R.n_workgroups * 64 * extra;
       if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); HIP_TRY(s->d_stack_overflow.alloc(need)); }
       R.stack_overflow = s->d_stack_overflow.p;
@@ -787,7 +788,7 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
   }
   {
     // launch_intersect uses at most 4096 workgroups of 4 waves
-    const uint32_t extra = s->dev.quad_stack_need > kQuadLdsStack ? s->dev.quad_stack_need - kQuadLdsStack : 0;
+    const uint32_t extra = s->dev.quad_stack_need + 1u > kQuadLdsStack ? s->dev.quad_stack_need + 1u - kQuadLdsStack : 0;  // + 1: sentinel
     const size_t need = (size_t)4096 * 4 * 64 * extra;
     if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); RB_TRY(s->d_stack_overflow.alloc(need)); }
     B.stack_overflow = s->d_stack_overflow.p;

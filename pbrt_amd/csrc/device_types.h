@@ -16,7 +16,10 @@
 
 namespace pbrt_hip {
 
-constexpr uint32_t kQuadLdsStack = 40;  // LDS entries per lane of the quad walk's stack
+#ifndef PBRT_QUAD_LDS_STACK
+#define PBRT_QUAD_LDS_STACK 40
+#endif
+constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK;  // LDS entries per lane of the quad walk's stack
 
 struct DevScene {
   const uint4 *nodes;

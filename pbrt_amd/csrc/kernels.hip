@@ -243,17 +243,21 @@ __device__ __forceinline__ uint32_t trav_leaf_cnt(const Trav &T) { return trav_p
 #ifdef PBRT_PHASE_PROBE
 __shared__ unsigned long long s_probe[8];
 __device__ unsigned long long g_probe[8];
-#define PROBE_ADD(i_, v_) do { if (threadIdx.x == 0) s_probe[i_] += (v_); } while (0)
+#define PROBE_ADD(i_, v_) do { const unsigned long long pv_ = (v_); if (threadIdx.x == 0) s_probe[i_] += pv_; } while (0)
 #else
 #define PROBE_ADD(i_, v_) do { } while (0)
 #endif
 template <bool EXACT>
-__device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, V3 o, V3 d, float tmax, bool any,
+__device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t *stk, V3 o, V3 d, float tmax, bool any,
                                            unsigned long long &cn) {
   T.o = o;
   T.d = d;
   T.tmax = tmax;
   T.sp = 0;
+  if (!EXACT) {  // production walk: entry 0 is a sentinel, so that popping needs no emptiness test
+    stk[0] = kDone;
+    T.sp = 1;
+  }
   T.any = any ? 1u : 0u;
   T.occluded = 0;
   T.h.t = kInf;
@@ -368,39 +372,61 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const float gx = (o.x - __uint_as_float(W0.x)) * inv.x, gy = (o.y - __uint_as_float(W0.y)) * inv.y;
       const float gz = (o.z - __uint_as_float(W0.z)) * inv.z;
       const float mx = fabsf(gx) * 0x1.8p-22f, my = fabsf(gy) * 0x1.8p-22f, mz = fabsf(gz) * 0x1.8p-22f;
-      const float gnx = -(gx + mx), gfx = -(gx - mx), gny = -(gy + my), gfy = -(gy - my), gnz = -(gz + mz), gfz = -(gz - mz);
-      const float cix = __uint_as_float((W0.w & 0xffu) << 23) * inv.x, ciy = __uint_as_float(((W0.w >> 8) & 0xffu) << 23) * inv.y;
-      const float ciz = __uint_as_float(((W0.w >> 16) & 0xffu) << 23) * inv.z;
+      const f32x2 gxx = {gx + mx, gx - mx}, gyy = {gy + my, gy - my}, gzz = {gz + mz, gz - mz};  // {near, far}: subtracted below
+      const float cix = __uint_as_float(W2.z << 16) * inv.x, ciy = __uint_as_float(W2.z & 0xffff0000u) * inv.y;
+      const float ciz = __uint_as_float(W2.w << 16) * inv.z;
       // near / far planes by the sign of the inverse direction: one select per axis serves all four
       // children (a dword holds the four children's bytes of one plane)
       const uint32_t bnx = negx ? W1.w : W1.x, bfx = negx ? W1.x : W1.w;
       const uint32_t bny = negy ? W2.x : W1.y, bfy = negy ? W1.y : W2.x;
       const uint32_t bnz = negz ? W2.y : W1.z, bfz = negz ? W1.z : W2.y;
+      // {near, far} of one axis side by side: one packed fma (v_pk_fma_f32, IEEE per element) per child and axis
+      const f32x2 cxx = {cix, cix}, cyy = {ciy, ciy}, czz = {ciz, ciz};
       float key[4];
+      bool hit[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float tnx = __fmaf_rn((float)((bnx >> (8 * k)) & 0xffu), cix, gnx), tfx = __fmaf_rn((float)((bfx >> (8 * k)) & 0xffu), cix, gfx);
-        const float tny = __fmaf_rn((float)((bny >> (8 * k)) & 0xffu), ciy, gny), tfy = __fmaf_rn((float)((bfy >> (8 * k)) & 0xffu), ciy, gfy);
-        const float tnz = __fmaf_rn((float)((bnz >> (8 * k)) & 0xffu), ciz, gnz), tfz = __fmaf_rn((float)((bfz >> (8 * k)) & 0xffu), ciz, gfz);
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, kRayTMin));
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tfar));
-        key[k] = tn <= tf * kBoxPad ? tn : kInf;
+        const f32x2 qx = {(float)((bnx >> (8 * k)) & 0xffu), (float)((bfx >> (8 * k)) & 0xffu)};
+        const f32x2 qy = {(float)((bny >> (8 * k)) & 0xffu), (float)((bfy >> (8 * k)) & 0xffu)};
+        const f32x2 qz = {(float)((bnz >> (8 * k)) & 0xffu), (float)((bfz >> (8 * k)) & 0xffu)};
+        const f32x2 tx = __builtin_elementwise_fma(qx, cxx, -gxx), ty = __builtin_elementwise_fma(qy, cyy, -gyy);
+        const f32x2 tz = __builtin_elementwise_fma(qz, czz, -gzz);
+        const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kRayTMin));
+        const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar));
+        hit[k] = tn <= tf * kBoxPad;
+        key[k] = tn;
       }
       // an unused child slot (ref kDone) must never be taken: its inverted box does not exclude it on an axis where
       // the node is flat or the ray is parallel to the slab
-      if (W3.z == kDone) key[2] = kInf;  // (slots 0 and 1 are always used: every node has >= 2 children)
-      if (W3.w == kDone) key[3] = kInf;
-      // order the children by entry distance (missed ones count as +inf): nearest first, the others
-      // stacked.  Order affects only speed (tie rule of 3.4); a full sort of the rest was 1 % slower.
-      float k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3];
-      uint32_t r0 = W3.x, r1 = W3.y, r2 = W3.z, r3 = W3.w;
-      cswap(k0, r0, k1, r1);
-      cswap(k2, r2, k3, r3);
-      cswap(k0, r0, k2, r2);  // three comparators: the nearest child is in front, the rest keep an arbitrary order
-      if (k3 < kInf) trav_push<OVF>(T, stk, ovf, r3);
-      if (k2 < kInf) trav_push<OVF>(T, stk, ovf, r2);
-      if (k1 < kInf) trav_push<OVF>(T, stk, ovf, r1);
-      trav_enter(T, k0 < kInf ? r0 : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
+      hit[2] = hit[2] && W3.z != kDone;  // (slots 0 and 1 are always used: every node has >= 2 children)
+      hit[3] = hit[3] && W3.w != kDone;
+#pragma unroll
+      for (int k = 0; k < 4; k++) key[k] = hit[k] ? key[k] : kInf;
+      // The nearest child hit is entered, the other hit ones are stacked in slot order.  Order affects only
+      // speed (tie rule of 3.4); sorting the stacked ones cost more than it saved.
+      const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
+      const bool n0 = key[0] == kmin, n1 = !n0 && key[1] == kmin, n2 = !n0 && !n1 && key[2] == kmin;
+      const bool n3 = !n0 && !n1 && !n2;
+      if (OVF) {
+        if (hit[3] && !n3) trav_push<OVF>(T, stk, ovf, W3.w);
+        if (hit[2] && !n2) trav_push<OVF>(T, stk, ovf, W3.z);
+        if (hit[1] && !n1) trav_push<OVF>(T, stk, ovf, W3.y);
+        if (hit[0] && !n0) trav_push<OVF>(T, stk, ovf, W3.x);
+      } else {
+        // branch-free: the slot above the stack top is scratch (the launcher keeps one LDS row spare)
+        stk[T.sp * 64u] = W3.w; T.sp += (hit[3] && !n3) ? 1u : 0u;
+        stk[T.sp * 64u] = W3.z; T.sp += (hit[2] && !n2) ? 1u : 0u;
+        stk[T.sp * 64u] = W3.y; T.sp += (hit[1] && !n1) ? 1u : 0u;
+        stk[T.sp * 64u] = W3.x; T.sp += (hit[0] && !n0) ? 1u : 0u;
+      }
+      const bool any_hit = hit[0] || hit[1] || hit[2] || hit[3];
+      if (OVF) {
+        trav_enter(T, any_hit ? (n0 ? W3.x : (n1 ? W3.y : (n2 ? W3.z : W3.w))) : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
+      } else {
+        const uint32_t top = stk[(T.sp - 1u) * 64u];  // T.sp >= 1 while the lane walks: entry 0 is the sentinel kDone
+        T.sp -= any_hit ? 0u : 1u;
+        trav_enter(T, any_hit ? (n0 ? W3.x : (n1 ? W3.y : (n2 ? W3.z : W3.w))) : top);
+      }
     }
     }
 
@@ -832,7 +858,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
         }
       }
       path_store(rec, P);
-      if (launch) trav_begin<EXACT>(S, T, ro, rd, rtmax, launch_any, c_nodes);
+      if (launch) trav_begin<EXACT>(S, T, stk, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
     trav_run<EXACT, COUNT, (!EXACT && STACK != 0)>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
@@ -899,7 +925,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(const DevScene S, const 
       if (next < B.n) {
         idx = next;
         next += stride;
-        trav_begin<COUNT>(S, T, mk(B.o[3 * idx], B.o[3 * idx + 1], B.o[3 * idx + 2]),
+        trav_begin<COUNT>(S, T, stk, mk(B.o[3 * idx], B.o[3 * idx + 1], B.o[3 * idx + 2]),
                           mk(B.d[3 * idx], B.d[3 * idx + 1], B.d[3 * idx + 2]), B.tmax[idx], any_hit != 0, cn);
         have = true;
       }
@@ -949,7 +975,7 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
   const dim3 grid(R.n_workgroups), block(64);
   // the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
   if (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
-    if (S.quad_stack_need > kQuadLdsStack) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
+    if (S.quad_stack_need + 2u > kQuadLdsStack) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
     else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, 0, st, S, R);
     return hipGetLastError();
   }
