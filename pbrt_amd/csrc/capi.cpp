@@ -794,7 +794,16 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
     B.stack_overflow = s->d_stack_overflow.p;
     B.stack_overflow_entries = extra;
   }
+  const bool timed = std::getenv("PBRT_HIP_TIME_INTERSECT") != nullptr;  // tuning aid: kernel time to stderr
+  if (timed) RB_TRY(hipEventRecord(s->ev0, s->stream));
   RB_TRY(launch_intersect(s->dev, B, any, s->bvh.depth, s->stream));
+  if (timed) {
+    RB_TRY(hipEventRecord(s->ev1, s->stream));
+    RB_TRY(hipEventSynchronize(s->ev1));
+    float ms = 0.f;
+    RB_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    std::fprintf(stderr, "pbrt_hip intersect kernel: %lld rays %.3f ms %.1f Mrays/s\n", (long long)n, ms, (double)n / ms / 1e3);
+  }
   if (any) {
     RB_TRY(hipMemcpyAsync(occ, d_occ.p, (size_t)n, hipMemcpyDeviceToHost, s->stream));
   } else {
