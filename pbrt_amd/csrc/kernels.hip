@@ -357,6 +357,14 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
       const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
       const uint4 W3 = *reinterpret_cast<const uint4 *>(quads + off + 48u);
+#ifdef PBRT_EXTRA_LOADS
+      {
+        uint4 X0, X1;
+        const char *pp = quads + off;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:32\n\ts_waitcnt vmcnt(0)" : "=&v"(X0), "=&v"(X1) : "v"(pp) : "memory");
+        if ((X0.x ^ X1.y) == 0x9e3779b9u && X0.z == 0x12345u) T.tmax = 0.f;
+      }
+#endif
       if (COUNT) cn++;  // one 64-byte fetch
       const float tfar = fminf(T.h.t, T.tmax);
       // Node-relative slab test.  A decoded plane is the REAL number origin + q * cell (the builder
@@ -899,6 +907,10 @@ __global__ void __launch_bounds__(256, PBRT_INTERSECT_WAVES_PER_SIMD) intersect_
   uint32_t *ovf = B.stack_overflow + ((size_t)blockIdx.x * 4u + wave) * B.stack_overflow_entries * 64u + lane;
   const TravTuning tune = {B.min_walkers, B.min_parked};
   unsigned long long cn = 0, ct = 0;
+#ifdef PBRT_PHASE_PROBE
+  if (threadIdx.x < 8) s_probe[threadIdx.x] = 0;  // (thread 0 counts: wave 0 of the block is the sample)
+  __syncthreads();
+#endif
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t next = (int64_t)blockIdx.x * 256 + threadIdx.x, idx = 0;
   bool have = false;
@@ -936,6 +948,9 @@ __global__ void __launch_bounds__(256, PBRT_INTERSECT_WAVES_PER_SIMD) intersect_
     if (__ballot(have) == 0ull) break;
     trav_run<COUNT, COUNT, !COUNT>(S, T, stk, stkt, ovf, have, tune, cn, ct);
   }
+#ifdef PBRT_PHASE_PROBE
+  if (threadIdx.x < 8) atomicAdd(&g_probe[threadIdx.x], s_probe[threadIdx.x]);
+#endif
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       cn += __shfl_down(cn, off, 64);
@@ -1020,6 +1035,9 @@ static hipError_t launch_intersect_t(const DevScene &S, const RayBatch &B, bool 
   const dim3 grid((uint32_t)blocks), block(256);
   if (depth <= 32) hipLaunchKernelGGL((intersect_kernel<SPH, COUNT, 32>), grid, block, 0, st, S, B, any_hit ? 1 : 0);
   else hipLaunchKernelGGL((intersect_kernel<SPH, COUNT, 64>), grid, block, 0, st, S, B, any_hit ? 1 : 0);
+#ifdef PBRT_PHASE_PROBE
+  probe_dump<<<1, 1, 0, st>>>();
+#endif
   return hipGetLastError();
 }
 
