@@ -67,7 +67,7 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
   long x = std::strtol(v, nullptr, 10);
   return x < 0 ? 0u : (x > cap ? (uint32_t)cap : (uint32_t)x);
 }
-constexpr uint32_t kMinWalkers = 32, kMinParked = 8, kRenderWorkgroups = 4096;
+constexpr uint32_t kMinWalkers = 32, kMinParked = 12, kRenderWorkgroups = 4096;
 
 constexpr uint32_t kLeafRef = 0x80000000u;
 

@@ -898,7 +898,7 @@ __global__ void probe_dump() {
 // The traversal loop alone over a ray batch, as persistent waves with dynamic fetch: a lane whose
 // walk is over writes its result and pulls its next ray while the other lanes keep walking.
 template <bool SPH, bool COUNT, int STACK>
-__global__ void __launch_bounds__(256, PBRT_INTERSECT_WAVES_PER_SIMD) intersect_kernel(const DevScene S, const RayBatch B, const int any_hit) {
+__global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIMD)) intersect_kernel(const DevScene S, const RayBatch B, const int any_hit) {
   __shared__ uint32_t lds_stack[4][COUNT ? STACK : kQuadLdsStack][64];
   __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
