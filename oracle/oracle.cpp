@@ -3,12 +3,17 @@
 // the pbrt-v3 SamplerIntegrator::Render / PathIntegrator::Li structure that comment sketches,
 // with every arithmetic choice fixed in DESIGN.md section 3.
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <chrono>
 #include <thread>
 
 #include "oracle_scene.hpp"
 
 namespace orc {
+static bool g_debug_li = false;  // ORC_DEBUG_LI=1: orc_pixel_samples traces every bounce to stderr (parity debugging)
+
 
 // -------- Sampler: stratified pixel position + independent later dimensions --------
 class StratifiedSampler {
@@ -98,6 +103,7 @@ class PathIntegrator {
   // PathIntegrator::Li.  `direct_only_` turns it into the direct-lighting
   // integrator: first non-specular vertex gets its one-light estimate and the path ends.
   Vec3 Li(Ray ray, StratifiedSampler &sampler, RayStats &st) const {
+    if (g_debug_li) std::fprintf(stderr, "ORC sample begins\n");
     Vec3 L = {0, 0, 0}, beta = {1, 1, 1};
     bool specular = false;
     const uint32_t nL = (uint32_t)scene.lights.size();
@@ -108,6 +114,11 @@ class PathIntegrator {
       if (bounces == 0) st.camera++; else st.bounce++;
       Hit h = scene.Intersect(ray, &st.c);
       bool hit = h.prim != 0xffffffffu;
+      if (g_debug_li) {
+        uint32_t tb, lb, bb; std::memcpy(&tb, &h.t, 4); std::memcpy(&lb, &L.x, 4); std::memcpy(&bb, &beta.x, 4);
+        std::fprintf(stderr, "ORC bounce %u prim %u t %08x b1 %a b2 %a L %08x beta %08x\n", bounces, h.prim, tb, h.b1, h.b2, lb, bb);
+        std::fprintf(stderr, "ORC   ray o %a %a %a d %a %a %a\n", ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+      }
       Vec3 p{}, ng{};
       const orc_material *m = nullptr;
       Vec3 wo = -ray.d;
@@ -152,13 +163,19 @@ class PathIntegrator {
           Ray sh;
           if (sample_light(scene.lights[li], po, nf, k, u1, u2, nLf, &Ld, &sh)) {
             st.shadow++;
-            if (!scene.IntersectP(sh, &st.c)) L = L + beta * Ld;
+            const bool occ = scene.IntersectP(sh, &st.c);
+            if (g_debug_li) { uint32_t a; std::memcpy(&a, &Ld.x, 4); std::fprintf(stderr, "ORC   light %u Ld %08x occluded %d tmax %a\n", li, a, (int)occ, sh.tmax); }
+            if (!occ) L = L + beta * Ld;
           }
         }
         if (direct_only_) break;
         float u1 = sampler.Get1D();
         float u2 = sampler.Get1D();
         float z = cosine_sample_about(nf, u1, u2, &wi);
+        if (g_debug_li) {
+          float dx, dy; concentric_sample_disk(u1, u2, &dx, &dy);
+          std::fprintf(stderr, "ORC   cos u1 %a u2 %a dx %a dy %a z %a nf %a %a %a wi %a %a %a\n", u1, u2, dx, dy, z, nf.x, nf.y, nf.z, wi.x, wi.y, wi.z);
+        }
         if (z == 0.f) break;
         beta = beta * k;
         specular = false;
@@ -426,10 +443,12 @@ void orc_camera_ray(const orc_scene *sc, float fx, float fy, float o[3], float d
   d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
 }
 void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int y, float *out) {
+  orc::g_debug_li = std::getenv("ORC_DEBUG_LI") != nullptr;
   PathIntegrator integ(sc->s, r->max_depth, r->integrator == 1);
   RayStats st;
   float px[4];
   render_pixel(sc->s, integ, *r, x, y, px, out, st);
+  orc::g_debug_li = false;
 }
 
 int orc_render(const orc_scene *sc, const orc_render_desc *r, float *film, orc_stats *out, int n_threads) {

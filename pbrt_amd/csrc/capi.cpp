@@ -68,6 +68,7 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
   return x < 0 ? 0u : (x > cap ? (uint32_t)cap : (uint32_t)x);
 }
 constexpr uint32_t kMinWalkers = 32, kMinParked = 12, kRenderWorkgroups = 4096;
+constexpr uint32_t kTwoPhaseMinSpp = 64;  // frames with at least this many samples per pixel are rendered in two launches
 
 constexpr uint32_t kLeafRef = 0x80000000u;
 
@@ -330,6 +331,9 @@ struct pbrt_hip_scene {
   DevBuf<float4> d_tris, d_mats, d_lights, d_spheres;
   DevBuf<float4> d_slab, d_film;          // scratch of pbrt_hip_render()
   DevBuf<float4> d_lane_state;            // per-lane path state records of the render kernel
+  DevBuf<float4> d_pixel_state;           // two-launch frames: parked pixels (2 records each)
+  DevBuf<uint32_t> d_pixel_sort;          // keys, sorted keys, pixel ids, pixel order
+  DevBuf<unsigned char> d_sort_tmp;       // radix sort scratch
   DevBuf<unsigned long long> d_counters;  // 5
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t stream = nullptr;  // own stream of pbrt_hip_render()
@@ -341,7 +345,7 @@ struct pbrt_hip_scene {
   ~pbrt_hip_scene() {
     d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release(); d_quads.release(); d_stack_overflow.release();
     d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
-    d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release();
+    d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release(); d_pixel_state.release(); d_pixel_sort.release(); d_sort_tmp.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -644,8 +648,40 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 6 * sizeof(unsigned long long), st));
+    // One launch renders samples [s_begin, s_end) of every pixel.  A frame with many samples per pixel is rendered
+    // in two launches: the first takes spp/32 samples of every pixel and parks each pixel (film sum, RNG state)
+    // with the cycles it took; the pixels are then ordered by that cost, most expensive first, and the second
+    // launch resumes them in that order -- the cheap pixels go out last and the persistent waves run dry
+    // together (a pixel's samples are sequential, ~0.4 s for C3's 512: with 2 pixels per lane, as on 8 GPUs,
+    // the unordered tail cost 30 %).  Scheduling only: every pixel still sees its samples in order.
+    const uint32_t spp = r->spp_x * r->spp_y;
+    const char *tp = std::getenv("PBRT_HIP_TWO_PHASE");  // "0": always one launch (tuning / A-B runs)
+    const uint32_t s_split = (spp >= kTwoPhaseMinSpp && !(tp && tp[0] == '0')) ? std::max<uint32_t>(1u, spp / 32u) : 0u;
+    R.pixel_state = nullptr;
+    R.pixel_order = nullptr;
+    size_t sort_bytes = 0;
+    if (s_split) {
+      const size_t n = R.n_pixels;
+      if (s->d_pixel_state.n < 2 * n) { s->d_pixel_state.release(); HIP_TRY(s->d_pixel_state.alloc(2 * n)); }
+      if (s->d_pixel_sort.n < 4 * n) { s->d_pixel_sort.release(); HIP_TRY(s->d_pixel_sort.alloc(4 * n)); }
+      HIP_TRY(launch_pixel_order(nullptr, R.n_pixels, nullptr, nullptr, nullptr, nullptr, nullptr, &sort_bytes, st));
+      if (s->d_sort_tmp.n < sort_bytes) { s->d_sort_tmp.release(); HIP_TRY(s->d_sort_tmp.alloc(sort_bytes)); }
+      R.pixel_state = s->d_pixel_state.p;
+      HIP_TRY(hipMemsetAsync(s->d_pixel_state.p, 0, 2 * n * sizeof(float4), st));  // cost 0 = pixel outside the film
+    }
     HIP_TRY(hipEventRecord(s->ev0, st));
+    R.s_begin = 0;
+    R.s_end = s_split ? s_split : spp;
     HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
+    if (s_split) {
+      uint32_t *keys = s->d_pixel_sort.p, *keys_out = keys + R.n_pixels, *vals = keys + 2 * (size_t)R.n_pixels, *order = keys + 3 * (size_t)R.n_pixels;
+      HIP_TRY(launch_pixel_order(R.pixel_state, R.n_pixels, keys, keys_out, vals, order, s->d_sort_tmp.p, &sort_bytes, st));
+      HIP_TRY(hipMemsetAsync(R.next_pixel, 0, sizeof(uint32_t), st));
+      R.pixel_order = order;
+      R.s_begin = s_split;
+      R.s_end = spp;
+      HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
+    }
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
     s->pending_counters = counters != 0;

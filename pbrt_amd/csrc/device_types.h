@@ -54,6 +54,10 @@ struct RenderParams {
   uint32_t *next_pixel;   // hand-out counter of the render kernel's pixel list (zeroed before the launch)
   uint32_t n_pixels;      // n_local_super * 4096
   uint32_t n_workgroups;  // one-wave workgroups launched: what the device holds at once, not one per tile
+  // A frame may be rendered in two launches (capi.cpp render_device): samples [s_begin, s_end) of every pixel.
+  uint32_t s_begin, s_end;
+  float4 *pixel_state;        // [n_pixels][2]: {sum.xyz, cycles spent}{rng state lo, hi, -, -} between the launches
+  const uint32_t *pixel_order;  // the order in which pixels are handed out (null: 0, 1, 2, ...)
 };
 
 struct RayBatch {
@@ -75,6 +79,10 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);
+// keys[q] = coarse log2 of the cycles pixel q took in the first launch (0 = not rendered), vals[q] = q; then
+// vals sorted by descending key (stable) into `order`.  `tmp` / `tmp_bytes`: scratch (query with tmp == nullptr).
+hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint32_t *keys, uint32_t *keys_out, uint32_t *vals,
+                              uint32_t *order, void *tmp, size_t *tmp_bytes, hipStream_t stream);
 hipError_t launch_assemble(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
                            uint32_t n_local_super, hipStream_t stream);
 

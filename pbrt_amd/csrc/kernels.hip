@@ -39,7 +39,7 @@ constexpr float kShadowShrink = 0.9999f;
 constexpr float kBoxPad = 0x1.000006p+0f;  // 1 + 2*gamma(3)
 constexpr float kInvPi = 0.31830988618379067154f;
 constexpr float kPiOver4 = 0.78539816339744830961f;
-constexpr float kOneMinusEps = 0x1.fffffep-1f;  // 1 - f32::EPSILON, core/rng.rs:19
+constexpr float kOneMinusEps = 0x1.fffffcp-1f;  // 1 - f32::EPSILON = 1 - 2^-23, core/rng.rs:19 (NOT pbrt-v3's 1 - 2^-24)
 constexpr uint32_t kNoPrim = 0xffffffffu;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -589,6 +589,7 @@ struct PathState {
   Pcg rng;     // rng.inc is recomputed from the pixel, only the state is stored
   uint32_t s, bounces;
   bool specular, cont;
+  uint32_t t0lo, t0hi;  // clock when the lane took the pixel (two-launch frames: the pixel's cost estimate)
 };
 __device__ __forceinline__ void path_store(float4 *rec, const PathState &P) {
   rec[0] = make_float4(P.sum.x, P.sum.y, P.sum.z, P.L.x);
@@ -596,7 +597,8 @@ __device__ __forceinline__ void path_store(float4 *rec, const PathState &P) {
   rec[128] = make_float4(P.beta.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
   rec[192] = make_float4(P.Lpend.x, P.Lpend.y, P.Lpend.z,
                          __uint_as_float(P.s | (P.bounces << 20) | (P.specular ? 1u << 30 : 0u) | (P.cont ? 1u << 31 : 0u)));
-  rec[256] = make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)), 0.f, 0.f);
+  rec[256] = make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)),
+                         __uint_as_float(P.t0lo), __uint_as_float(P.t0hi));
 }
 __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
   const float4 a = rec[0], b = rec[64], c = rec[128], d = rec[192], e = rec[256];
@@ -611,6 +613,8 @@ __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
   P.specular = (w >> 30) & 1u;
   P.cont = (w >> 31) & 1u;
   P.rng.state = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
+  P.t0lo = __float_as_uint(e.z);
+  P.t0hi = __float_as_uint(e.w);
 }
 
 // COUNT: accumulate ray / visit counters.  EXACT (needs COUNT): walk the tree in exactly the oracle's
@@ -680,11 +684,23 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
         if (SPH) trav_spheres(S, T);
         bool advance = false;  // take the prepared bounce (or end the sample)
         if (state == ST_SHADOW) {
+#ifdef PBRT_DEBUG_PIXEL_X
+          if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+            printf("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(P.Lpend.x), T.occluded, T.tmax);
+#endif
           if (!T.occluded) P.L = P.L + P.Lpend;
           advance = true;
         } else {
           const HitRec h = T.h;
           const bool hit = h.prim != kNoPrim;
+#ifdef PBRT_DEBUG_PIXEL_X
+          if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+          {
+            printf("HIP s %u bounce %u prim %u t %08x b1 %a b2 %a L %08x beta %08x\n", P.s, P.bounces, h.prim, __float_as_uint(h.t), h.b1, h.b2,
+                   __float_as_uint(P.L.x), __float_as_uint(P.beta.x));
+            printf("HIP s %u   ray o %a %a %a d %a %a %a\n", P.s, T.o.x, T.o.y, T.o.z, T.d.x, T.d.y, T.d.z);
+          }
+#endif
           V3 p = {0.f, 0.f, 0.f}, ng = {0.f, 0.f, 1.f};
           float4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
           const V3 wo = -T.d;
@@ -742,6 +758,10 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
               } else {
                 const float u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
                 const float z = cosine_about(nf, u1, u2, P.wi_next);
+#ifdef PBRT_DEBUG_PIXEL_X
+                if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+                  printf("HIP s %u   cos u1 %a u2 %a z %a nf %a %a %a wi %a %a %a\n", P.s, u1, u2, z, nf.x, nf.y, nf.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
+#endif
                 if (z == 0.f) alive = false;
                 else { P.beta = P.beta * k; P.specular = false; }
               }
@@ -789,6 +809,10 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
             // radiance sanitising of SamplerIntegrator::Render, then FilmTile::AddSample (box filter)
             const float y = (0.212671f * P.L.x + 0.715160f * P.L.y) + 0.072169f * P.L.z;
             if (isnan(P.L.x) || isnan(P.L.y) || isnan(P.L.z) || y < -1e-5f || isinf(y)) P.L = {0.f, 0.f, 0.f};
+#ifdef PBRT_DEBUG_PIXEL_X  // parity debugging: per-sample radiance of one pixel, to diff against oracle pixel_samples()
+            if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+              printf("SAMPLE %u %08x %08x %08x\n", P.s, __float_as_uint(P.L.x), __float_as_uint(P.L.y), __float_as_uint(P.L.z));
+#endif
             P.sum = P.sum + P.L;
             P.s++;
             state = ST_NEW;
@@ -796,14 +820,23 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
           P.cont = false;
         }
       }
-      if (state == ST_NEW && P.s == spp) {
-        // Film::merge_film_tile (core/film.rs:313-326): xyz = rgb_to_xyz(contrib_sum), weight = spp
-        float4 o;
-        o.x = 0.412453f * P.sum.x + 0.357580f * P.sum.y + 0.180423f * P.sum.z;
-        o.y = 0.212671f * P.sum.x + 0.715160f * P.sum.y + 0.072169f * P.sum.z;
-        o.z = 0.019334f * P.sum.x + 0.119193f * P.sum.y + 0.950227f * P.sum.z;
-        o.w = (float)spp;
-        R.slab[(size_t)(pix >> 12) * 4096u + (((pix >> 9) & 7u) * 8u + ((pix >> 3) & 7u)) * 64u + ((pix >> 6) & 7u) * 8u + (pix & 7u)] = o;
+      if (state == ST_NEW && P.s == R.s_end) {
+        if (R.s_end == spp) {
+          // Film::merge_film_tile (core/film.rs:313-326): xyz = rgb_to_xyz(contrib_sum), weight = spp
+          float4 o;
+          o.x = 0.412453f * P.sum.x + 0.357580f * P.sum.y + 0.180423f * P.sum.z;
+          o.y = 0.212671f * P.sum.x + 0.715160f * P.sum.y + 0.072169f * P.sum.z;
+          o.z = 0.019334f * P.sum.x + 0.119193f * P.sum.y + 0.950227f * P.sum.z;
+          o.w = (float)spp;
+          R.slab[(size_t)(pix >> 12) * 4096u + (((pix >> 9) & 7u) * 8u + ((pix >> 3) & 7u)) * 64u + ((pix >> 6) & 7u) * 8u + (pix & 7u)] = o;
+        } else {
+          // first launch of a two-launch frame: park the pixel (the second launch resumes it at sample s_end)
+          // together with the cycles it took, the cost estimate by which the second launch orders the pixels
+          const uint64_t dt = (uint64_t)clock64() - ((uint64_t)P.t0lo | ((uint64_t)P.t0hi << 32));
+          R.pixel_state[2 * (size_t)pix] = make_float4(P.sum.x, P.sum.y, P.sum.z, (float)dt);
+          R.pixel_state[2 * (size_t)pix + 1] =
+              make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)), 0.f, 0.f);
+        }
         state = ST_FETCH;  // this lane takes another pixel
       }
     }
@@ -818,20 +851,30 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
       if (lane == 0) base = atomicAdd(R.next_pixel, (uint32_t)__popcll(mw));
       base = __builtin_amdgcn_readfirstlane(base);
       if (state == ST_FETCH) {
-        const uint32_t q = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
-        if (q >= R.n_pixels) {
+        const uint32_t qi = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+        if (qi >= R.n_pixels) {
           state = ST_DONE;
         } else {
+          const uint32_t q = R.pixel_order ? R.pixel_order[qi] : qi;
           pixel_xy(q, xr, yr);
           if (xr < W && yr < H) {  // (pixels of a ragged super-tile outside the image are skipped)
             pix = q;
-            P.sum = {0.f, 0.f, 0.f};
             P.L = {0.f, 0.f, 0.f};
             P.beta = {1.f, 1.f, 1.f};
             P.wi_next = {0.f, 0.f, 0.f};
             P.Lpend = {0.f, 0.f, 0.f};
             pcg_seq(P.rng, seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr));
-            P.s = 0;
+            if (R.s_begin == 0u) {
+              P.sum = {0.f, 0.f, 0.f};
+            } else {  // resume the pixel where the first launch parked it
+              const float4 a = R.pixel_state[2 * (size_t)q], b = R.pixel_state[2 * (size_t)q + 1];
+              P.sum = {a.x, a.y, a.z};
+              P.rng.state = (uint64_t)__float_as_uint(b.x) | ((uint64_t)__float_as_uint(b.y) << 32);
+            }
+            const uint64_t now = (uint64_t)clock64();
+            P.t0lo = (uint32_t)now;
+            P.t0hi = (uint32_t)(now >> 32);
+            P.s = R.s_begin;
             P.bounces = 0;
             P.specular = false;
             P.cont = false;

@@ -82,6 +82,8 @@ RENDER_CASES = [
     ("check_sphere", INTEGRATOR_DIRECT, 5, (2, 1), 4),
     ("ties", INTEGRATOR_PATH, 8, (3, 2), 5),  # duplicated / coplanar / degenerate geometry: the tie rule decides
     ("deep", INTEGRATOR_PATH, 6, (2, 2), 6),  # a very deep tree: 64-entry exact stack, HBM overflow of the production stack
+    ("mesh1k", INTEGRATOR_PATH, 8, (8, 8), 7),  # >= 64 spp: the frame is rendered in two launches (pixels parked, cost-ordered)
+    ("check_sphere", INTEGRATOR_PATH, 5, (16, 5), 2),
 ]
 
 
@@ -98,6 +100,27 @@ def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
     assert st2["samples"] == sd.xres * sd.yres * spp[0] * spp[1] and st2["kernel_ms"] > 0
     assert psnr(gpu.film_to_rgb(film), oracle.film_write_rgb(ref)) >= 50.0
+
+
+def test_two_launch_frame_is_scheduling_only(gpu, oracle, monkeypatch):
+    """Frames with >= 64 spp are rendered in two launches with the pixels re-ordered by cost in between
+    (capi.cpp render_device).  The film must not depend on it: ragged image, three ranks, and the one-launch
+    path forced through PBRT_HIP_TWO_PHASE=0, all bit-equal to the oracle."""
+    sd = scenes.cornell_scene(200, 136)
+    ref, rst = oracle.OracleScene(sd).render(max_depth=4, spp=(8, 9), seed=5)
+    with gpu.Scene(sd) as sc:
+        full, st = sc.render(max_depth=4, spp=(8, 9), seed=5, counters=True)
+        acc = np.zeros_like(full)
+        for r in range(3):
+            part, _ = sc.render(max_depth=4, spp=(8, 9), seed=5, rank=r, world_size=3)
+            acc += part
+        monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "0")
+        one, _ = sc.render(max_depth=4, spp=(8, 9), seed=5)
+    assert_bit_equal(full, ref, "two-launch film")
+    assert_bit_equal(acc, ref, "two-launch film, union of 3 ranks")
+    assert_bit_equal(one, ref, "one-launch film")
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+        assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
 
 
 def test_golden_fixture(gpu):

@@ -13,8 +13,9 @@ spp = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2, 2)
 n, res = (1_000_000, 2048) if wl == "c3" else (100_000, 1024)
 sd = scenes.random_mesh_scene(n, res, res)
 with pbrt_amd.Scene(sd) as sc:
-    film, st = sc.render(max_depth=8, spp=spp, seed=0)
-    print(wl, spp, "kernel_ms", st["kernel_ms"], "Msamples/s", st["samples"] / st["kernel_ms"] / 1e3)
+    world = int(os.environ.get("PROBE_WORLD", "1"))  # PROBE_WORLD=8: rank 0's share of an 8-GPU job (strong scaling)
+    film, st = sc.render(max_depth=8, spp=spp, seed=0, world_size=world)
+    print(wl, spp, "world", world, "kernel_ms", st["kernel_ms"], "Msamples/s", st["samples"] / st["kernel_ms"] / 1e3)
     if os.environ.get("PROBE_COUNTERS"):
         _, ex = sc.render(max_depth=8, spp=spp, seed=0, counters=True)
         _, wk = sc.render(max_depth=8, spp=spp, seed=0, counters="walk")
