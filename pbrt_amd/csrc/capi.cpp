@@ -506,7 +506,7 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(s->d_mats.alloc(mats.size()));
     HIP_TRY(s->d_lights.alloc(lights.size()));
     HIP_TRY(s->d_spheres.alloc(spheres.size()));
-    HIP_TRY(s->d_counters.alloc(6));  // [5] is the render kernel's pixel hand-out counter
+    HIP_TRY(s->d_counters.alloc(8));  // [5] is the render kernel's pixel hand-out counter, [6..7] the pixel-order scratch
     HIP_TRY(hipStreamCreate(&s->stream));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
@@ -650,7 +650,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 6 * sizeof(unsigned long long), st));
     // One launch renders samples [s_begin, s_end) of every pixel.  A frame with many samples per pixel is rendered
     // in two launches: the first takes spp/32 samples of every pixel and parks each pixel (film sum, RNG state)
-    // with the cycles it took; the pixels are then ordered by that cost, most expensive first, and the second
+    // with the rays it took; the pixels are then ordered by that cost, most expensive first, and the second
     // launch resumes them in that order -- the cheap pixels go out last and the persistent waves run dry
     // together (a pixel's samples are sequential, ~0.4 s for C3's 512: with 2 pixels per lane, as on 8 GPUs,
     // the unordered tail cost 30 %).  Scheduling only: every pixel still sees its samples in order.
@@ -664,7 +664,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       const size_t n = R.n_pixels;
       if (s->d_pixel_state.n < 2 * n) { s->d_pixel_state.release(); HIP_TRY(s->d_pixel_state.alloc(2 * n)); }
       if (s->d_pixel_sort.n < 4 * n) { s->d_pixel_sort.release(); HIP_TRY(s->d_pixel_sort.alloc(4 * n)); }
-      HIP_TRY(launch_pixel_order(nullptr, R.n_pixels, nullptr, nullptr, nullptr, nullptr, nullptr, &sort_bytes, st));
+      HIP_TRY(launch_pixel_order(nullptr, R.n_pixels, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sort_bytes, st));
       if (s->d_sort_tmp.n < sort_bytes) { s->d_sort_tmp.release(); HIP_TRY(s->d_sort_tmp.alloc(sort_bytes)); }
       R.pixel_state = s->d_pixel_state.p;
       HIP_TRY(hipMemsetAsync(s->d_pixel_state.p, 0, 2 * n * sizeof(float4), st));  // cost 0 = pixel outside the film
@@ -675,7 +675,10 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
     if (s_split) {
       uint32_t *keys = s->d_pixel_sort.p, *keys_out = keys + R.n_pixels, *vals = keys + 2 * (size_t)R.n_pixels, *order = keys + 3 * (size_t)R.n_pixels;
-      HIP_TRY(launch_pixel_order(R.pixel_state, R.n_pixels, keys, keys_out, vals, order, s->d_sort_tmp.p, &sort_bytes, st));
+      // finer cost buckets the fewer pixels a lane renders (pixel_order.hip): 2 at 16 pixels per lane, 16 at 2
+      const uint32_t per_lane = std::max<uint32_t>(1u, R.n_pixels / (R.n_workgroups * 64u));
+      const uint32_t buckets = std::min<uint32_t>(32u, std::max<uint32_t>(1u, tuning("PBRT_HIP_ORDER_BUCKETS", 32u / per_lane, 64)));
+      HIP_TRY(launch_pixel_order(R.pixel_state, R.n_pixels, buckets, s->d_counters.p + 6, keys, keys_out, vals, order, s->d_sort_tmp.p, &sort_bytes, st));
       HIP_TRY(hipMemsetAsync(R.next_pixel, 0, sizeof(uint32_t), st));
       R.pixel_order = order;
       R.s_begin = s_split;

@@ -56,7 +56,7 @@ struct RenderParams {
   uint32_t n_workgroups;  // one-wave workgroups launched: what the device holds at once, not one per tile
   // A frame may be rendered in two launches (capi.cpp render_device): samples [s_begin, s_end) of every pixel.
   uint32_t s_begin, s_end;
-  float4 *pixel_state;        // [n_pixels][2]: {sum.xyz, cycles spent}{rng state lo, hi, -, -} between the launches
+  float4 *pixel_state;        // [n_pixels][2]: {sum.xyz, rays traced}{rng state lo, hi, -, -} between the launches
   const uint32_t *pixel_order;  // the order in which pixels are handed out (null: 0, 1, 2, ...)
 };
 
@@ -79,10 +79,11 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);
-// keys[q] = coarse log2 of the cycles pixel q took in the first launch (0 = not rendered), vals[q] = q; then
-// vals sorted by descending key (stable) into `order`.  `tmp` / `tmp_bytes`: scratch (query with tmp == nullptr).
-hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint32_t *keys, uint32_t *keys_out, uint32_t *vals,
-                              uint32_t *order, void *tmp, size_t *tmp_bytes, hipStream_t stream);
+// Orders the pixels of a two-launch frame for the second launch (pixel_order.hip): keys[q] = work of pixel q in
+// the first launch in units of 1/buckets of the mean (0 = not rendered), vals[q] = q; vals sorted by descending key
+// (stable) into `order`.  `work_sum`: 2 counters of scratch.  `tmp` / `tmp_bytes`: sort scratch (query with tmp == nullptr).
+hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint32_t buckets, unsigned long long *work_sum, uint32_t *keys,
+                              uint32_t *keys_out, uint32_t *vals, uint32_t *order, void *tmp, size_t *tmp_bytes, hipStream_t stream);
 hipError_t launch_assemble(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
                            uint32_t n_local_super, hipStream_t stream);
 

@@ -176,6 +176,7 @@ struct Trav {
   uint32_t any;       // any-hit (shadow) ray
   uint32_t occluded;  // any-hit result
   HitRec h;           // closest-hit result
+  uint32_t work;      // node steps + triangle tests of this walk (production walk: a pixel's cost estimate)
 };
 
 struct TravTuning {
@@ -260,6 +261,7 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
   }
   T.any = any ? 1u : 0u;
   T.occluded = 0;
+  T.work = 0;
   T.h.t = kInf;
   T.h.prim = kNoPrim;
   T.h.slot = kNoPrim;
@@ -366,6 +368,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       }
 #endif
       if (COUNT) cn++;  // one 64-byte fetch
+      T.work++;
       const float tfar = fminf(T.h.t, T.tmax);
       // Node-relative slab test.  A decoded plane is the REAL number origin + q * cell (the builder
       // checks in exact arithmetic that these planes enclose the true box), so
@@ -454,6 +457,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
           const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
           if (COUNT) ct++;
+          T.work++;
           // Moeller-Trumbore, operation order of DESIGN.md 3.5
           const V3 p0 = xyz(a);
           const V3 e1 = xyz(b) - p0, e2 = xyz(c) - p0;
@@ -589,7 +593,7 @@ struct PathState {
   Pcg rng;     // rng.inc is recomputed from the pixel, only the state is stored
   uint32_t s, bounces;
   bool specular, cont;
-  uint32_t t0lo, t0hi;  // clock when the lane took the pixel (two-launch frames: the pixel's cost estimate)
+  uint32_t work;  // node steps + triangle tests + 16 per ray spent on this pixel so far (two-launch frames: its cost estimate)
 };
 __device__ __forceinline__ void path_store(float4 *rec, const PathState &P) {
   rec[0] = make_float4(P.sum.x, P.sum.y, P.sum.z, P.L.x);
@@ -598,7 +602,7 @@ __device__ __forceinline__ void path_store(float4 *rec, const PathState &P) {
   rec[192] = make_float4(P.Lpend.x, P.Lpend.y, P.Lpend.z,
                          __uint_as_float(P.s | (P.bounces << 20) | (P.specular ? 1u << 30 : 0u) | (P.cont ? 1u << 31 : 0u)));
   rec[256] = make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)),
-                         __uint_as_float(P.t0lo), __uint_as_float(P.t0hi));
+                         __uint_as_float(P.work), 0.f);
 }
 __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
   const float4 a = rec[0], b = rec[64], c = rec[128], d = rec[192], e = rec[256];
@@ -613,8 +617,7 @@ __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
   P.specular = (w >> 30) & 1u;
   P.cont = (w >> 31) & 1u;
   P.rng.state = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
-  P.t0lo = __float_as_uint(e.z);
-  P.t0hi = __float_as_uint(e.w);
+  P.work = __float_as_uint(e.z);
 }
 
 // COUNT: accumulate ray / visit counters.  EXACT (needs COUNT): walk the tree in exactly the oracle's
@@ -663,6 +666,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   T.any = 0;
   T.occluded = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
+  T.work = 0;
 
 #ifdef PBRT_PHASE_PROBE
   if (lane < 8) s_probe[lane] = 0;
@@ -682,6 +686,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
       P.rng.inc = ((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) << 1) | 1u;
       if (state != ST_NEW) {
         if (SPH) trav_spheres(S, T);
+        P.work += T.work + 16u;  // + the ray's share of the service stage, in step units
         bool advance = false;  // take the prepared bounce (or end the sample)
         if (state == ST_SHADOW) {
 #ifdef PBRT_DEBUG_PIXEL_X
@@ -831,9 +836,8 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
           R.slab[(size_t)(pix >> 12) * 4096u + (((pix >> 9) & 7u) * 8u + ((pix >> 3) & 7u)) * 64u + ((pix >> 6) & 7u) * 8u + (pix & 7u)] = o;
         } else {
           // first launch of a two-launch frame: park the pixel (the second launch resumes it at sample s_end)
-          // together with the cycles it took, the cost estimate by which the second launch orders the pixels
-          const uint64_t dt = (uint64_t)clock64() - ((uint64_t)P.t0lo | ((uint64_t)P.t0hi << 32));
-          R.pixel_state[2 * (size_t)pix] = make_float4(P.sum.x, P.sum.y, P.sum.z, (float)dt);
+          // together with the traversal work it took, the cost estimate by which the second launch orders the pixels
+          R.pixel_state[2 * (size_t)pix] = make_float4(P.sum.x, P.sum.y, P.sum.z, __uint_as_float(P.work));
           R.pixel_state[2 * (size_t)pix + 1] =
               make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)), 0.f, 0.f);
         }
@@ -871,9 +875,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
               P.sum = {a.x, a.y, a.z};
               P.rng.state = (uint64_t)__float_as_uint(b.x) | ((uint64_t)__float_as_uint(b.y) << 32);
             }
-            const uint64_t now = (uint64_t)clock64();
-            P.t0lo = (uint32_t)now;
-            P.t0hi = (uint32_t)(now >> 32);
+            P.work = 0;
             P.s = R.s_begin;
             P.bounces = 0;
             P.specular = false;
@@ -966,6 +968,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
   T.any = 0;
   T.occluded = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
+  T.work = 0;
   for (;;) {
     if (T.cur == kDone) {
       if (have) {

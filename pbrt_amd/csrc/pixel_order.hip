@@ -10,27 +10,52 @@
 
 namespace pbrt_hip {
 
-static __global__ void pixel_keys_kernel(const float4 *pixel_state, uint32_t n, uint32_t *keys, uint32_t *vals) {
+// sum[0] += work of all pixels, sum[1] += number of pixels rendered (both zeroed by the caller)
+static __global__ void pixel_work_sum_kernel(const float4 *pixel_state, uint32_t n, unsigned long long *sum) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long w = q < n ? __float_as_uint(pixel_state[2 * (size_t)q].w) : 0u;
+  unsigned long long c = w != 0ull ? 1ull : 0ull;
+  for (int off = 32; off > 0; off >>= 1) {
+    w += __shfl_down(w, off, 64);
+    c += __shfl_down(c, off, 64);
+  }
+  if ((threadIdx.x & 63u) == 0u && c != 0ull) {
+    atomicAdd(&sum[0], w);
+    atomicAdd(&sum[1], c);
+  }
+}
+
+static __global__ void pixel_keys_kernel(const float4 *pixel_state, uint32_t n, const unsigned long long *sum, uint32_t buckets,
+                                         uint32_t *keys, uint32_t *vals) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
-  // float exponent + 2 mantissa bits of the cycle count: four buckets per octave.  Coarse on purpose: pixels of
-  // one bucket keep their spatial order (the sort is stable), so a wave's pixels stay close together.
-  const float c = pixel_state[2 * (size_t)q].w;
-  keys[q] = c > 0.f ? (__float_as_uint(c) >> 21) & 0x3ffu : 0u;
+  // key = the pixel's work (node steps + triangle tests + 16 per ray) in units of 1/buckets of the mean
+  // pixel's, at most 255; 0 also for pixels not rendered (outside the film).  The pixels of one bucket keep their
+  // spatial order (the sort is stable).  `buckets` is small when a lane renders many pixels (the frame is then
+  // handed out as neighbouring pixels of mixed cost, which the waves render fastest, and only markedly
+  // expensive pixels move to the front) and large when it renders few (then the order of the tail is what counts).
+  const uint32_t work = __float_as_uint(pixel_state[2 * (size_t)q].w);
+  const unsigned long long mean = sum[1] ? sum[0] / sum[1] : 1ull;
+  const unsigned long long k = ((unsigned long long)buckets * work) / (mean ? mean : 1ull);
+  keys[q] = k > 255ull ? 255u : (uint32_t)k;
   vals[q] = q;
 }
 
-hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint32_t *keys, uint32_t *keys_out, uint32_t *vals,
-                              uint32_t *order, void *tmp, size_t *tmp_bytes, hipStream_t stream) {
+hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint32_t buckets, unsigned long long *work_sum, uint32_t *keys,
+                              uint32_t *keys_out, uint32_t *vals, uint32_t *order, void *tmp, size_t *tmp_bytes, hipStream_t stream) {
   if (tmp == nullptr) {  // size query (the sort of a small list may need no scratch at all: never report 0)
-    hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, *tmp_bytes, keys, keys_out, vals, order, (int)n_pixels, 0, 10, stream);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, *tmp_bytes, keys, keys_out, vals, order, (int)n_pixels, 0, 8, stream);
     if (*tmp_bytes < 256) *tmp_bytes = 256;
     return e;
   }
-  hipLaunchKernelGGL(pixel_keys_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, pixel_state, n_pixels, keys, vals);
-  hipError_t e = hipGetLastError();
+  const dim3 grid((n_pixels + 255u) / 256u), block(256);
+  hipError_t e = hipMemsetAsync(work_sum, 0, 2 * sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
-  return hipcub::DeviceRadixSort::SortPairsDescending(tmp, *tmp_bytes, keys, keys_out, vals, order, (int)n_pixels, 0, 10, stream);
+  hipLaunchKernelGGL(pixel_work_sum_kernel, grid, block, 0, stream, pixel_state, n_pixels, work_sum);
+  hipLaunchKernelGGL(pixel_keys_kernel, grid, block, 0, stream, pixel_state, n_pixels, work_sum, buckets, keys, vals);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return hipcub::DeviceRadixSort::SortPairsDescending(tmp, *tmp_bytes, keys, keys_out, vals, order, (int)n_pixels, 0, 8, stream);
 }
 
 }  // namespace pbrt_hip
