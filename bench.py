@@ -192,12 +192,15 @@ def main():
         rays = cst["camera_rays"] + cst["bounce_rays"] + cst["shadow_rays"]
         roof.update({
             "achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel": "render_kernel", "kernel_ms": avg_kernel_ms,
+            "launches_per_step": 2 if spp[0] * spp[1] >= 64 else 1,
             "bytes_per_sample": bps, "algorithmic_bytes_per_launch": alg_bytes,
             "rays_per_sample": rays / cst["samples"], "nodes_per_ray": cst["nodes_visited"] / rays,
             "tris_per_ray": cst["tris_tested"] / rays, "mrays_per_s": rays / (avg_kernel_ms * 1e-3) / 1e6,
             "frac_of_measured_stream_6290": ach / 6290.0,
             "note": "algorithmic bytes = SURVEY 8d formula on the CANONICAL binary-BVH walk (exact counters, equal to the "
-                    "oracle's) / HIP-event kernel time; it can exceed the HBM peak because the scene "
+                    "oracle's) / HIP-event kernel time of one frame (a frame with >= 64 spp is two launches of "
+                    "render_kernel, the first takes spp/32 samples of every pixel, plus a pixel sort; kernel_ms spans them, "
+                    "and the rocprof summary under profiles/ gives the same per-frame sum); it can exceed the HBM peak because the scene "
                     f"({info['device_bytes'] / 1e6:.0f} MB) sits in the 256 MiB Infinity Cache and the production kernel walks a "
                     "quantised 4-wide form of the tree that moves fewer bytes (see kernel_*)",
         })
@@ -218,7 +221,7 @@ def main():
     if world == 1 and not args.spp and os.path.exists(pmc):
         p = json.load(open(pmc))
         roof["traffic"] = p["traffic_bytes_raw"]
-        roof["traffic_note"] = (f"(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from {os.path.relpath(pmc, ROOT)} "
+        roof["traffic_note"] = (f"(FETCH_SIZE + WRITE_SIZE) x 1024 per frame from {os.path.relpath(pmc, ROOT)} "
                                 f"(round {p.get('round', '?')} kernel, {p['avg_ms']:.0f} ms); FETCH_SIZE counts L2-miss requests "
                                 "incl. Infinity-Cache hits and is uncalibrated for 16-B gathers (x2 if the wide-stream correction applied)")
 

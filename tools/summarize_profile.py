@@ -4,6 +4,10 @@ profiles/: the kernel-stats CSV of the --kernel-trace --stats run and a JSON wit
 counters of the dominant kernel.
 
   python tools/summarize_profile.py <round-tag> <workload> <trace_dir> [<fetch_dir> <write_dir>]
+
+A frame (one bench step) with >= 64 spp is TWO launches of render_kernel (capi.cpp render_device), so the
+figures are per FRAME: total time / counter sum of the kernel's launches divided by the number of frames
+(FRAMES_TRACE = 3 for --steps 2 --warmup 1, FRAMES_PMC = 1 for --steps 1 --warmup 0).
 """
 import csv
 import glob
@@ -33,14 +37,19 @@ def main():
             r["Name"] = r["Name"][:160]
             w.writerow(r)
     k = [r for r in rows if KERNEL in r["Name"]][0]
-    summary = {"workload": workload, "kernel": k["Name"], "calls": int(k["Calls"]), "avg_ms": float(k["AverageNs"]) / 1e6,
-               "min_ms": float(k["MinNs"]) / 1e6, "max_ms": float(k["MaxNs"]) / 1e6,
-               "source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1"}
+    frames_trace = int(os.environ.get("FRAMES_TRACE", "3"))
+    frames_pmc = int(os.environ.get("FRAMES_PMC", "1"))
+    calls = int(k["Calls"])
+    summary = {"workload": workload, "kernel": k["Name"], "calls": calls, "frames": frames_trace,
+               "launches_per_frame": calls / frames_trace, "avg_ms": float(k["TotalDurationNs"]) / 1e6 / frames_trace,
+               "avg_ms_per_launch": float(k["AverageNs"]) / 1e6, "min_ms": float(k["MinNs"]) / 1e6, "max_ms": float(k["MaxNs"]) / 1e6,
+               "share_of_gpu_time_pct": float(k["Percentage"]),
+               "source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1; avg_ms = per frame"}
     if len(sys.argv) >= 6:
         for name, d in (("FETCH_SIZE", sys.argv[4]), ("WRITE_SIZE", sys.argv[5])):
             cr = list(csv.DictReader(open(one(os.path.join(d, "**", "*counter_collection.csv")))))
             vals = [float(r["Counter_Value"]) for r in cr if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
-            summary[name + "_KB_per_launch"] = sum(vals) / len(vals)
+            summary[name + "_KB_per_launch"] = sum(vals) / frames_pmc  # per frame (all launches of the frame)
             kr = [r for r in cr if KERNEL in r["Kernel_Name"]][0]
             summary.update({"vgpr": int(kr["VGPR_Count"]), "sgpr": int(kr["SGPR_Count"]), "lds_bytes": int(kr["LDS_Block_Size"]),
                             "grid": int(kr["Grid_Size"]), "workgroup": int(kr["Workgroup_Size"])})
