@@ -26,7 +26,7 @@
 
 // node steps of the production walk between two scheduling checks (trav_run)
 #ifndef PBRT_STEPS_PER_CHECK
-#define PBRT_STEPS_PER_CHECK 2
+#define PBRT_STEPS_PER_CHECK 3
 #endif
 
 namespace pbrt_hip {
