@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, nargs=2, default=None, help="override strata (diagnostics; invalid as a headline)")
+    ap.add_argument("--builder", default="host", choices=["host", "gpu"],
+                    help="accelerator builder: host binned SAH (headline) or the device LBVH (same film, no canonical counters)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="skip the untimed counting pass (roofline.achieved = null)")
     args = ap.parse_args()
@@ -143,7 +145,9 @@ def main():
         spp = tuple(args.spp)
     t0 = time.time()
     sd = make_scene_data(kind, n, res)
-    scene = pbrt_amd.Scene(sd, device=device_index)
+    scene = pbrt_amd.Scene(sd, device=device_index, builder=args.builder)
+    if args.builder == "gpu":
+        args.no_counters = True  # the canonical counters exist only for the host-built tree
     info = scene.info()
     build_s = time.time() - t0
     kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=0)
@@ -233,7 +237,7 @@ def main():
         "config": {"workload": descr, "triangles": int(sd.idx.shape[0]), "resolution": [res, res], "spp": spp[0] * spp[1],
                    "maxdepth": depth, "sharding": f"64x64 super-tiles round-robin over {world} rank(s), one gather",
                    "bvh_nodes": info["n_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
-                   "scene_build_s": round(build_s, 2)},
+                   "scene_build_s": round(build_s, 2), "accelerator": dict(scene.build_info(), builder=args.builder)},
         "roofline": roof,
     }
     if rank == 0:

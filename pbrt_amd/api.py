@@ -16,6 +16,7 @@ LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
 FLAG_COUNTERS = 1
 FLAG_WALK_COUNTERS = 2
+SCENE_GPU_BUILD = 1  # pbrt_hip_scene_create_ex flag
 
 
 def _fp(a):
@@ -203,14 +204,35 @@ def slab_pixel_index(xres, yres, crop, rank, world_size):
 class Scene:
     """A scene resident in HBM (flattened BVH + leaf-ordered triangles + tables)."""
 
-    def __init__(self, sd, device=-1):
+    def __init__(self, sd, device=-1, builder=None):
+        """builder: None (host SAH builder unless PBRT_HIP_BUILDER=gpu), "host" or "gpu" (accelerator built on the
+        device: same film and hit records, no canonical counters)."""
         self.sd = sd.normalized()
         desc = SceneDesc()
         keep = fill_desc(desc, self.sd, Material, Light, Sphere)
         h = C.c_void_p()
-        check(lib().pbrt_hip_scene_create(C.byref(desc), device, C.byref(h)), "pbrt_hip_scene_create")
+        if builder is None:
+            check(lib().pbrt_hip_scene_create(C.byref(desc), device, C.byref(h)), "pbrt_hip_scene_create")
+        else:
+            flags = {"host": 0, "gpu": SCENE_GPU_BUILD}[builder]
+            check(lib().pbrt_hip_scene_create_ex(C.byref(desc), device, flags, C.byref(h)), "pbrt_hip_scene_create_ex")
         del keep
         self._h = h
+
+    def build_info(self):
+        g, ms = C.c_uint32(), C.c_double()
+        check(lib().pbrt_hip_scene_build_info(self._h, C.byref(g), C.byref(ms)), "pbrt_hip_scene_build_info")
+        return {"gpu_built": bool(g.value), "build_ms": ms.value}
+
+    def export_quads(self):
+        """(quads[n, 16] uint32, order[n_tris] uint32): the production walk's tree as it sits in HBM."""
+        n = C.c_uint32()
+        check(lib().pbrt_hip_scene_export_quads(self._h, None, 0, C.byref(n), None), "pbrt_hip_scene_export_quads")
+        quads = np.zeros((max(n.value, 1), 16), np.uint32)
+        order = np.zeros(max(self.sd.idx.shape[0], 1), np.uint32)
+        check(lib().pbrt_hip_scene_export_quads(self._h, _u32p(quads), quads.shape[0], C.byref(n), _u32p(order)),
+              "pbrt_hip_scene_export_quads")
+        return quads[:n.value], order[:self.sd.idx.shape[0]]
 
     def close(self):
         if getattr(self, "_h", None):

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpbrt_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "pbrt")  # the C++ command line (csrc/pbrt_main.cpp)
-SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip", "pixel_order.hip"]
+SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip", "pixel_order.hip", "bvh_gpu.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <exception>
 #include <limits>
 #include <memory>
@@ -339,6 +340,9 @@ struct pbrt_hip_scene {
   hipStream_t stream = nullptr;  // own stream of pbrt_hip_render()
   bool pending = false;
   bool pending_counters = false;
+  uint32_t n_quads_gpu = 0;
+  bool gpu_built = false;  // accelerator built on the device (no canonical tree: counter flags refused)
+  double build_ms = 0.0;
   uint64_t pending_samples = 0;
   uint64_t device_bytes = 0;
 
@@ -404,6 +408,11 @@ int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *i
 }
 
 int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_scene **out) {
+  const char *b = std::getenv("PBRT_HIP_BUILDER");
+  return pbrt_hip_scene_create_ex(d, device, (b && std::strcmp(b, "gpu") == 0) ? PBRT_HIP_SCENE_GPU_BUILD : 0u, out);
+}
+
+int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t flags, pbrt_hip_scene **out) {
   if (!d || !out) return fail(PBRT_HIP_ERR_INVALID, "scene_create: null argument");
   *out = nullptr;
   try {
@@ -430,13 +439,17 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     s->desc.P = nullptr; s->desc.idx = nullptr; s->desc.mat_id = nullptr;
     s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
 
-    // --- accelerator ---
-    build_bvh(d->P, d->idx, d->n_tris, &s->bvh);
-    if (s->bvh.depth > 64) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: BVH deeper than the 64-entry traversal stack");
+    // --- accelerator: the host's binned-SAH builder, or (PBRT_HIP_SCENE_GPU_BUILD) the device builder further down ---
+    if (flags & ~PBRT_HIP_SCENE_GPU_BUILD) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
+    s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && d->n_tris >= 2;
     PairNodes pairs;
-    {
+    if (!s->gpu_built) {
+      const auto t0 = std::chrono::steady_clock::now();
+      build_bvh(d->P, d->idx, d->n_tris, &s->bvh);
+      if (s->bvh.depth > 64) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: BVH deeper than the 64-entry traversal stack");
       std::string why;
       if (!make_pair_nodes(s->bvh, &pairs, &why)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: " + why);
+      s->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
     // --- light table: explicit lights, then every emissive triangle in index order ---
@@ -496,12 +509,14 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(s->d_mat_id.alloc(nt));
     HIP_TRY(s->d_order.alloc(nt));
     QuadNodes quads;
-    {
+    if (!s->gpu_built) {
+      const auto t0 = std::chrono::steady_clock::now();
       const char *sl = std::getenv("PBRT_HIP_SPLIT_LEAVES");
       make_quad_nodes(s->bvh, d->P, d->idx, !(sl && sl[0] == '0'), &quads);
+      s->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     HIP_TRY(s->d_nodes.alloc(pairs.q.size()));
-    HIP_TRY(s->d_quads.alloc(quads.q.size()));
+    HIP_TRY(s->d_quads.alloc(s->gpu_built ? 4 * (size_t)nt : quads.q.size()));
     HIP_TRY(s->d_tris.alloc(3 * (size_t)nt));
     HIP_TRY(s->d_mats.alloc(mats.size()));
     HIP_TRY(s->d_lights.alloc(lights.size()));
@@ -517,9 +532,17 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     HIP_TRY(up(s->d_P.p, d->P, s->d_P.n * 4));
     HIP_TRY(up(s->d_idx.p, d->idx, s->d_idx.n * 4));
     HIP_TRY(up(s->d_mat_id.p, d->mat_id, s->d_mat_id.n * 2));
-    HIP_TRY(up(s->d_order.p, s->bvh.order.data(), s->d_order.n * 4));
+    GpuBuildInfo gb{};
+    if (s->gpu_built) {
+      HIP_TRY(gpu_build_quads(s->d_P.p, s->d_idx.p, nt, s->d_order.p, s->d_quads.p, nt, &gb, s->stream));
+      if (gb.stack_need + 1u > 4096u) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: device-built tree too deep");
+      quads.stack_need = gb.stack_need;
+      s->build_ms = gb.build_ms;
+    } else {
+      HIP_TRY(up(s->d_order.p, s->bvh.order.data(), s->d_order.n * 4));
+    }
     HIP_TRY(up(s->d_nodes.p, pairs.q.data(), pairs.q.size() * 16));
-    HIP_TRY(up(s->d_quads.p, quads.q.data(), quads.q.size() * 16));
+    if (!s->gpu_built) HIP_TRY(up(s->d_quads.p, quads.q.data(), quads.q.size() * 16));
     HIP_TRY(up(s->d_mats.p, mats.data(), mats.size() * 16));
     HIP_TRY(up(s->d_lights.p, lights.data(), lights.size() * 16));
     HIP_TRY(up(s->d_spheres.p, spheres.data(), spheres.size() * 16));
@@ -540,6 +563,12 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_sce
     D.n_nodes = (uint32_t)s->bvh.nodes.size();
     D.root_ref = pairs.root_ref;
     for (int k = 0; k < 3; k++) { D.root_lo[k] = pairs.root_lo[k]; D.root_hi[k] = pairs.root_hi[k]; }
+    if (s->gpu_built) {  // the walk enters quad 0 through the root box; there is no canonical binary tree
+      D.n_nodes = 2u * nt - 1u;
+      D.root_ref = 0u;
+      for (int k = 0; k < 3; k++) { D.root_lo[k] = gb.root_lo[k]; D.root_hi[k] = gb.root_hi[k]; }
+      s->n_quads_gpu = gb.n_quads;
+    }
     D.n_tris = nt;
     D.n_spheres = d->n_spheres;
     D.n_lights = s->n_lights;
@@ -586,8 +615,28 @@ int pbrt_hip_scene_info(const pbrt_hip_scene *s, uint32_t *n_nodes, uint32_t *de
 
 int pbrt_hip_scene_walk_info(const pbrt_hip_scene *s, uint32_t *quad_nodes, uint32_t *stack_need) {
   if (!s) return fail(PBRT_HIP_ERR_INVALID, "walk_info: null scene");
-  if (quad_nodes) *quad_nodes = (uint32_t)(s->d_quads.n / 4);
+  if (quad_nodes) *quad_nodes = s->gpu_built ? s->n_quads_gpu : (uint32_t)(s->d_quads.n / 4);
   if (stack_need) *stack_need = s->dev.quad_stack_need;
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_scene_build_info(const pbrt_hip_scene *s, uint32_t *gpu_built, double *build_ms) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "build_info: null scene");
+  if (gpu_built) *gpu_built = s->gpu_built ? 1u : 0u;
+  if (build_ms) *build_ms = s->build_ms;
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_scene_export_quads(const pbrt_hip_scene *s, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *order) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "export_quads: null scene");
+  const uint32_t n = s->gpu_built ? s->n_quads_gpu : (uint32_t)(s->d_quads.n / 4);
+  if (n_quads) *n_quads = n;
+  HIP_TRY(hipSetDevice(s->device));
+  if (quads) {
+    if (cap_nodes < n) return fail(PBRT_HIP_ERR_LIMIT, "export_quads: output too small");
+    if (n) HIP_TRY(hipMemcpy(quads, s->d_quads.p, 64 * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  if (order && s->d_order.n) HIP_TRY(hipMemcpy(order, s->d_order.p, 4 * s->d_order.n, hipMemcpyDeviceToHost));
   return PBRT_HIP_OK;
 }
 
@@ -647,6 +696,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);
+    if (counters == 1 && s->gpu_built)
+      return fail(PBRT_HIP_ERR_INVALID, "render: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 6 * sizeof(unsigned long long), st));
     // One launch renders samples [s_begin, s_end) of every pixel.  A frame with many samples per pixel is rendered
     // in two launches: the first takes spp/32 samples of every pixel and parks each pixel (film sum, RNG state)
@@ -787,6 +838,8 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
     if (counters) counters[0] = counters[1] = 0;
     return PBRT_HIP_OK;
   }
+  if (counters && s->gpu_built)
+    return fail(PBRT_HIP_ERR_INVALID, "intersect: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
   HIP_TRY(hipSetDevice(s->device));
   DevBuf<float> d_o, d_d, d_tmax, d_t, d_b1, d_b2;
   DevBuf<uint32_t> d_prim;

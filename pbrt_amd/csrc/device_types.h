@@ -84,6 +84,14 @@ hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t 
 // (stable) into `order`.  `work_sum`: 2 counters of scratch.  `tmp` / `tmp_bytes`: sort scratch (query with tmp == nullptr).
 hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint32_t buckets, unsigned long long *work_sum, uint32_t *keys,
                               uint32_t *keys_out, uint32_t *vals, uint32_t *order, void *tmp, size_t *tmp_bytes, hipStream_t stream);
+// bvh_gpu.hip: the accelerator built on the device.  d_order (n_tris) and d_quads (>= n_tris nodes of 4 uint4) are outputs.
+struct GpuBuildInfo {
+  uint32_t n_quads, stack_need, levels;
+  float root_lo[3], root_hi[3];
+  float build_ms;
+};
+hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_tris, uint32_t *d_order, uint4 *d_quads,
+                           uint32_t quad_capacity, GpuBuildInfo *info, hipStream_t stream);
 hipError_t launch_assemble(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
                            uint32_t n_local_super, hipStream_t stream);
 

@@ -12,7 +12,8 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 spp = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2, 2)
 n, res = (1_000_000, 2048) if wl == "c3" else (100_000, 1024)
 sd = scenes.random_mesh_scene(n, res, res)
-with pbrt_amd.Scene(sd) as sc:
+with pbrt_amd.Scene(sd, builder=os.environ.get("PROBE_BUILDER")) as sc:
+    print("accelerator:", sc.build_info(), sc.info())
     world = int(os.environ.get("PROBE_WORLD", "1"))  # PROBE_WORLD=8: rank 0's share of an 8-GPU job (strong scaling)
     film, st = sc.render(max_depth=8, spp=spp, seed=0, world_size=world)
     print(wl, spp, "world", world, "kernel_ms", st["kernel_ms"], "Msamples/s", st["samples"] / st["kernel_ms"] / 1e3)
