@@ -69,7 +69,10 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
   return x < 0 ? 0u : (x > cap ? (uint32_t)cap : (uint32_t)x);
 }
 constexpr uint32_t kMinWalkers = 32, kMinParked = 12, kRenderWorkgroups = 4096;
-constexpr uint32_t kTwoPhaseMinSpp = 64;  // frames with at least this many samples per pixel are rendered in two launches
+// A frame is rendered in two launches (cost-ordered hand-out, render_device) when a pixel is long (>= this many
+// samples) and a lane renders few of them (< kTwoPhaseMaxPerLane): only then does the order of the tail matter.
+// PBRT_HIP_TWO_PHASE=0 / =1 forces one / two launches (tests, A-B runs).
+constexpr uint32_t kTwoPhaseMinSpp = 128, kTwoPhaseMaxPerLane = 16;
 
 constexpr uint32_t kLeafRef = 0x80000000u;
 
@@ -699,15 +702,19 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     if (counters == 1 && s->gpu_built)
       return fail(PBRT_HIP_ERR_INVALID, "render: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 6 * sizeof(unsigned long long), st));
-    // One launch renders samples [s_begin, s_end) of every pixel.  A frame with many samples per pixel is rendered
+    // One launch renders samples [s_begin, s_end) of every pixel.  A frame of few, long pixels per lane is rendered
     // in two launches: the first takes spp/32 samples of every pixel and parks each pixel (film sum, RNG state)
-    // with the rays it took; the pixels are then ordered by that cost, most expensive first, and the second
-    // launch resumes them in that order -- the cheap pixels go out last and the persistent waves run dry
+    // with the traversal work it took; the pixels are then ordered by that cost, most expensive first, and the
+    // second launch resumes them in that order -- the cheap pixels go out last and the persistent waves run dry
     // together (a pixel's samples are sequential, ~0.4 s for C3's 512: with 2 pixels per lane, as on 8 GPUs,
     // the unordered tail cost 30 %).  Scheduling only: every pixel still sees its samples in order.
     const uint32_t spp = r->spp_x * r->spp_y;
-    const char *tp = std::getenv("PBRT_HIP_TWO_PHASE");  // "0": always one launch (tuning / A-B runs)
-    const uint32_t s_split = (spp >= kTwoPhaseMinSpp && !(tp && tp[0] == '0')) ? std::max<uint32_t>(1u, spp / 32u) : 0u;
+    const uint32_t per_lane = std::max<uint32_t>(1u, R.n_pixels / (R.n_workgroups * 64u));
+    const char *tp = std::getenv("PBRT_HIP_TWO_PHASE");
+    bool two = spp >= kTwoPhaseMinSpp && per_lane < kTwoPhaseMaxPerLane;
+    if (tp && tp[0] == '0') two = false;
+    if (tp && tp[0] == '1' && spp >= 2u) two = true;
+    const uint32_t s_split = two ? std::max<uint32_t>(1u, spp / 32u) : 0u;
     R.pixel_state = nullptr;
     R.pixel_order = nullptr;
     size_t sort_bytes = 0;
@@ -727,7 +734,6 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     if (s_split) {
       uint32_t *keys = s->d_pixel_sort.p, *keys_out = keys + R.n_pixels, *vals = keys + 2 * (size_t)R.n_pixels, *order = keys + 3 * (size_t)R.n_pixels;
       // finer cost buckets the fewer pixels a lane renders (pixel_order.hip): 2 at 16 pixels per lane, 16 at 2
-      const uint32_t per_lane = std::max<uint32_t>(1u, R.n_pixels / (R.n_workgroups * 64u));
       const uint32_t buckets = std::min<uint32_t>(32u, std::max<uint32_t>(1u, tuning("PBRT_HIP_ORDER_BUCKETS", 32u / per_lane, 64)));
       HIP_TRY(launch_pixel_order(R.pixel_state, R.n_pixels, buckets, s->d_counters.p + 6, keys, keys_out, vals, order, s->d_sort_tmp.p, &sort_bytes, st));
       HIP_TRY(hipMemsetAsync(R.next_pixel, 0, sizeof(uint32_t), st));

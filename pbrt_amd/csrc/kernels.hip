@@ -294,7 +294,7 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
 //     lanes keep their state and resume on the next call.
 // `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
 // caller once its walk is over.
-template <bool EXACT, bool COUNT, bool OVF>
+template <bool EXACT, bool COUNT, bool OVF, int STEPS = PBRT_STEPS_PER_CHECK>
 __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf,
                                          const bool alive, const TravTuning tune, unsigned long long &cn,
                                          unsigned long long &ct) {
@@ -347,10 +347,10 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       trav_enter(T, hit_near ? ref_near : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
     }
 
-    // production walk: PBRT_STEPS_PER_CHECK node steps between two scheduling checks (a lane that parks or
+    // production walk: STEPS node steps between two scheduling checks (a lane that parks or
     // finishes in the first one idles through the rest; the checks cost about a fifth of a step)
 #pragma unroll
-    for (int rep = 0; !EXACT && rep < PBRT_STEPS_PER_CHECK; rep++) {
+    for (int rep = 0; !EXACT && rep < STEPS; rep++) {
     { const unsigned long long ma = __ballot(T.cur != kDone && !trav_parked(T)); if (ma) { PROBE_ADD(0, 1); PROBE_ADD(1, __popcll(ma)); } }
     if (T.cur != kDone && !trav_parked(T)) {
       // ---- one step of the production walk: the four children of quantised quad node T.cur (64 bytes) ----
@@ -626,7 +626,7 @@ __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
 // One workgroup = one wavefront = one 8x8 pixel tile; 64 workgroups per 64x64 super-tile.
 // STACK: LDS entries of the exact walk; for the production walk it only says whether the HBM overflow
 // area is compiled in (STACK != 0).
-template <bool SPH, bool COUNT, bool EXACT, int STACK>
+template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK>
 __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) render_kernel(const DevScene S, const RenderParams R) {
   __shared__ uint32_t lds_stack[EXACT ? STACK : kQuadLdsStack][64];
   __shared__ float lds_tn[EXACT ? STACK : 1][64];  // entry distances: exact walk only
@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
       if (launch) trav_begin<EXACT>(S, T, stk, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
-    trav_run<EXACT, COUNT, (!EXACT && STACK != 0)>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
+    trav_run<EXACT, COUNT, (!EXACT && STACK != 0), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
 #ifdef PBRT_PHASE_PROBE
@@ -1039,7 +1039,10 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
   const dim3 grid(R.n_workgroups), block(64);
   // the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
   if (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
+    // node steps per scheduling check: 3 for deep trees (C3 +1 %, C2 +2 % over 2), 2 for shallow ones whose walks
+    // are a few steps long (C4: 3 would cost 5 %)
     if (S.quad_stack_need + 2u > kQuadLdsStack) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
+    else if (!COUNT && S.quad_stack_need <= 16u) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0, 2>), grid, block, 0, st, S, R);
     else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, 0, st, S, R);
     return hipGetLastError();
   }

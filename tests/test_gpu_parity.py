@@ -82,7 +82,7 @@ RENDER_CASES = [
     ("check_sphere", INTEGRATOR_DIRECT, 5, (2, 1), 4),
     ("ties", INTEGRATOR_PATH, 8, (3, 2), 5),  # duplicated / coplanar / degenerate geometry: the tie rule decides
     ("deep", INTEGRATOR_PATH, 6, (2, 2), 6),  # a very deep tree: 64-entry exact stack, HBM overflow of the production stack
-    ("mesh1k", INTEGRATOR_PATH, 8, (8, 8), 7),  # >= 64 spp: the frame is rendered in two launches (pixels parked, cost-ordered)
+    ("mesh1k", INTEGRATOR_PATH, 8, (8, 8), 7),  # (sample 35 of pixel (13, 0) draws u32 > 2^32 - 2^9: the 1 - 2^-23 clamp of rng.rs:19)
     ("check_sphere", INTEGRATOR_PATH, 5, (16, 5), 2),
 ]
 
@@ -103,11 +103,12 @@ def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
 
 
 def test_two_launch_frame_is_scheduling_only(gpu, oracle, monkeypatch):
-    """Frames with >= 64 spp are rendered in two launches with the pixels re-ordered by cost in between
-    (capi.cpp render_device).  The film must not depend on it: ragged image, three ranks, and the one-launch
-    path forced through PBRT_HIP_TWO_PHASE=0, all bit-equal to the oracle."""
+    """Frames of few long pixels per lane are rendered in two launches with the pixels re-ordered by cost in
+    between (capi.cpp render_device; forced here with PBRT_HIP_TWO_PHASE=1).  The film must not depend on it: ragged
+    image, three ranks, and the one-launch path forced through PBRT_HIP_TWO_PHASE=0, all bit-equal to the oracle."""
     sd = scenes.cornell_scene(200, 136)
     ref, rst = oracle.OracleScene(sd).render(max_depth=4, spp=(8, 9), seed=5)
+    monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "1")
     with gpu.Scene(sd) as sc:
         full, st = sc.render(max_depth=4, spp=(8, 9), seed=5, counters=True)
         acc = np.zeros_like(full)
