@@ -37,13 +37,17 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     extra_flags = list(extra_flags) + os.environ.get("PBRT_HIP_EXTRA_FLAGS", "").split()
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
               "-Wno-unused-function", f"--offload-arch={ARCH}"] + extra_flags
-    for src in SOURCES:
+    def compile_one(src):
         obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
         cmd = [HIPCC] + common + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:  # the translation units are independent
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
