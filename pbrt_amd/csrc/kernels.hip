@@ -20,7 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "device_types.h"
 
@@ -581,6 +583,10 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FET
 #define PBRT_RENDER_WAVES_PER_SIMD 4
 #endif
 
+#ifdef PBRT_RAY_LOG
+__device__ float4 *g_raylog = nullptr;
+__device__ unsigned long long g_raylog_n = 0, g_raylog_cap = 0;
+#endif
 // Path state of one pixel while its lane is busy walking the BVH: five 16-byte records per lane in
 // HBM, laid out [record][lane] per wave so that a wave's access is one coalesced 1 KB transaction.
 // It is loaded and stored only in the service stage (once per ray, against ~76 gather steps), which
@@ -911,6 +917,15 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
         }
       }
       path_store(rec, P);
+#ifdef PBRT_RAY_LOG  // experiment: every ray the frame traces, in the order it is launched (tools/raylog_probe.py)
+      if (launch && g_raylog) {
+        const unsigned long long k = atomicAdd(&g_raylog_n, 1ull);
+        if (k < g_raylog_cap) {
+          g_raylog[2 * k] = make_float4(ro.x, ro.y, ro.z, rtmax);
+          g_raylog[2 * k + 1] = make_float4(rd.x, rd.y, rd.z, launch_any ? 1.f : 0.f);
+        }
+      }
+#endif
       if (launch) trav_begin<EXACT>(S, T, stk, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
@@ -1059,6 +1074,28 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
                          int counters, hipStream_t stream) {
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
+#ifdef PBRT_RAY_LOG
+  if (counters == 0) {
+    const unsigned long long cap = 160ull << 20, zero = 0;
+    float4 *buf = nullptr;
+    if (hipMalloc((void **)&buf, cap * 32) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raylog), &buf, sizeof(buf));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raylog_cap), &cap, sizeof(cap));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raylog_n), &zero, sizeof(zero));
+    hipError_t e = sph ? launch_render_t<true, false, false>(S, R, n_local_super, bvh_depth, stream)
+                       : launch_render_t<false, false, false>(S, R, n_local_super, bvh_depth, stream);
+    (void)hipStreamSynchronize(stream);
+    unsigned long long n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_raylog_n), sizeof(n));
+    if (n > cap) n = cap;
+    std::vector<float4> host(2 * n);
+    (void)hipMemcpy(host.data(), buf, n * 32, hipMemcpyDeviceToHost);
+    if (FILE *f = std::fopen("/tmp/raylog.bin", "wb")) { std::fwrite(host.data(), 32, n, f); std::fclose(f); }
+    std::fprintf(stderr, "raylog: %llu rays -> /tmp/raylog.bin\n", n);
+    (void)hipFree(buf);
+    return e;
+  }
+#endif
 #ifdef PBRT_PHASE_PROBE
   if (counters == 0) {
     hipError_t e = sph ? launch_render_t<true, false, false>(S, R, n_local_super, bvh_depth, stream)
