@@ -124,6 +124,27 @@ def test_two_launch_frame_is_scheduling_only(gpu, oracle, monkeypatch):
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
 
 
+@pytest.mark.parametrize("name,integrator,depth,spp,seed", [
+    ("check_sphere", INTEGRATOR_PATH, 5, (4, 8), 9),   # spheres + mirror + distant / infinite lights
+    ("sphere", INTEGRATOR_DIRECT, 5, (8, 4), 0),        # direct lighting
+    ("deep", INTEGRATOR_PATH, 6, (8, 4), 6),            # HBM-overflow variant of the walk
+    ("ties", INTEGRATOR_PATH, 8, (6, 6), 5),            # duplicated / coplanar / degenerate geometry
+])
+def test_two_launch_frames_on_other_kernel_variants(gpu, oracle, monkeypatch, name, integrator, depth, spp, seed):
+    """The forced two-launch path (pixels parked after spp/32 samples, cost-ordered, resumed) on the other
+    instantiations of the render kernel: film and canonical counters equal the oracle's."""
+    sd = SMALL_SCENES[name]()
+    ref, rst = oracle.OracleScene(sd).render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
+    monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "1")
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed, counters=True)
+        film2, _ = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
+    assert_bit_equal(film, ref, f"{name} film (two launches, exact walk)")
+    assert_bit_equal(film2, ref, f"{name} film (two launches)")
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+        assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
+
+
 def test_golden_fixture(gpu):
     """tests/golden/render_golden.npz: films the oracle produced when the fixtures were made
     (tests/golden/make_golden.py); the HIP path must reproduce them bit for bit."""
