@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <vector>
+
 #include <hipcub/hipcub.hpp>
 
 #include "device_types.h"
@@ -33,27 +36,57 @@ __device__ __forceinline__ void tri_box(const float *P, const uint32_t *idx, uin
   }
 }
 
+// A node's box as three 64-bit words {lo.x lo.y}{lo.z hi.x}{hi.y hi.z}: the bottom-up fit reads a sibling's box with
+// three device-scope atomic loads (a box another CU has just written must not come from this CU's L1).
+__device__ __forceinline__ unsigned long long pack2(float a, float b) {
+  return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+}
+__device__ __forceinline__ void box_store(unsigned long long *bx, uint32_t id, const float lo[3], const float hi[3]) {
+  bx[3 * (size_t)id] = pack2(lo[0], lo[1]);
+  bx[3 * (size_t)id + 1] = pack2(lo[2], hi[0]);
+  bx[3 * (size_t)id + 2] = pack2(hi[1], hi[2]);
+}
+template <bool COHERENT>
+__device__ __forceinline__ void box_load(const unsigned long long *bx, uint32_t id, float lo[3], float hi[3]) {
+  unsigned long long w[3];
+  for (int k = 0; k < 3; k++)
+    w[k] = COHERENT ? __hip_atomic_load(&bx[3 * (size_t)id + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bx[3 * (size_t)id + k];
+  lo[0] = __uint_as_float((uint32_t)w[0]); lo[1] = __uint_as_float((uint32_t)(w[0] >> 32));
+  lo[2] = __uint_as_float((uint32_t)w[1]); hi[0] = __uint_as_float((uint32_t)(w[1] >> 32));
+  hi[1] = __uint_as_float((uint32_t)w[2]); hi[2] = __uint_as_float((uint32_t)(w[2] >> 32));
+}
+
 // bounds[0..2] = min, bounds[3..5] = max of the triangle-box centres, as order-preserving integers
 __global__ void centroid_bounds_kernel(const float *P, const uint32_t *idx, uint32_t n, uint32_t *bounds) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  float c[3] = {0.f, 0.f, 0.f};
-  const bool live = t < n;
-  if (live) {
+  __shared__ uint32_t red[6];
+  if (threadIdx.x < 6) red[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+  __syncthreads();
+  // a few triangles per thread, then wave, then block: 6 global atomics per 2048 triangles
+  float c[3];
+  uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+  for (uint32_t t = blockIdx.x * blockDim.x * 8u + threadIdx.x, k = 0; k < 8u; k++, t += blockDim.x) {
+    if (t >= n) break;
     float lo[3], hi[3];
     tri_box(P, idx, t, lo, hi);
-    for (int a = 0; a < 3; a++) c[a] = 0.5f * lo[a] + 0.5f * hi[a];
+    for (int a = 0; a < 3; a++) {
+      c[a] = 0.5f * lo[a] + 0.5f * hi[a];
+      mn[a] = min(mn[a], f2ord(c[a]));
+      mx[a] = max(mx[a], f2ord(c[a]));
+    }
   }
   for (int a = 0; a < 3; a++) {
-    uint32_t mn = live ? f2ord(c[a]) : 0xffffffffu, mx = live ? f2ord(c[a]) : 0u;
     for (int off = 32; off > 0; off >>= 1) {
-      mn = min(mn, (uint32_t)__shfl_down(mn, off, 64));
-      mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
+      mn[a] = min(mn[a], (uint32_t)__shfl_down(mn[a], off, 64));
+      mx[a] = max(mx[a], (uint32_t)__shfl_down(mx[a], off, 64));
     }
     if ((threadIdx.x & 63u) == 0u) {
-      atomicMin(&bounds[a], mn);
-      atomicMax(&bounds[3 + a], mx);
+      atomicMin(&red[a], mn[a]);
+      atomicMax(&red[3 + a], mx[a]);
     }
   }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], red[threadIdx.x]);
+  else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], red[threadIdx.x]);
 }
 
 __device__ __forceinline__ uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
@@ -122,25 +155,28 @@ __global__ void radix_tree_kernel(const uint32_t *keys, int n, uint32_t *child, 
 
 // Boxes bottom-up: node ids are internal 0..n-2, leaf k -> (n-1) + k.  The second thread to reach a node fits it.
 __global__ void fit_kernel(const float *P, const uint32_t *idx, const uint32_t *vals, int n, const uint32_t *child,
-                           const uint32_t *parent_internal, const uint32_t *parent_leaf, uint32_t *visits, float4 *blo, float4 *bhi) {
+                           const uint32_t *parent_internal, const uint32_t *parent_leaf, uint32_t *visits, unsigned long long *bx) {
   const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (k >= n) return;
   float lo[3], hi[3];
   tri_box(P, idx, vals[k], lo, hi);
-  blo[n - 1 + k] = make_float4(lo[0], lo[1], lo[2], 0.f);
-  bhi[n - 1 + k] = make_float4(hi[0], hi[1], hi[2], 0.f);
-  uint32_t node = parent_leaf[k];
+  box_store(bx, (uint32_t)(n - 1 + k), lo, hi);
+  uint32_t node = parent_leaf[k], from = (uint32_t)(n - 1 + k);
   while (node != kNone) {
     __threadfence();
     if (atomicAdd(&visits[node], 1u) == 0u) return;  // the sibling subtree is not done yet
     __threadfence();
+    // this thread carries the box of the child it came from; the other child's was written by another thread
     const uint32_t c0 = child[2 * node], c1 = child[2 * node + 1];
     const uint32_t i0 = (c0 & kLeafRef) ? (uint32_t)(n - 1) + (c0 & ~kLeafRef) : c0, i1 = (c1 & kLeafRef) ? (uint32_t)(n - 1) + (c1 & ~kLeafRef) : c1;
-    const volatile float4 *vlo = blo, *vhi = bhi;
-    const float4 a0 = make_float4(vlo[i0].x, vlo[i0].y, vlo[i0].z, 0.f), a1 = make_float4(vlo[i1].x, vlo[i1].y, vlo[i1].z, 0.f);
-    const float4 b0 = make_float4(vhi[i0].x, vhi[i0].y, vhi[i0].z, 0.f), b1 = make_float4(vhi[i1].x, vhi[i1].y, vhi[i1].z, 0.f);
-    blo[node] = make_float4(fminf(a0.x, a1.x), fminf(a0.y, a1.y), fminf(a0.z, a1.z), 0.f);
-    bhi[node] = make_float4(fmaxf(b0.x, b1.x), fmaxf(b0.y, b1.y), fmaxf(b0.z, b1.z), 0.f);
+    float slo[3], shi[3];
+    box_load<true>(bx, i0 == from ? i1 : i0, slo, shi);
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], slo[a]);
+      hi[a] = fmaxf(hi[a], shi[a]);
+    }
+    box_store(bx, node, lo, hi);
+    from = node;
     node = parent_internal[node];
   }
 }
@@ -153,11 +189,11 @@ struct CollapseItem {
 // interior child with the largest surface area while the result fits four slots (the rule of capi.cpp
 // make_quad_nodes; leaves hold one triangle here, so only interior children open).  Child boxes are quantised to
 // the node's own 8-bit grid exactly as the host builder does it, enclosure checked in double arithmetic.
-// counters: [0] quads allocated, [1] items of the next level, [2] stack need (max)
-__global__ void collapse_kernel(const CollapseItem *items, uint32_t n_items, int n, const uint32_t *child, const float4 *blo,
-                                const float4 *bhi, uint4 *quads, CollapseItem *next, uint32_t *counters) {
+// counters: [0] quads allocated, [1] stack need (max); level_count[0] = items of this level, level_count[1] of the next
+__global__ void collapse_kernel(const CollapseItem *items, uint32_t *level_count, int n, const uint32_t *child, const unsigned long long *bx,
+                                uint4 *quads, CollapseItem *next, uint32_t *counters) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_items) return;
+  if (w >= level_count[0]) return;
   const CollapseItem it = items[w];
   struct Kid {
     float lo[3], hi[3];
@@ -166,9 +202,7 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t n_items, int
   int nk = 0;
   auto add = [&](uint32_t c) {
     const uint32_t id = (c & kLeafRef) ? (uint32_t)(n - 1) + (c & ~kLeafRef) : c;
-    const float4 l = blo[id], h = bhi[id];
-    kids[nk].lo[0] = l.x; kids[nk].lo[1] = l.y; kids[nk].lo[2] = l.z;
-    kids[nk].hi[0] = h.x; kids[nk].hi[1] = h.y; kids[nk].hi[2] = h.z;
+    box_load<false>(bx, id, kids[nk].lo, kids[nk].hi);
     kids[nk].c = c;
     nk++;
   };
@@ -190,9 +224,9 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t n_items, int
     add(child[2 * c + 1]);
   }
   const uint32_t path = it.path + (uint32_t)(nk - 1);
-  atomicMax(&counters[2], path);
-  const float4 mlo = blo[it.node], mhi = bhi[it.node];
-  const float me_lo[3] = {mlo.x, mlo.y, mlo.z}, me_hi[3] = {mhi.x, mhi.y, mhi.z};
+  atomicMax(&counters[1], path);
+  float me_lo[3], me_hi[3];
+  box_load<false>(bx, it.node, me_lo, me_hi);
   uint32_t ebyte[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
   for (int a = 0; a < 3; a++) {
     const float origin = me_lo[a], extent = me_hi[a] - me_lo[a];
@@ -231,7 +265,7 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t n_items, int
       ref[k] = kLeafRef | (1u << 24) | (c & ~kLeafRef);  // one triangle, leaf slot = sorted position
     } else {
       ref[k] = atomicAdd(&counters[0], 1u);
-      next[atomicAdd(&counters[1], 1u)] = CollapseItem{c, ref[k], path};
+      next[atomicAdd(&level_count[1], 1u)] = CollapseItem{c, ref[k], path};
     }
   }
   uint4 *q = quads + 4 * (size_t)it.quad;
@@ -258,7 +292,7 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   if (n < 2) return hipErrorInvalidValue;  // (the caller builds trees of fewer than two triangles on the host)
   if (quad_capacity + 1u < n_tris) return hipErrorInvalidValue;  // a quad per interior node of the binary tree at most
   const dim3 block(256), grid_t((n_tris + 255u) / 256u);
-  Tmp bounds, keys, keys_out, vals, sort_tmp, child, par_i, par_l, visits, blo, bhi, q0, q1, counters;
+  Tmp bounds, keys, keys_out, vals, sort_tmp, child, par_i, par_l, visits, bx, q0, q1, counters, level_counts;
   GB_TRY(bounds.alloc(6 * 4));
   GB_TRY(keys.alloc(4 * (size_t)n));
   GB_TRY(keys_out.alloc(4 * (size_t)n));
@@ -267,11 +301,11 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   GB_TRY(par_i.alloc(4 * (size_t)n));
   GB_TRY(par_l.alloc(4 * (size_t)n));
   GB_TRY(visits.alloc(4 * (size_t)n));
-  GB_TRY(blo.alloc(16 * (size_t)(2 * n)));
-  GB_TRY(bhi.alloc(16 * (size_t)(2 * n)));
+  GB_TRY(bx.alloc(24 * (size_t)(2 * n)));
   GB_TRY(q0.alloc(sizeof(CollapseItem) * (size_t)n));
   GB_TRY(q1.alloc(sizeof(CollapseItem) * (size_t)n));
-  GB_TRY(counters.alloc(3 * 4));
+  GB_TRY(counters.alloc(2 * 4));
+  GB_TRY(level_counts.alloc(64 * 4));
   size_t sort_bytes = 0;
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
   GB_TRY(sort_tmp.alloc(sort_bytes));
@@ -282,38 +316,50 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   GB_TRY(hipEventRecord(e0, stream));
   const uint32_t init_bounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   GB_TRY(hipMemcpyAsync(bounds.p, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
-  hipLaunchKernelGGL(centroid_bounds_kernel, grid_t, block, 0, stream, d_P, d_idx, n_tris, bounds.as<uint32_t>());
+  hipLaunchKernelGGL(centroid_bounds_kernel, dim3((n_tris + 2047u) / 2048u), block, 0, stream, d_P, d_idx, n_tris, bounds.as<uint32_t>());
   hipLaunchKernelGGL(morton_kernel, grid_t, block, 0, stream, d_P, d_idx, n_tris, bounds.as<uint32_t>(), keys.as<uint32_t>(), vals.as<uint32_t>());
   GB_TRY(hipGetLastError());
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
   GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
   hipLaunchKernelGGL(radix_tree_kernel, grid_t, block, 0, stream, keys_out.as<uint32_t>(), n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>());
   hipLaunchKernelGGL(fit_kernel, grid_t, block, 0, stream, d_P, d_idx, d_order, n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>(),
-                     visits.as<uint32_t>(), blo.as<float4>(), bhi.as<float4>());
+                     visits.as<uint32_t>(), bx.as<unsigned long long>());
   GB_TRY(hipGetLastError());
 
-  // top-down collapse, one launch per level of the quad tree
+  // top-down collapse, one launch per level of the quad tree.  The host does not know how many items a level holds
+  // (the kernel reads the count the level above left on the device) nor how deep the tree is: it launches kBatch
+  // levels blind -- level L holds at most min(4^L, n) items -- and looks at the device once per batch.
+  constexpr uint32_t kBatch = 48;
   const CollapseItem root{0u, 0u, 0u};
   GB_TRY(hipMemcpyAsync(q0.p, &root, sizeof(root), hipMemcpyHostToDevice, stream));
-  uint32_t h_counters[3] = {1u, 0u, 0u};  // quad 0 is the root's
+  uint32_t h_counters[2] = {1u, 0u};  // quad 0 is the root's
   GB_TRY(hipMemcpyAsync(counters.p, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream));
-  uint32_t n_items = 1, levels = 0;
+  uint32_t levels = 0;
   CollapseItem *cur = q0.as<CollapseItem>(), *nxt = q1.as<CollapseItem>();
-  while (n_items) {
-    hipLaunchKernelGGL(collapse_kernel, dim3((n_items + 127u) / 128u), dim3(128), 0, stream, cur, n_items, n, child.as<uint32_t>(), blo.as<float4>(),
-                       bhi.as<float4>(), d_quads, nxt, counters.as<uint32_t>());
+  for (uint32_t first = 1;;) {  // `first`: items of the batch's first level
+    std::vector<uint32_t> zeros(kBatch + 1, 0u);
+    zeros[0] = first;
+    GB_TRY(hipMemcpyAsync(level_counts.p, zeros.data(), 4 * zeros.size(), hipMemcpyHostToDevice, stream));
+    GB_TRY(hipStreamSynchronize(stream));  // (zeros is a local)
+    uint64_t bound = first;
+    for (uint32_t l = 0; l < kBatch; l++) {
+      const uint32_t cap = (uint32_t)std::min<uint64_t>(bound, (uint64_t)n);
+      hipLaunchKernelGGL(collapse_kernel, dim3((cap + 127u) / 128u), dim3(128), 0, stream, cur, level_counts.as<uint32_t>() + l, n,
+                         child.as<uint32_t>(), bx.as<unsigned long long>(), d_quads, nxt, counters.as<uint32_t>());
+      CollapseItem *t = cur; cur = nxt; nxt = t;
+      bound = std::min<uint64_t>(bound * 4u, (uint64_t)n);
+    }
     GB_TRY(hipGetLastError());
-    GB_TRY(hipMemcpyAsync(h_counters, counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+    std::vector<uint32_t> got(kBatch + 1);
+    GB_TRY(hipMemcpyAsync(got.data(), level_counts.p, 4 * got.size(), hipMemcpyDeviceToHost, stream));
     GB_TRY(hipStreamSynchronize(stream));
-    n_items = h_counters[1];
-    const uint32_t zero = 0;
-    GB_TRY(hipMemcpyAsync(counters.as<uint32_t>() + 1, &zero, 4, hipMemcpyHostToDevice, stream));
-    CollapseItem *t = cur; cur = nxt; nxt = t;
-    levels++;
+    for (uint32_t l = 0; l < kBatch && got[l]; l++) levels++;
+    first = got[kBatch];
+    if (!first) break;
   }
-  float4 rl, rh;
-  GB_TRY(hipMemcpyAsync(&rl, blo.p, 16, hipMemcpyDeviceToHost, stream));
-  GB_TRY(hipMemcpyAsync(&rh, bhi.p, 16, hipMemcpyDeviceToHost, stream));
+  GB_TRY(hipMemcpyAsync(h_counters, counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
+  float root_box[6];  // {lo.x lo.y lo.z hi.x hi.y hi.z} of node 0
+  GB_TRY(hipMemcpyAsync(root_box, bx.p, 24, hipMemcpyDeviceToHost, stream));
   GB_TRY(hipEventRecord(e1, stream));
   GB_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
@@ -321,10 +367,9 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   info->n_quads = h_counters[0];
-  info->stack_need = h_counters[2];
+  info->stack_need = h_counters[1];
   info->levels = levels;
-  info->root_lo[0] = rl.x; info->root_lo[1] = rl.y; info->root_lo[2] = rl.z;
-  info->root_hi[0] = rh.x; info->root_hi[1] = rh.y; info->root_hi[2] = rh.z;
+  for (int a = 0; a < 3; a++) { info->root_lo[a] = root_box[a]; info->root_hi[a] = root_box[3 + a]; }
   info->build_ms = ms;
   return hipSuccess;
 }
