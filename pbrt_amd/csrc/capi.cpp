@@ -524,7 +524,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     HIP_TRY(s->d_mats.alloc(mats.size()));
     HIP_TRY(s->d_lights.alloc(lights.size()));
     HIP_TRY(s->d_spheres.alloc(spheres.size()));
-    HIP_TRY(s->d_counters.alloc(8));  // [5] is the render kernel's pixel hand-out counter, [6..7] the pixel-order scratch
+    HIP_TRY(s->d_counters.alloc(80));  // [0..4] ray / visit counters, [6..7] pixel-order scratch, [8..71] the pixel hand-out counters
     HIP_TRY(hipStreamCreate(&s->stream));
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
@@ -682,7 +682,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     // (256 CUs x 16: the LDS stack allows 4 per SIMD), each lane drawing pixel after pixel from the rank's list.
     R.n_pixels = sh.n_local * 4096u;
     R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", kRenderWorkgroups, 1 << 20)));
-    R.next_pixel = reinterpret_cast<uint32_t *>(s->d_counters.p + 5);
+    R.next_pixel = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
+    R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
     {
       const size_t need = (size_t)R.n_workgroups * 320;  // float4 records: 64 workgroups per super-tile x 5 x 64
       if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
@@ -701,7 +702,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);
     if (counters == 1 && s->gpu_built)
       return fail(PBRT_HIP_ERR_INVALID, "render: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
-    HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 6 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 80 * sizeof(unsigned long long), st));
     // One launch renders samples [s_begin, s_end) of every pixel.  A frame of few, long pixels per lane is rendered
     // in two launches: the first takes spp/32 samples of every pixel and parks each pixel (film sum, RNG state)
     // with the traversal work it took; the pixels are then ordered by that cost, most expensive first, and the
@@ -736,8 +737,9 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       // finer cost buckets the fewer pixels a lane renders (pixel_order.hip): 2 at 16 pixels per lane, 16 at 2
       const uint32_t buckets = std::min<uint32_t>(32u, std::max<uint32_t>(1u, tuning("PBRT_HIP_ORDER_BUCKETS", 32u / per_lane, 64)));
       HIP_TRY(launch_pixel_order(R.pixel_state, R.n_pixels, buckets, s->d_counters.p + 6, keys, keys_out, vals, order, s->d_sort_tmp.p, &sort_bytes, st));
-      HIP_TRY(hipMemsetAsync(R.next_pixel, 0, sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(R.next_pixel, 0, 64 * sizeof(unsigned long long), st));
       R.pixel_order = order;
+      R.n_regions = 1;  // the cost-ordered list is handed out front to back
       R.s_begin = s_split;
       R.s_end = spp;
       HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));

@@ -51,7 +51,8 @@ struct RenderParams {
   float4 *lane_state;                // 5 x 64 float4 per workgroup: path state parked in HBM (kernels.hip PathState)
   uint32_t *stack_overflow;          // [workgroup][entry][lane]: stack entries beyond the LDS part
   uint32_t stack_overflow_entries;
-  uint32_t *next_pixel;   // hand-out counter of the render kernel's pixel list (zeroed before the launch)
+  uint32_t *next_pixel;   // hand-out counters of the render kernel's pixel list, one per region, 16 words apart (zeroed before the launch)
+  uint32_t n_regions;     // contiguous parts of the list, one per XCD (kernels.hip fetch step); 1: a single ordered list
   uint32_t n_pixels;      // n_local_super * 4096
   uint32_t n_workgroups;  // one-wave workgroups launched: what the device holds at once, not one per tile
   // A frame may be rendered in two launches (capi.cpp render_device): samples [s_begin, s_end) of every pixel.

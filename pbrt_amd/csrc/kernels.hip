@@ -662,6 +662,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
 
   float4 *rec = R.lane_state + (size_t)blockIdx.x * 320u + lane;
   uint32_t state = ST_FETCH;
+  uint32_t region = blockIdx.x % R.n_regions;  // the part of the pixel list this wave draws from
   unsigned long long c_cam = 0, c_bounce = 0, c_shadow = 0, c_nodes = 0, c_tris = 0;
   Trav T;
   T.o = mk(0.f, 0.f, 0.f);
@@ -857,13 +858,25 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
     for (;;) {
       const unsigned long long mw = __ballot(state == ST_FETCH);
       if (mw == 0ull) break;
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(R.next_pixel, (uint32_t)__popcll(mw));
-      base = __builtin_amdgcn_readfirstlane(base);
+      // XCD-aware hand-out: workgroup w runs on XCD w mod 8 (each XCD has its own 4 MiB L2), so the list is cut into
+      // n_regions contiguous parts and a wave draws from the part of its XCD -- the waves that share an L2 render
+      // one part of the image -- and helps the next part when its own is exhausted.  (n_regions = 1: the second
+      // launch of a two-launch frame, whose list is ordered by cost.)
+      uint32_t base = 0, lim = R.n_pixels;
+      for (uint32_t tries = 0; tries < R.n_regions; tries++) {
+        const uint32_t lo = (uint32_t)(((uint64_t)R.n_pixels * region) / R.n_regions);
+        const uint32_t hi = (uint32_t)(((uint64_t)R.n_pixels * (region + 1u)) / R.n_regions);
+        if (lane == 0) base = atomicAdd(R.next_pixel + 16u * region, (uint32_t)__popcll(mw));
+        base = __builtin_amdgcn_readfirstlane(base) + lo;
+        lim = hi;
+        if (base < hi) break;
+        region = region + 1u < R.n_regions ? region + 1u : 0u;  // own part exhausted: help the next one
+        base = lim;
+      }
       if (state == ST_FETCH) {
         const uint32_t qi = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
-        if (qi >= R.n_pixels) {
-          state = ST_DONE;
+        if (qi >= lim) {
+          if (base >= lim) state = ST_DONE;  // every part exhausted (else: this lane draws again in the next round)
         } else {
           const uint32_t q = R.pixel_order ? R.pixel_order[qi] : qi;
           pixel_xy(q, xr, yr);
