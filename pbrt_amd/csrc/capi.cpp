@@ -68,7 +68,7 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
   long x = std::strtol(v, nullptr, 10);
   return x < 0 ? 0u : (x > cap ? (uint32_t)cap : (uint32_t)x);
 }
-constexpr uint32_t kMinWalkers = 32, kMinParked = 12, kRenderWorkgroups = 4096;
+constexpr uint32_t kMinWalkers = 36, kMinParked = 12, kRenderWorkgroups = 4096;
 // A frame is rendered in two launches (cost-ordered hand-out, render_device) when a pixel is long (>= this many
 // samples) and a lane renders few of them (< kTwoPhaseMaxPerLane): only then does the order of the tail matter.
 // PBRT_HIP_TWO_PHASE=0 / =1 forces one / two launches (tests, A-B runs).
