@@ -68,7 +68,9 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
   long x = std::strtol(v, nullptr, 10);
   return x < 0 ? 0u : (x > cap ? (uint32_t)cap : (uint32_t)x);
 }
-constexpr uint32_t kMinWalkers = 36, kMinParked = 12, kRenderWorkgroups = 4096;
+// min_walkers: 36 for deep trees (long walks: C3 +1 % over 32), 20 for shallow ones, where a frame is mostly shading and
+// the shading stage should wait for more lanes (C4 +12 % over 36)
+constexpr uint32_t kMinWalkers = 36, kMinWalkersShallow = 20, kShallowStackNeed = 16, kMinParked = 12, kRenderWorkgroups = 4096;
 // A frame is rendered in two launches (cost-ordered hand-out, render_device) when a pixel is long (>= this many
 // samples) and a lane renders few of them (< kTwoPhaseMaxPerLane): only then does the order of the tail matter.
 // PBRT_HIP_TWO_PHASE=0 / =1 forces one / two launches (tests, A-B runs).
@@ -697,7 +699,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       R.stack_overflow = s->d_stack_overflow.p;
       R.stack_overflow_entries = extra;
     }
-    R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", kMinWalkers);
+    R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", s->dev.quad_stack_need <= kShallowStackNeed ? kMinWalkersShallow : kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);
     if (counters == 1 && s->gpu_built)
