@@ -1,39 +1,16 @@
-# INTEGRATION — binding `libpbrt_hip.so` from the reference crate
+// UNCOMPILED DOCUMENTATION -- there is no Rust toolchain in the image this repository is built in (no cargo, no
+// rustc), so nothing in this file has ever been through a compiler.  It is what a maintainer of wathiede/pbrt would
+// add to call libpbrt_hip.so from `PbrtAPI::world_end` (src/core/api.rs:432-473): the `extern "C"` mirror of
+// include/pbrt_hip.h and the body of `world_end`.  INTEGRATION.md explains each piece; the C++ program
+// pbrt_amd/csrc/pbrt_main.cpp does the same through the same C ABI and IS compiled and tested.
 
-The reference has no FFI layer and no renderer; the seam is the body of `PbrtAPI::world_end`
-(`/root/reference/src/core/api.rs:432-473`), reached from the parser's `"WorldEnd"` arm
-(`src/core/parser.rs:312`). Below is what a maintainer of the Rust crate would add. **It is
-documentation, not compiled code**: there is no Rust toolchain in this image (`cargo`, `rustc` absent). The Rust
-fragments below are also collected in `rust-shim/ffi.rs` (same caveat in its header).
-
-## 1. What the crate must provide that it does not have today
-
-`RenderOptions` (`api.rs:201-224`) holds names + `ParamSet`s + `camera_to_world` + `lights`, but **no geometry**
-(`api.rs:220-223` is a TODO) and the parser rejects `Shape` / `Material` (`parser.rs:276,300`). To call the
-library the crate has to collect, while parsing the world block:
-
-| C field (`pbrt_hip_scene_desc`) | from |
-|---|---|
-| `P`, `idx` | `Shape "trianglemesh" "point P" "integer indices"` (param shapes already parsed in the test at `parser.rs:821-839`), transformed by the CTM at the time of the directive (`api.rs:588-747` maintains it) |
-| `mat_id`, `mats` | the `Material "matte" "rgb Kd"` / `"mirror" "rgb Kr"` in the current graphics state; `AreaLightSource "diffuse" "rgb L"` → `le` (replaces `api.rs:476-478` `todo!()`) |
-| `spheres` | `Shape "sphere" "float radius"`, centre = CTM translation |
-| `lights` | `LightSource "point" / "distant" / "infinite"` (replaces `make_light`'s `todo!()`s, `api.rs:334-351`) |
-| `cam_to_world`, `fov` | `RenderOptions.camera_to_world` (`api.rs:813-820`), `camera_params.find_one_float("fov", 90.)` |
-| `xres`, `yres`, `crop` | `film_params`: `xresolution`, `yresolution`, `cropwindow` (`film.rs:82-101`) |
-| render desc | `integrator_name` (`"path"` default `api.rs:239` / `"directlighting"`), `"integer maxdepth"`, `"integer pixelsamples"` → `spp_x·spp_y` |
-
-## 2. `build.rs`
-
-```rust
+// ---------------------------------------------------------------- build.rs
 fn main() {
     println!("cargo:rustc-link-search=native={}", std::env::var("PBRT_HIP_LIB_DIR").unwrap());
     println!("cargo:rustc-link-lib=dylib=pbrt_hip");        // pbrt_amd/lib/libpbrt_hip.so
 }
-```
 
-## 3. `src/core/hip.rs` — the `extern "C"` block (mirrors `include/pbrt_hip.h` one to one)
-
-```rust
+// ---------------------------------------------------------------- src/core/hip.rs
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)] pub struct HipMaterial { pub kind: u32, pub k: [f32; 3], pub le: [f32; 3], pub pad: f32 }
@@ -80,11 +57,8 @@ extern "C" {
     pub fn pbrt_hip_read_image(name: *const c_char, rgb: *mut f32, width: *mut i32, height: *mut i32) -> c_int;
     // ... the remaining entry points of include/pbrt_hip.h bind the same way
 }
-```
 
-## 4. `world_end` (replaces the comment block at `api.rs:446-453`)
-
-```rust
+// ---------------------------------------------------------------- src/core/api.rs (world_end)
 fn world_end(&mut self) {
     verify_world!(self, "WorldEnd");
     // ... existing attribute / transform stack checks (api.rs:434-444) ...
@@ -111,24 +85,4 @@ fn world_end(&mut self) {
     film.write_image(1.);            // unchanged: film.rs:340-383 -> imageio::write_image
     self.current_api_state = APIState::OptionsBlock;   // api.rs:458
 }
-```
 
-Ownership: every pointer in `desc` is borrowed for the duration of `pbrt_hip_scene_create` only; `xyzw` is
-caller-owned; the opaque `HipScene` owns all device memory. Errors: non-zero status + thread-local message;
-nothing unwinds across the boundary. Threading: one host thread per scene handle (the crate is
-single-threaded; `Options.num_threads` is never read, `lib.rs:61`).
-
-## 5. The same flow in C++ (compiled and tested here)
-
-`pbrt_amd/csrc/pbrt_main.cpp` → `pbrt_amd/lib/pbrt` is the C++ counterpart of `src/bin/pbrt.rs` (same flags) and does
-exactly what section 4 sketches, through the same C ABI: `pbrt_hip_load_file` → `pbrt_hip_loaded_get` →
-`pbrt_hip_scene_create` → `pbrt_hip_render` → `pbrt_hip_film_to_rgb` → `pbrt_hip_write_image`.
-`tests/test_gpu_parity.py::test_native_cli_renders_c0` runs it on BASELINE config C0's scene and checks the PFM it
-writes bit for bit against a library render.
-
-## 6. Other hosts
-
-Python (`ctypes`): `pbrt_amd/_lib.py` is the complete binding (struct mirrors + argtypes for all 35 symbols);
-`tests/test_host.py::test_struct_layouts_match_header` compiles the header as C99 and checks the mirrors'
-sizes. Multi-GPU: one process per GPU calls `pbrt_hip_render_device` with `rank/world_size` and gathers the slabs
-(`pbrt_amd/dist.py`).
