@@ -19,7 +19,8 @@ namespace pbrt_hip {
 #ifndef PBRT_QUAD_LDS_STACK
 #define PBRT_QUAD_LDS_STACK 40
 #endif
-constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK;  // LDS entries per lane of the quad walk's stack
+constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK;
+constexpr uint32_t kQuadLdsEntries = kQuadLdsStack - 1u;  // entries kept in LDS (the sentinel first); the last row is scratch  // LDS entries per lane of the quad walk's stack
 
 struct DevScene {
   const uint4 *nodes;

@@ -218,15 +218,15 @@ __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt
   if (T.sp == 0u) return kDone;
   T.sp--;
   if (!OVF) return stk[T.sp * 64u];
-  return T.sp < kQuadLdsStack ? stk[T.sp * 64u] : ovf[(T.sp - kQuadLdsStack) * 64u];
+  return T.sp < kQuadLdsEntries ? stk[T.sp * 64u] : ovf[(T.sp - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)];
 }
-// production walk: kQuadLdsStack entries of a lane's stack live in LDS.  The walk stacks at most 3
-// entries per level of the quad tree; only for trees deeper than that allows (OVF) do the deeper
-// entries go to a per-lane HBM area.
+// production walk: the LDS part of a lane's stack has kQuadLdsStack rows = kQuadLdsEntries entries (the
+// sentinel first) + one scratch row, which the branch-free pushes below write when they do not push.  Only for
+// trees whose worst-case bound exceeds that (OVF) do the deeper entries go to a per-lane HBM area.
 template <bool OVF>
 __device__ __forceinline__ void trav_push(Trav &T, uint32_t *stk, uint32_t *ovf, uint32_t ref) {
-  if (!OVF || T.sp < kQuadLdsStack) stk[T.sp * 64u] = ref;
-  else ovf[(T.sp - kQuadLdsStack) * 64u] = ref;
+  if (!OVF || T.sp < kQuadLdsEntries) stk[T.sp * 64u] = ref;
+  else ovf[(T.sp - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)] = ref;
   T.sp++;
 }
 __device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
@@ -420,25 +420,28 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
       const bool n0 = key[0] == kmin, n1 = !n0 && key[1] == kmin, n2 = !n0 && !n1 && key[2] == kmin;
       const bool n3 = !n0 && !n1 && !n2;
-      if (OVF) {
-        if (hit[3] && !n3) trav_push<OVF>(T, stk, ovf, W3.w);
-        if (hit[2] && !n2) trav_push<OVF>(T, stk, ovf, W3.z);
-        if (hit[1] && !n1) trav_push<OVF>(T, stk, ovf, W3.y);
-        if (hit[0] && !n0) trav_push<OVF>(T, stk, ovf, W3.x);
+      const bool any_hit = hit[0] || hit[1] || hit[2] || hit[3];
+      const uint32_t nearest = n0 ? W3.x : (n1 ? W3.y : (n2 ? W3.z : W3.w));
+      // OVF (trees whose worst-case stack bound exceeds the LDS part): one wave-uniform test per step -- is any lane
+      // within four entries of the end of its LDS part? -- picks the slow form with predicated pushes that spill
+      // to HBM; stacks rarely get that deep, so nearly every step takes the branch-free form below.
+      if (OVF && __ballot(T.sp + 4u > kQuadLdsEntries) != 0ull) {
+        if (hit[3] && !n3) trav_push<true>(T, stk, ovf, W3.w);
+        if (hit[2] && !n2) trav_push<true>(T, stk, ovf, W3.z);
+        if (hit[1] && !n1) trav_push<true>(T, stk, ovf, W3.y);
+        if (hit[0] && !n0) trav_push<true>(T, stk, ovf, W3.x);
+        trav_enter(T, any_hit ? nearest : trav_pop<false, true>(T, stk, stkt, ovf, cn));
       } else {
-        // branch-free: the slot above the stack top is scratch (the launcher keeps one LDS row spare)
+        // branch-free: each ref is written above the stack top in any case (one LDS row beyond the entries is
+        // scratch) and the top advances by the hit mask; entry 0 is the sentinel kDone, so T.sp >= 1 while the
+        // lane walks and the top can be read in any case
         stk[T.sp * 64u] = W3.w; T.sp += (hit[3] && !n3) ? 1u : 0u;
         stk[T.sp * 64u] = W3.z; T.sp += (hit[2] && !n2) ? 1u : 0u;
         stk[T.sp * 64u] = W3.y; T.sp += (hit[1] && !n1) ? 1u : 0u;
         stk[T.sp * 64u] = W3.x; T.sp += (hit[0] && !n0) ? 1u : 0u;
-      }
-      const bool any_hit = hit[0] || hit[1] || hit[2] || hit[3];
-      if (OVF) {
-        trav_enter(T, any_hit ? (n0 ? W3.x : (n1 ? W3.y : (n2 ? W3.z : W3.w))) : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
-      } else {
-        const uint32_t top = stk[(T.sp - 1u) * 64u];  // T.sp >= 1 while the lane walks: entry 0 is the sentinel kDone
+        const uint32_t top = stk[(T.sp - 1u) * 64u];
         T.sp -= any_hit ? 0u : 1u;
-        trav_enter(T, any_hit ? (n0 ? W3.x : (n1 ? W3.y : (n2 ? W3.z : W3.w))) : top);
+        trav_enter(T, any_hit ? nearest : top);
       }
     }
     }
@@ -639,7 +642,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   const uint32_t lane = threadIdx.x;
   uint32_t *stk = &lds_stack[0][lane];
   float *stkt = &lds_tn[0][lane];
-  uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u + lane;
+  uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u;  // wave-uniform (SGPRs); the lane is added at use
 
   // Pixels are handed out dynamically (see the fetch step of the service stage): pixel number `pix` of this
   // rank is pixel (pix & 63) of 8x8 block ((pix >> 6) & 63) of local super-tile (pix >> 12), both row-major,
@@ -977,7 +980,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *stk = &lds_stack[wave][0][lane];
   float *stkt = &lds_tn[COUNT ? wave : 0][0][lane];
-  uint32_t *ovf = B.stack_overflow + ((size_t)blockIdx.x * 4u + wave) * B.stack_overflow_entries * 64u + lane;
+  uint32_t *ovf = B.stack_overflow + ((size_t)blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * B.stack_overflow_entries * 64u;  // wave-uniform
   const TravTuning tune = {B.min_walkers, B.min_parked};
   unsigned long long cn = 0, ct = 0;
 #ifdef PBRT_PHASE_PROBE
@@ -1069,7 +1072,8 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
   if (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
     // node steps per scheduling check: 3 for deep trees (C3 +1 %, C2 +2 % over 2), 2 for shallow ones whose walks
     // are a few steps long (C4: 3 would cost 5 %)
-    if (S.quad_stack_need + 2u > kQuadLdsStack) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
+    static const bool force_ovf = std::getenv("PBRT_HIP_FORCE_OVERFLOW_VARIANT") != nullptr;  // A-B runs
+    if (S.quad_stack_need + 2u > kQuadLdsStack || force_ovf) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
     else if (!COUNT && S.quad_stack_need <= 16u) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0, 2>), grid, block, 0, st, S, R);
     else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, 0, st, S, R);
     return hipGetLastError();
