@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include <hipcub/hipcub.hpp>
 
 #include "device_types.h"
@@ -26,15 +28,24 @@ static __global__ void pixel_work_sum_kernel(const float4 *pixel_state, uint32_t
 }
 
 static __global__ void pixel_keys_kernel(const float4 *pixel_state, uint32_t n, const unsigned long long *sum, uint32_t buckets,
-                                         uint32_t *keys, uint32_t *vals) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+                                         uint32_t smooth_own, uint32_t *keys, uint32_t *vals) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // (n is a multiple of 4096: no partial waves)
   if (q >= n) return;
   // key = the pixel's work (node steps + triangle tests + 16 per ray) in units of 1/buckets of the mean
   // pixel's, at most 255; 0 also for pixels not rendered (outside the film).  The pixels of one bucket keep their
   // spatial order (the sort is stable).  `buckets` is small when a lane renders many pixels (the frame is then
   // handed out as neighbouring pixels of mixed cost, which the waves render fastest, and only markedly
   // expensive pixels move to the front) and large when it renders few (then the order of the tail is what counts).
-  const uint32_t work = __float_as_uint(pixel_state[2 * (size_t)q].w);
+  // the 16 or so samples of the first launch make a noisy estimate of what a pixel costs; the cost varies smoothly
+  // over the image, so the pixel's own work is averaged with the mean of its 8x8 block (64 consecutive list entries
+  // = one wave here)
+  const uint32_t own = __float_as_uint(pixel_state[2 * (size_t)q].w);
+  unsigned long long bsum = own, bcnt = own ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) {
+    bsum += __shfl_xor(bsum, off, 64);
+    bcnt += __shfl_xor(bcnt, off, 64);
+  }
+  const unsigned long long work = own ? (own * (unsigned long long)smooth_own + (bcnt ? bsum / bcnt : 0ull) * (unsigned long long)(4u - smooth_own)) / 4ull : 0ull;
   const unsigned long long mean = sum[1] ? sum[0] / sum[1] : 1ull;
   const unsigned long long k = ((unsigned long long)buckets * work) / (mean ? mean : 1ull);
   keys[q] = k > 255ull ? 255u : (uint32_t)k;
@@ -49,10 +60,12 @@ hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint
     return e;
   }
   const dim3 grid((n_pixels + 255u) / 256u), block(256);
+  const char *so = std::getenv("PBRT_HIP_ORDER_SMOOTH");  // weight of the pixel's own work in quarters (tuning)
+  const uint32_t smooth_own = so ? (uint32_t)std::atoi(so) & 7u : 2u;
   hipError_t e = hipMemsetAsync(work_sum, 0, 2 * sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(pixel_work_sum_kernel, grid, block, 0, stream, pixel_state, n_pixels, work_sum);
-  hipLaunchKernelGGL(pixel_keys_kernel, grid, block, 0, stream, pixel_state, n_pixels, work_sum, buckets, keys, vals);
+  hipLaunchKernelGGL(pixel_keys_kernel, grid, block, 0, stream, pixel_state, n_pixels, work_sum, buckets, smooth_own, keys, vals);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   return hipcub::DeviceRadixSort::SortPairsDescending(tmp, *tmp_bytes, keys, keys_out, vals, order, (int)n_pixels, 0, 8, stream);
