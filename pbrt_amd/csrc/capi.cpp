@@ -175,6 +175,46 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
   static const bool greedy = !(std::getenv("PBRT_HIP_GREEDY_COLLAPSE") && std::getenv("PBRT_HIP_GREEDY_COLLAPSE")[0] == '0');
   if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
   auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+  // Which descendants become the (up to four) children of a quad node?  Default: greedy (open the child with the
+  // largest surface area while the result fits four slots).  PBRT_HIP_COLLAPSE=dp instead minimises the summed
+  // surface area of all quad nodes -- the SAH cost of the 4-wide tree, every node step costing the same -- by dynamic
+  // programming over the binary tree (after Ylitie, Karras, Laine 2017, section 3.2):
+  //   F(n, k) = least area of the quad nodes inside subtree n when n may occupy up to k child slots of its parent quad
+  //           = min( present n as ONE child: 0 for a single triangle, else A(n) + min_{k1+k2=4} F(l,k1) + F(r,k2),
+  //                  open n (k >= 2):        min_{k1+k2=k} F(l,k1) + F(r,k2)   [a leaf of c <= k triangles: 0] ).
+  // Measured: 11.6 % fewer nodes, C2 3 % faster, C3 6 % SLOWER (42.4 instead of 41.0 fetches and 5.25 instead of 4.99
+  // triangle tests per ray): the model does not see that a small child of a large node gets a coarse 8-bit box.
+  static const bool use_dp = greedy && std::getenv("PBRT_HIP_COLLAPSE") && std::strcmp(std::getenv("PBRT_HIP_COLLAPSE"), "dp") == 0;
+  const size_t nn = b.nodes.size();
+  std::vector<float> F;       // F[5 * n + k], k = 1..4
+  std::vector<float> one;     // cost of presenting n as one child
+  if (use_dp) {
+    F.assign(5 * nn, 0.f);
+    one.assign(nn, 0.f);
+    auto node_area = [&](const BvhNode &n) {
+      const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+      return (dx * dy + dx * dz) + dy * dz;
+    };
+    for (size_t i = nn; i-- > 0;) {  // children have larger indices than their parent (depth-first order)
+      const BvhNode &n = b.nodes[i];
+      const uint32_t cnt = n.count_axis & 0xffffu;
+      if (cnt) {
+        const bool splittable = split_leaves && cnt >= 2 && cnt <= 4;
+        one[i] = splittable ? node_area(n) : 0.f;
+        for (uint32_t k = 1; k <= 4; k++) F[5 * i + k] = (splittable && k < cnt) ? one[i] : 0.f;
+      } else {
+        const size_t l = i + 1, r = n.offset;
+        auto dist = [&](uint32_t k) {
+          float best = std::numeric_limits<float>::infinity();
+          for (uint32_t k1 = 1; k1 < k; k1++) best = std::min(best, F[5 * l + k1] + F[5 * r + (k - k1)]);
+          return best;
+        };
+        one[i] = node_area(n) + dist(4);
+        F[5 * i + 1] = one[i];
+        for (uint32_t k = 2; k <= 4; k++) F[5 * i + k] = std::min(one[i], dist(k));
+      }
+    }
+  }
   struct Item { uint32_t node, quad, path; bool is_leaf; };  // path = stack entries held above this node
   std::vector<Item> todo = {{0u, 0u, 0u, false}};
   out->q.assign(4, make_uint4(0, 0, 0, 0));
@@ -215,6 +255,40 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
       // Greedy collapse: start from the two children of the binary node and keep opening the child with the
       // largest surface area (an interior node into its two children, a small leaf into its triangles) while
       // the result still fits four slots.
+      if (use_dp) {
+        // follow the minimising choices: node c with k slots is opened (its children share the k slots) or presented as one
+        struct Open { uint32_t c, k; };
+        std::vector<Open> st;
+        auto split = [&](uint32_t c, uint32_t k) {  // the (k1, k - k1) that minimises F(l, k1) + F(r, k - k1); ties: the most even
+          const size_t l = c + 1, r = b.nodes[c].offset;
+          uint32_t bk = 1;
+          float best = std::numeric_limits<float>::infinity();
+          for (uint32_t k1 = 1; k1 < k; k1++) {
+            const float v = F[5 * l + k1] + F[5 * r + (k - k1)];
+            if (v < best || (v == best && std::abs((int)(2 * k1) - (int)k) < std::abs((int)(2 * bk) - (int)k))) { best = v; bk = k1; }
+          }
+          st.push_back({(uint32_t)r, k - bk});
+          st.push_back({(uint32_t)l, bk});
+        };
+        split(it.node, 4u);
+        while (!st.empty()) {
+          const Open o = st.back();
+          st.pop_back();
+          const BvhNode &n = b.nodes[o.c];
+          const uint32_t cnt = n.count_axis & 0xffffu;
+          if (cnt) {
+            if (split_leaves && cnt >= 2 && cnt <= 4 && o.k >= cnt) {
+              for (uint32_t j = 0; j < cnt; j++) kids[nk++] = tri_child(n.offset + j);  // opened: its triangles are direct children
+            } else {
+              add_node(o.c);
+            }
+          } else if (o.k >= 2u && F[5 * (size_t)o.c + o.k] < one[o.c]) {
+            split(o.c, o.k);
+          } else {
+            add_node(o.c);
+          }
+        }
+      } else {
       add_node(it.node + 1);
       add_node(me.offset);
       auto area = [](const QuadChild &k) {
@@ -247,6 +321,7 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
           if ((b.nodes[c].count_axis & 0xffffu) == 0) { add_node(c + 1); add_node(b.nodes[c].offset); }
           else add_node(c);
         }
+      }
       }
     }
     const uint32_t path = it.path + (uint32_t)(nk - 1);

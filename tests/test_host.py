@@ -252,3 +252,28 @@ def test_quantised_quad_tree_invariants(name, split):
     quads, need = pbrt_amd.quad_build_host(sd.P, sd.idx, split_leaves=split)
     assert len(quads) > 0 and need >= 1
     _check_quads(quads, need, sd.P, sd.idx, order)
+
+
+def test_dp_collapse_option_builds_a_valid_tree():
+    """PBRT_HIP_COLLAPSE=dp (SAH-optimal collapse by dynamic programming; read once per process, hence the child
+    process): fewer nodes than the greedy rule, same structural invariants."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.setrecursionlimit(10000); sys.path.insert(0, 'tests')\n"
+        "import pbrt_amd\n"
+        "from util import SMALL_SCENES\n"
+        "from test_host import _check_quads\n"
+        "sd = SMALL_SCENES['mesh20k']()\n"
+        "nodes, order, depth = pbrt_amd.bvh_build_host(sd.P, sd.idx)\n"
+        "quads, need = pbrt_amd.quad_build_host(sd.P, sd.idx)\n"
+        "_check_quads(quads, need, sd.P, sd.idx, order)\n"
+        "print(len(quads))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = {}
+    for mode in ("dp", "greedy"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root,
+                           env=dict(os.environ, PBRT_HIP_COLLAPSE=mode))
+        assert r.returncode == 0, r.stderr[-2000:]
+        n[mode] = int(r.stdout.split()[-1])
+    assert n["dp"] < n["greedy"]
