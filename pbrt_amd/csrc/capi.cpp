@@ -787,11 +787,12 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     // together (a pixel's samples are sequential, ~0.4 s for C3's 512: with 2 pixels per lane, as on 8 GPUs,
     // the unordered tail cost 30 %).  Scheduling only: every pixel still sees its samples in order.
     const uint32_t spp = r->spp_x * r->spp_y;
-    const uint32_t per_lane = std::max<uint32_t>(1u, R.n_pixels / (R.n_workgroups * 64u));
+    const uint32_t per_lane = std::max<uint32_t>(1u, R.n_pixels / std::max<uint32_t>(1u, R.n_workgroups * 64u));  // (a rank may own no tile at all)
     const char *tp = std::getenv("PBRT_HIP_TWO_PHASE");
     bool two = spp >= kTwoPhaseMinSpp && per_lane < kTwoPhaseMaxPerLane;
     if (tp && tp[0] == '0') two = false;
     if (tp && tp[0] == '1' && spp >= 2u) two = true;
+    if (sh.n_local == 0) two = false;  // a rank that owns no tile has nothing to order
     const uint32_t s_split = two ? std::max<uint32_t>(1u, spp / 32u) : 0u;
     R.pixel_state = nullptr;
     R.pixel_order = nullptr;

@@ -145,6 +145,21 @@ def test_two_launch_frames_on_other_kernel_variants(gpu, oracle, monkeypatch, na
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
 
 
+def test_rank_without_tiles(gpu, oracle, monkeypatch):
+    """A frame of one 64x64 super-tile split over three ranks: ranks 1 and 2 own nothing and must return an empty
+    (all-zero) film, with and without the two-launch path (found by the randomised tests: a division by the zero
+    workgroups of such a rank)."""
+    sd = scenes.cornell_scene(40, 33)
+    ref, _ = oracle.OracleScene(sd).render(max_depth=3, spp=(2, 2), seed=4)
+    for two in ("0", "1"):
+        monkeypatch.setenv("PBRT_HIP_TWO_PHASE", two)
+        with gpu.Scene(sd) as sc:
+            parts = [sc.render(max_depth=3, spp=(2, 2), seed=4, rank=r, world_size=3) for r in range(3)]
+        assert_bit_equal(parts[0][0], ref, "rank 0 holds the whole frame")
+        for film, st in parts[1:]:
+            assert not film.any() and st["samples"] == 0
+
+
 def test_golden_fixture(gpu):
     """tests/golden/render_golden.npz: films the oracle produced when the fixtures were made
     (tests/golden/make_golden.py); the HIP path must reproduce them bit for bit."""
@@ -377,3 +392,70 @@ def test_gpu_built_scene_equals_host_built_scene_c2(gpu):
         fb, _ = b.render(max_depth=8, spp=(8, 8), seed=0)
         assert b.build_info()["gpu_built"] and not a.build_info()["gpu_built"]
     assert_bit_equal(fa, fb, "host-built vs device-built")
+
+
+# ---- randomised scenes: everything the path takes as input, drawn at random ----
+
+def _random_scene(seed):
+    from pbrt_amd.scenes import MATTE, MIRROR, _camera, _mat
+    rng = np.random.default_rng(1000 + seed)
+    n_tris = int(rng.choice([0, 1, 2, 5, 17, 64, 300]))
+    c = rng.uniform(-1, 1, (n_tris, 1, 3))
+    P = (c + rng.uniform(-0.4, 0.4, (n_tris, 3, 3))).reshape(-1, 3).astype(np.float32)
+    if n_tris >= 5 and seed % 3 == 0:  # some exact duplicates and a degenerate triangle: the tie rule and |det| < 1e-8
+        P[3:6] = P[0:3]
+        P[6:9] = P[6]
+    idx = np.arange(3 * n_tris, dtype=np.uint32).reshape(-1, 3)
+    n_mats = int(rng.integers(1, 6))
+    mats = []
+    for m in range(n_mats):
+        kind = MIRROR if rng.random() < 0.3 else MATTE
+        le = tuple(rng.uniform(0.5, 8.0, 3)) if (kind == MATTE and rng.random() < 0.3) else (0, 0, 0)
+        mats.append(_mat(kind, tuple(rng.uniform(0.1, 0.95, 3)), le))
+    mat_id = rng.integers(0, n_mats, n_tris).astype(np.uint16)
+    lights = []
+    for _ in range(int(rng.integers(0, 4))):
+        kind = int(rng.integers(0, 3))
+        if kind == LIGHT_INFINITE:
+            lights.append([kind, 0, 0, 0, *rng.uniform(0.1, 1.0, 3)])
+        elif kind == 1:
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            lights.append([kind, *d, *rng.uniform(0.5, 3.0, 3)])
+        else:
+            lights.append([kind, *rng.uniform(-3, 3, 3), *rng.uniform(2.0, 30.0, 3)])
+    spheres = [[*rng.uniform(-1, 1, 3), rng.uniform(0.1, 0.7), int(rng.integers(0, n_mats))] for _ in range(int(rng.integers(0, 3)))]
+    eye = rng.uniform(-3.5, 3.5, 3)
+    if np.linalg.norm(eye) < 1.5:
+        eye = eye / max(np.linalg.norm(eye), 1e-3) * 2.5
+    xres, yres = int(rng.integers(5, 90)), int(rng.integers(5, 80))
+    crop = (0.0, 1.0, 0.0, 1.0) if seed % 4 else (0.1, 0.83, 0.25, 0.9)
+    return SceneData(P=P, idx=idx, mat_id=mat_id, materials=np.array(mats, np.float32),
+                     lights=np.array(lights, np.float32).reshape(-1, 7), spheres=np.array(spheres, np.float32).reshape(-1, 5),
+                     cam_to_world=_camera(tuple(eye), tuple(rng.uniform(-0.3, 0.3, 3)), (0, 0, 1)), fov=float(rng.uniform(25, 100)),
+                     xres=xres, yres=yres, crop=crop).normalized(), rng
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
+    """Triangle counts 0..300 (with duplicates and degenerate triangles), random materials (mirrors, emitters),
+    0-3 lights of every kind, 0-2 spheres, random camera / resolution / crop / strata / depth / integrator /
+    seed / rank split; odd seeds force the two-launch frame, every third builds the tree on the device."""
+    sd, rng = _random_scene(seed)
+    integ = INTEGRATOR_DIRECT if seed % 5 == 4 else INTEGRATOR_PATH
+    depth, spp, rseed = int(rng.integers(0, 12)), (int(rng.integers(1, 7)), int(rng.integers(1, 6))), int(rng.integers(0, 1 << 20))
+    world = int(rng.integers(1, 4))
+    ref, rst = oracle.OracleScene(sd).render(integrator=integ, max_depth=depth, spp=spp, seed=rseed)
+    if seed % 2 and spp[0] * spp[1] >= 2:
+        monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "1")
+    with gpu.Scene(sd, builder="gpu" if seed % 3 == 2 else "host") as sc:
+        acc = None
+        for r in range(world):
+            part, _ = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, rank=r, world_size=world)
+            acc = part if acc is None else acc + part
+        st = None
+        if not sc.build_info()["gpu_built"]:
+            _, st = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, counters=True)
+    assert_bit_equal(acc, ref, f"random scene {seed} ({len(sd.idx)} tris, {len(sd.spheres)} spheres, {len(sd.lights)} lights, {world} ranks)")
+    if st is not None:
+        for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+            assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
