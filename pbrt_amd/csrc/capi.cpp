@@ -522,6 +522,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     // --- accelerator: the host's binned-SAH builder, or (PBRT_HIP_SCENE_GPU_BUILD) the device builder further down ---
     if (flags & ~PBRT_HIP_SCENE_GPU_BUILD) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
     s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && d->n_tris >= 2;
+    if (d->n_tris > (1u << 24)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 2^24 triangles (leaf references hold a 24-bit slot)");
     PairNodes pairs;
     if (!s->gpu_built) {
       const auto t0 = std::chrono::steady_clock::now();

@@ -435,7 +435,7 @@ def _random_scene(seed):
                      xres=xres, yres=yres, crop=crop).normalized(), rng
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     """Triangle counts 0..300 (with duplicates and degenerate triangles), random materials (mirrors, emitters),
     0-3 lights of every kind, 0-2 spheres, random camera / resolution / crop / strata / depth / integrator /
