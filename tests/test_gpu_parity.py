@@ -455,6 +455,13 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
         st = None
         if not sc.build_info()["gpu_built"]:
             _, st = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, counters=True)
+        o, d, tmax = random_rays(3000, seed, inside=2.5)
+        hit = sc.intersect(o, d, tmax)
+        occ = sc.occluded(o, d, tmax)
+    rhit = oracle.OracleScene(sd).intersect(o, d, tmax)
+    for a, b, what in zip(hit[:4], rhit[:4], ("t", "prim", "b1", "b2")):
+        assert_bit_equal(a, b, f"random scene {seed}: {what}")
+    assert np.array_equal(occ != 0, oracle.OracleScene(sd).occluded(o, d, tmax) != 0)
     assert_bit_equal(acc, ref, f"random scene {seed} ({len(sd.idx)} tris, {len(sd.spheres)} spheres, {len(sd.lights)} lights, {world} ranks)")
     if st is not None:
         for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
