@@ -108,7 +108,9 @@ int pbrt_hip_device_count(void);
 const char *pbrt_hip_last_error(void);
 const char *pbrt_hip_version(void);
 
-/* ---- scene: flatten + BVH build on the host, upload to HBM.  device < 0: current device. ---- */
+/* ---- scene: flatten + BVH build on the host, upload to HBM.  device < 0: current device.
+ * Input is validated before any device work: indices in range, vertices / spheres / camera matrix finite, sphere radii
+ * positive, 0 < fov < 180 (PBRT_HIP_ERR_INVALID otherwise). ---- */
 int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_scene **out);
 /* The same with options.  PBRT_HIP_SCENE_GPU_BUILD: build the accelerator on the device (Morton codes, radix sort,
  * binary radix tree, collapse into the quantised 4-wide nodes) instead of the host's binned-SAH

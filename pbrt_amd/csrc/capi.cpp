@@ -78,6 +78,16 @@ constexpr uint32_t kTwoPhaseMinSpp = 128, kTwoPhaseMaxPerLane = 16;
 
 constexpr uint32_t kLeafRef = 0x80000000u;
 
+// A vertex that a triangle uses and that is NaN or infinite would send the builders' bucket index out of range:
+// such input is refused at the boundary.  Returns the first offending vertex, or -1.
+long long first_non_finite_vertex(const float *P, const uint32_t *idx, uint32_t n_tris) {
+  for (size_t i = 0; i < 3 * (size_t)n_tris; i++) {
+    const float *v = P + 3 * (size_t)idx[i];
+    if (!std::isfinite(v[0]) || !std::isfinite(v[1]) || !std::isfinite(v[2])) return (long long)idx[i];
+  }
+  return -1;
+}
+
 // "Children in parent" form of the binary tree for the kernels: one 64-byte record per INTERIOR
 // node with the boxes and references of its two children.  ref = interior index
 // (dense numbering of interior nodes in depth-first order) or kLeafRef | n_prims << 24 | first slot.
@@ -453,6 +463,7 @@ int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *id
     if ((n_tris && (!P || !idx)) || !n_nodes || !depth) return fail(PBRT_HIP_ERR_INVALID, "bvh_build_host: null argument");
     for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
       if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "bvh_build_host: vertex index out of range");
+    if (first_non_finite_vertex(P, idx, n_tris) >= 0) return fail(PBRT_HIP_ERR_INVALID, "bvh_build_host: a vertex is not finite");
     Bvh b;
     build_bvh(P, idx, n_tris, &b);
     *n_nodes = (uint32_t)b.nodes.size();
@@ -471,6 +482,7 @@ int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *i
     if ((n_tris && (!P || !idx)) || !n_quads || !stack_need) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: null argument");
     for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
       if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: vertex index out of range");
+    if (first_non_finite_vertex(P, idx, n_tris) >= 0) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: a vertex is not finite");
     Bvh b;
     build_bvh(P, idx, n_tris, &b);
     QuadNodes q;
@@ -504,6 +516,18 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       if (d->idx[i] >= d->n_verts) return fail(PBRT_HIP_ERR_INVALID, "scene_create: vertex index out of range");
     for (uint32_t t = 0; t < d->n_tris; t++)
       if (d->mat_id[t] >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: material id out of range");
+    {
+      const long long bad = first_non_finite_vertex(d->P, d->idx, d->n_tris);
+      if (bad >= 0) return fail(PBRT_HIP_ERR_INVALID, "scene_create: vertex " + std::to_string(bad) + " is not finite");
+    }
+    for (uint32_t s = 0; s < d->n_spheres; s++) {
+      const pbrt_hip_sphere &sp = d->spheres[s];
+      if (!std::isfinite(sp.c[0]) || !std::isfinite(sp.c[1]) || !std::isfinite(sp.c[2]) || !std::isfinite(sp.r) || !(sp.r > 0.f))
+        return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere centre / radius must be finite and the radius positive");
+    }
+    for (int k = 0; k < 16; k++)
+      if (!std::isfinite(d->cam_to_world[k])) return fail(PBRT_HIP_ERR_INVALID, "scene_create: camera matrix is not finite");
+    if (!(d->fov > 0.f && d->fov < 180.f)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: fov must lie in (0, 180) degrees");
     for (uint32_t s = 0; s < d->n_spheres; s++)
       if (d->spheres[s].mat >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere material id out of range");
 

@@ -69,6 +69,26 @@ def test_bad_arguments_are_rejected_before_any_device_work():
     sd.xres = 0
     with pytest.raises(_lib.PbrtHipError):
         pbrt_amd.Scene(sd)
+    for bad in (np.nan, np.inf, -np.inf):  # a non-finite vertex would send the SAH bucket index out of range
+        sd = scenes.cornell_scene(8, 8)
+        sd.P = sd.P.copy()
+        sd.P[5, 1] = bad
+        with pytest.raises(_lib.PbrtHipError) as e:
+            pbrt_amd.Scene(sd)
+        assert e.value.code == -1 and "not finite" in str(e.value)
+        with pytest.raises(_lib.PbrtHipError):
+            pbrt_amd.bvh_build_host(sd.P, sd.idx)
+        with pytest.raises(_lib.PbrtHipError):
+            pbrt_amd.quad_build_host(sd.P, sd.idx)
+    sd = scenes.check_sphere_scene(8, 8)
+    sd.spheres = sd.spheres.copy()
+    sd.spheres[0, 3] = 0.0
+    with pytest.raises(_lib.PbrtHipError):
+        pbrt_amd.Scene(sd)
+    sd = scenes.cornell_scene(8, 8)
+    sd.fov = 180.0
+    with pytest.raises(_lib.PbrtHipError):
+        pbrt_amd.Scene(sd)
     with pytest.raises(ValueError):
         pbrt_amd.slab_pixel_index(64, 64, (0, 1, 0, 1), 2, 2)
 
