@@ -186,42 +186,92 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
   if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
   auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
   // Which descendants become the (up to four) children of a quad node?  Default: greedy (open the child with the
-  // largest surface area while the result fits four slots).  PBRT_HIP_COLLAPSE=dp instead minimises the summed
-  // surface area of all quad nodes -- the SAH cost of the 4-wide tree, every node step costing the same -- by dynamic
-  // programming over the binary tree (after Ylitie, Karras, Laine 2017, section 3.2):
-  //   F(n, k) = least area of the quad nodes inside subtree n when n may occupy up to k child slots of its parent quad
-  //           = min( present n as ONE child: 0 for a single triangle, else A(n) + min_{k1+k2=4} F(l,k1) + F(r,k2),
-  //                  open n (k >= 2):        min_{k1+k2=k} F(l,k1) + F(r,k2)   [a leaf of c <= k triangles: 0] ).
-  // Measured: 11.6 % fewer nodes, C2 3 % faster, C3 6 % SLOWER (42.4 instead of 41.0 fetches and 5.25 instead of 4.99
-  // triangle tests per ray): the model does not see that a small child of a large node gets a coarse 8-bit box.
+  // largest surface area while the result fits four slots).  PBRT_HIP_COLLAPSE=dp instead minimises, by dynamic
+  // programming over the binary tree (after Ylitie, Karras, Laine 2017, section 3.2), the expected work of a walk:
+  // every child of a quad node R is reached with the probability of its box AS R's 8-BIT GRID HOLDS IT (about one
+  // cell of R wider per axis -- a small child of a large node gets a coarse box), a reached interior child costs one
+  // node step, a reached triangle c_tri.  R is the ancestor at binary distance d = 1..3 of the node in question:
+  //   F(n, k, d) = least expected work inside subtree n when n may occupy up to k child slots of R
+  //              = min( present n as ONE child: Aq(n, R) * (c_tri * #triangles)   for a plain leaf,
+  //                                             Aq(n, R) + G(n)                   else (one step at n, plus below),
+  //                     open n (k >= 2, d < 3): min_{k1+k2=k} F(l, k1, d+1) + F(r, k2, d+1) )
+  // with G(n) = min_{k1+k2=4} F(l,k1,1) + F(r,k2,1) the work below n as a quad node of its own (areas are
+  // unconditional reach probabilities up to the common factor 1/A(root), as in the SAH).
+  // Measured (c_tri = 2): C3 40.2 instead of 41.0 fetches per ray but a stack bound of 41 (overflow variant): -1 %;
+  // C2 +2 %.  Without the quantisation term the same programme made 11.6 % fewer nodes and C3 6 % slower.
   static const bool use_dp = greedy && std::getenv("PBRT_HIP_COLLAPSE") && std::strcmp(std::getenv("PBRT_HIP_COLLAPSE"), "dp") == 0;
+  static const float c_tri = std::getenv("PBRT_HIP_COLLAPSE_CTRI") ? (float)std::atof(std::getenv("PBRT_HIP_COLLAPSE_CTRI")) : 2.0f;
   const size_t nn = b.nodes.size();
-  std::vector<float> F;       // F[5 * n + k], k = 1..4
-  std::vector<float> one;     // cost of presenting n as one child
+  std::vector<float> F;            // F[(4 * n + (k - 1)) * 3 + (d - 1)]
+  std::vector<float> G;            // work below n as a quad node of its own (interior nodes and splittable leaves)
+  std::vector<uint32_t> parent;
+  auto Fi = [](size_t n, uint32_t k, uint32_t d) { return (4 * n + (k - 1)) * 3 + (d - 1); };
+  auto anc = [&](uint32_t n, uint32_t d) { while (d-- && parent[n] != 0xffffffffu) n = parent[n]; return n; };
+  // surface area of box (lo, hi) as the grid of quad node q holds it: about one cell wider per axis
+  auto area_q = [&](const float *lo, const float *hi, const BvhNode &q) {
+    float dd[3];
+    for (int a = 0; a < 3; a++) {
+      const float ext = q.hi[a] - q.lo[a];
+      int e = -126;
+      if (ext > 0.f) { std::frexp(ext / 255.0f, &e); if (e < -126) e = -126; }
+      dd[a] = (hi[a] - lo[a]) + std::ldexp(1.0f, e);
+    }
+    return (dd[0] * dd[1] + dd[0] * dd[2]) + dd[1] * dd[2];
+  };
+  auto tri_box = [&](uint32_t slot, float lo[3], float hi[3]) {
+    const uint32_t t = b.order[slot];
+    for (int a = 0; a < 3; a++) {
+      const float v0 = P[3 * idx[3 * t] + a], v1 = P[3 * idx[3 * t + 1] + a], v2 = P[3 * idx[3 * t + 2] + a];
+      lo[a] = std::min(v0, std::min(v1, v2));
+      hi[a] = std::max(v0, std::max(v1, v2));
+    }
+  };
+  auto one_cost = [&](uint32_t n, uint32_t d) {  // n presented as ONE child of its ancestor at distance d
+    const BvhNode &nd = b.nodes[n];
+    const uint32_t cnt = nd.count_axis & 0xffffu;
+    const float reach = area_q(nd.lo, nd.hi, b.nodes[anc(n, d)]);
+    if (cnt && !(split_leaves && cnt >= 2 && cnt <= 4)) return reach * c_tri * (float)cnt;  // plain leaf: its triangles are tested
+    return reach + G[n];  // a quad node of its own: one step when reached, plus what lies below
+  };
   if (use_dp) {
-    F.assign(5 * nn, 0.f);
-    one.assign(nn, 0.f);
-    auto node_area = [&](const BvhNode &n) {
-      const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
-      return (dx * dy + dx * dz) + dy * dz;
-    };
+    F.assign(12 * nn, 0.f);
+    G.assign(nn, 0.f);
+    parent.assign(nn, 0xffffffffu);
+    for (size_t i = 0; i < nn; i++)
+      if ((b.nodes[i].count_axis & 0xffffu) == 0) { parent[i + 1] = (uint32_t)i; parent[b.nodes[i].offset] = (uint32_t)i; }
     for (size_t i = nn; i-- > 0;) {  // children have larger indices than their parent (depth-first order)
       const BvhNode &n = b.nodes[i];
       const uint32_t cnt = n.count_axis & 0xffffu;
       if (cnt) {
         const bool splittable = split_leaves && cnt >= 2 && cnt <= 4;
-        one[i] = splittable ? node_area(n) : 0.f;
-        for (uint32_t k = 1; k <= 4; k++) F[5 * i + k] = (splittable && k < cnt) ? one[i] : 0.f;
+        if (splittable) {  // as a quad node of its own its triangles sit on ITS grid
+          float g = 0.f;
+          for (uint32_t j = 0; j < cnt; j++) { float lo[3], hi[3]; tri_box(n.offset + j, lo, hi); g += c_tri * area_q(lo, hi, n); }
+          G[i] = g;
+        }
+        for (uint32_t d = 1; d <= 3; d++) {
+          const float one = one_cost((uint32_t)i, d);
+          float opened = std::numeric_limits<float>::infinity();
+          if (splittable) {  // opened: its triangles are direct children of the ancestor
+            opened = 0.f;
+            const BvhNode &q = b.nodes[anc((uint32_t)i, d)];
+            for (uint32_t j = 0; j < cnt; j++) { float lo[3], hi[3]; tri_box(n.offset + j, lo, hi); opened += c_tri * area_q(lo, hi, q); }
+          }
+          for (uint32_t k = 1; k <= 4; k++) F[Fi(i, k, d)] = (splittable && k >= cnt) ? std::min(one, opened) : one;
+        }
       } else {
         const size_t l = i + 1, r = n.offset;
-        auto dist = [&](uint32_t k) {
+        auto dist = [&](uint32_t k, uint32_t d) {
           float best = std::numeric_limits<float>::infinity();
-          for (uint32_t k1 = 1; k1 < k; k1++) best = std::min(best, F[5 * l + k1] + F[5 * r + (k - k1)]);
+          for (uint32_t k1 = 1; k1 < k; k1++) best = std::min(best, F[Fi(l, k1, d)] + F[Fi(r, k - k1, d)]);
           return best;
         };
-        one[i] = node_area(n) + dist(4);
-        F[5 * i + 1] = one[i];
-        for (uint32_t k = 2; k <= 4; k++) F[5 * i + k] = std::min(one[i], dist(k));
+        G[i] = dist(4, 1);
+        for (uint32_t d = 1; d <= 3; d++) {
+          const float one = one_cost((uint32_t)i, d);
+          F[Fi(i, 1, d)] = one;
+          for (uint32_t k = 2; k <= 4; k++) F[Fi(i, k, d)] = d < 3 ? std::min(one, dist(k, d + 1)) : one;
+        }
       }
     }
   }
@@ -266,34 +316,35 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
       // largest surface area (an interior node into its two children, a small leaf into its triangles) while
       // the result still fits four slots.
       if (use_dp) {
-        // follow the minimising choices: node c with k slots is opened (its children share the k slots) or presented as one
-        struct Open { uint32_t c, k; };
+        // follow the minimising choices: node c with k slots at distance d is opened or presented as one child
+        struct Open { uint32_t c, k, d; };
         std::vector<Open> st;
-        auto split = [&](uint32_t c, uint32_t k) {  // the (k1, k - k1) that minimises F(l, k1) + F(r, k - k1); ties: the most even
+        auto split = [&](uint32_t c, uint32_t k, uint32_t d) {  // children of c share k slots at distance d; ties: the most even split
           const size_t l = c + 1, r = b.nodes[c].offset;
           uint32_t bk = 1;
           float best = std::numeric_limits<float>::infinity();
           for (uint32_t k1 = 1; k1 < k; k1++) {
-            const float v = F[5 * l + k1] + F[5 * r + (k - k1)];
+            const float v = F[Fi(l, k1, d)] + F[Fi(r, k - k1, d)];
             if (v < best || (v == best && std::abs((int)(2 * k1) - (int)k) < std::abs((int)(2 * bk) - (int)k))) { best = v; bk = k1; }
           }
-          st.push_back({(uint32_t)r, k - bk});
-          st.push_back({(uint32_t)l, bk});
+          st.push_back({(uint32_t)r, k - bk, d});
+          st.push_back({(uint32_t)l, bk, d});
         };
-        split(it.node, 4u);
+        split(it.node, 4u, 1u);
         while (!st.empty()) {
           const Open o = st.back();
           st.pop_back();
           const BvhNode &n = b.nodes[o.c];
           const uint32_t cnt = n.count_axis & 0xffffu;
+          const float one = one_cost(o.c, o.d);
           if (cnt) {
-            if (split_leaves && cnt >= 2 && cnt <= 4 && o.k >= cnt) {
+            if (split_leaves && cnt >= 2 && cnt <= 4 && o.k >= cnt && F[Fi(o.c, o.k, o.d)] < one) {
               for (uint32_t j = 0; j < cnt; j++) kids[nk++] = tri_child(n.offset + j);  // opened: its triangles are direct children
             } else {
               add_node(o.c);
             }
-          } else if (o.k >= 2u && F[5 * (size_t)o.c + o.k] < one[o.c]) {
-            split(o.c, o.k);
+          } else if (o.k >= 2u && o.d < 3u && F[Fi(o.c, o.k, o.d)] < one) {
+            split(o.c, o.k, o.d + 1u);
           } else {
             add_node(o.c);
           }
