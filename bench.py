@@ -62,7 +62,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0):
+def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0, gpu_film=None):
     """The CPU oracle ("port"), rebuilt -march=native on this box, all host cores, on a bounded
     sample of the same workload: every `world`-th 64x64 super-tile of the frame (spread over the
     whole image, at least 8 work tiles per host thread) at a reduced sample count chosen by a
@@ -90,7 +90,26 @@ def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0):
     film, st = sc.render(spp=(sx, sy), **kw)
     samples = pixels * sx * sy
     rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]
+    # the metric's quality half ("PSNR vs CPU reference"): a 48x48 window of the frame at the frame's FULL sample
+    # count on the oracle against the same pixels of the film the GPU has just rendered (linear RGB clamped to [0,1])
+    parity = None
+    if gpu_film is not None:
+        import numpy as np
+        import pbrt_amd
+        w = 48
+        x0, y0 = (res // 2 // w) * w, (res // 3 // w) * w
+        crop = (x0 / res, (x0 + w) / res, y0 / res, (y0 + w) / res)
+        ref, pst = ob.OracleScene(make_scene_data(kind, n, res, crop=crop), native=True).render(
+            integrator=integrator, max_depth=depth, seed=0, spp=spp, n_threads=cores)
+        got = gpu_film[y0:y0 + w, x0:x0 + w]
+        a = np.clip(pbrt_amd.film_to_rgb(np.ascontiguousarray(got)).astype(np.float64), 0, 1)
+        b = np.clip(pbrt_amd.film_to_rgb(np.ascontiguousarray(ref)).astype(np.float64), 0, 1)
+        mse = float(((a - b) ** 2).mean())
+        parity = {"window": [x0, y0, w, w], "spp": spp[0] * spp[1], "bit_equal": bool((got.view(np.uint32) == ref.view(np.uint32)).all()),
+                  "psnr_db": None if mse == 0 else 10 * np.log10(1.0 / mse), "psnr_note": "null = identical images (infinite PSNR)",
+                  "oracle_seconds": round(pst["seconds"], 2)}
     return {
+        "parity_window": parity,
         "value": samples / st["seconds"] / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": f"CPU oracle (ours; the reference has no renderer), {samples} samples = super-tiles t%{world}==0 "
                   f"({pixels} pixels) of the {res}x{res} frame at {sx}x{sy} spp, {st['seconds']:.1f} s on {cores} threads",
@@ -248,7 +267,8 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, n, res, integrator, depth, spp)
+            out["cpu_baseline"] = cpu_baseline(kind, n, res, integrator, depth, spp,
+                                               gpu_film=film.cpu().numpy() if film is not None else None)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if film is not None:
             import numpy as np
