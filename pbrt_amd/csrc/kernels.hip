@@ -229,15 +229,6 @@ __device__ __forceinline__ void trav_push(Trav &T, uint32_t *stk, uint32_t *ovf,
   else ovf[(T.sp - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)] = ref;
   T.sp++;
 }
-__device__ __forceinline__ void cswap(float &ka, uint32_t &ra, float &kb, uint32_t &rb) {
-  const bool sw = kb < ka;
-  const float k = sw ? kb : ka;
-  const uint32_t r = sw ? rb : ra;
-  kb = sw ? ka : kb;
-  rb = sw ? ra : rb;
-  ka = k;
-  ra = r;
-}
 
 __device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) { T.cur = ref; }
 __device__ __forceinline__ bool trav_parked(const Trav &T) { return T.cur != kDone && (T.cur & kLeafRef) != 0u; }
