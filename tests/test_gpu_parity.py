@@ -253,6 +253,25 @@ def test_full_size_properties_c2(gpu, oracle):
     assert_bit_equal(film[256:320, 256:320], ref, "window of the full frame")
 
 
+def test_c2_full_frame_eight_rank_shares_add_up(gpu):
+    """BASELINE config C2 at its full size and sample count: the frame rendered by one rank (one launch) equals, bit
+    for bit, the sum of the eight shares of an 8-GPU job (each rendered in two launches with the cost-ordered
+    hand-out): sharding, parking / resuming pixels and the XCD-aware hand-out change no sample."""
+    sd = scenes.random_mesh_scene(100_000, 1024, 1024)
+    with gpu.Scene(sd) as sc:
+        full, st = sc.render(max_depth=8, spp=(16, 16), seed=0)
+        acc = np.zeros_like(full)
+        n = 0
+        for r in range(8):
+            part, pst = sc.render(max_depth=8, spp=(16, 16), seed=0, rank=r, world_size=8)
+            assert ((acc[..., 3] == 0) | (part[..., 3] == 0)).all()  # shares do not overlap
+            acc += part
+            n += pst["samples"]
+    assert n == st["samples"] == 1024 * 1024 * 256
+    assert (full[..., 3] == 256).all()
+    assert_bit_equal(acc, full, "sum of 8 rank shares vs the single-rank frame")
+
+
 def test_c3_scene_window(gpu, oracle):
     """BASELINE config C3's scene (1M triangles, 2048x2048): a 16x16 window at 32x16 = 512 spp."""
     crop = (0.5, 0.5 + 16 / 2048, 0.5, 0.5 + 16 / 2048)
