@@ -1,13 +1,13 @@
 // kernels.hip -- the CDNA4 (gfx950) kernels of the render path.
 //
-//   render_kernel    one 64-lane wavefront per 8x8 pixel tile (4 waves = one 16x16 FilmTile per
-//                    workgroup); every lane owns one pixel and walks its samples in order:
-//                    stratified camera sample -> BVH closest hit -> emission -> one-light direct
-//                    estimate (any-hit shadow ray) -> BSDF sample -> Russian roulette.  A lane
-//                    whose path ends regenerates its next camera sample at once, so the wave
-//                    stays full until the tile runs out of samples; `__ballot` decides the
-//                    wave-uniform exits.  Per-lane traversal stack in LDS, laid out
-//                    stack[level][lane] (conflict-free: lane l -> bank l).
+//   render_kernel    persistent one-wave workgroups (as many as the device holds at once); every lane draws a
+//                    pixel from the rank's pixel list (XCD-aware hand-out, one atomic per wave and round), keeps
+//                    it for all its samples, in order: stratified camera sample -> BVH closest hit -> emission
+//                    -> one-light direct estimate (any-hit shadow ray) -> BSDF sample -> Russian roulette; then
+//                    writes the film pixel and draws the next one.  The wave walks a quantised 4-wide BVH in a
+//                    "while-while" loop with parked leaves; `__ballot` + popcount take every scheduling decision
+//                    wave-uniformly.  Per-lane traversal stack in LDS, laid out stack[level][lane]
+//                    (conflict-free: lane l -> bank l); path state parked in coalesced HBM records.
 //   intersect_kernel the traversal loop alone over a ray batch (parity + roofline of the loop).
 //   pack_tris_kernel builds the leaf-ordered 48-byte triangle records from the uploaded
 //                    vertex / index buffers.
