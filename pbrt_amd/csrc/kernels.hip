@@ -263,6 +263,13 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
   T.cur = kDone;
   if (S.n_nodes) {  // the root is the one node whose box is not held by a parent
     if (EXACT) cn++;
+    // production walk: a ray that starts inside the root box needs no test (entering a node the ray might miss is
+    // always allowed in a superset walk), and bounce / shadow rays always do: the three divisions are skipped
+    if (!EXACT && o.x >= S.root_lo[0] && o.x <= S.root_hi[0] && o.y >= S.root_lo[1] && o.y <= S.root_hi[1] && o.z >= S.root_lo[2] &&
+        o.z <= S.root_hi[2]) {
+      trav_enter(T, !(S.root_ref & kLeafRef) ? 0u : S.root_ref);
+      return;
+    }
     const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     float tn;
     if (box_test(S.root_lo[0], S.root_lo[1], S.root_lo[2], S.root_hi[0], S.root_hi[1], S.root_hi[2], o, inv,
