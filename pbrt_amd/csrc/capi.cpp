@@ -181,12 +181,13 @@ struct QuadChild {
   uint32_t node;       // binary interior node to recurse into, or 0xffffffff
   uint32_t leaf_node;  // binary leaf to expand into its own quad node, or 0xffffffff
 };
-void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, QuadNodes *out) {
-  static const bool greedy = !(std::getenv("PBRT_HIP_GREEDY_COLLAPSE") && std::getenv("PBRT_HIP_GREEDY_COLLAPSE")[0] == '0');
+enum Collapse { kCollapsePlain = 0, kCollapseGreedy = 1, kCollapseDp = 2 };
+void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, Collapse how, QuadNodes *out) {
+  const bool greedy = how != kCollapsePlain;
   if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
   auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-  // Which descendants become the (up to four) children of a quad node?  Default: greedy (open the child with the
-  // largest surface area while the result fits four slots).  PBRT_HIP_COLLAPSE=dp instead minimises, by dynamic
+  // Which descendants become the (up to four) children of a quad node?  Greedy: open the child with the largest
+  // surface area while the result fits four slots.  Dp instead minimises, by dynamic
   // programming over the binary tree (after Ylitie, Karras, Laine 2017, section 3.2), the expected work of a walk:
   // every child of a quad node R is reached with the probability of its box AS R's 8-BIT GRID HOLDS IT (about one
   // cell of R wider per axis -- a small child of a large node gets a coarse box), a reached interior child costs one
@@ -199,7 +200,7 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
   // unconditional reach probabilities up to the common factor 1/A(root), as in the SAH).
   // Measured (c_tri = 2): C3 40.2 instead of 41.0 fetches per ray but a stack bound of 41 (overflow variant): -1 %;
   // C2 +2 %.  Without the quantisation term the same programme made 11.6 % fewer nodes and C3 6 % slower.
-  static const bool use_dp = greedy && std::getenv("PBRT_HIP_COLLAPSE") && std::strcmp(std::getenv("PBRT_HIP_COLLAPSE"), "dp") == 0;
+  const bool use_dp = how == kCollapseDp;
   static const float c_tri = std::getenv("PBRT_HIP_COLLAPSE_CTRI") ? (float)std::atof(std::getenv("PBRT_HIP_COLLAPSE_CTRI")) : 2.0f;
   const size_t nn = b.nodes.size();
   std::vector<float> F;            // F[(4 * n + (k - 1)) * 3 + (d - 1)]
@@ -438,6 +439,18 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
     q[2] = make_uint4(qhi[1], qhi[2], (ebyte[0] << 7) | (ebyte[1] << 23), ebyte[2] << 7);
     q[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
   }
+}
+
+// The tree the walk gets: the greedy collapse.  PBRT_HIP_COLLAPSE=dp|plain selects the others (PBRT_HIP_GREEDY_COLLAPSE=0
+// = plain).  Measured: dp is 1.5-2 % faster on C2, 1 % slower on C3 (its stack bound of 41 needs the overflow variant)
+// and 2.6 % slower on C4's 19-node tree, and its build takes 50 % longer: greedy stays the default.
+void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, QuadNodes *out) {
+  const char *c = std::getenv("PBRT_HIP_COLLAPSE");
+  const char *g = std::getenv("PBRT_HIP_GREEDY_COLLAPSE");
+  Collapse how = kCollapseGreedy;
+  if ((g && g[0] == '0') || (c && std::strcmp(c, "plain") == 0)) how = kCollapsePlain;
+  else if (c && std::strcmp(c, "dp") == 0) how = kCollapseDp;
+  make_quad_nodes_as(b, P, idx, split_leaves, how, out);
 }
 
 template <class T>
