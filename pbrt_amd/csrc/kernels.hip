@@ -448,7 +448,10 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     const bool parked = trav_parked(T);
     const unsigned long long mleaf = __ballot(parked);
     if (mleaf != 0ull &&
-        ((uint32_t)__popcll(mleaf) >= tune.min_parked || __ballot(T.cur != kDone && !parked) == 0ull)) {
+        ((uint32_t)__popcll(mleaf) >= tune.min_parked ||
+         // ... or when the parked lanes are at least half as many as the lanes that can still step (with few
+         // steppers left, waiting for min_parked only idles the parked ones; this also covers "nobody can step")
+         (uint32_t)__popcll(mleaf) * 2u >= (uint32_t)__popcll(__ballot(T.cur != kDone && !parked)))) {
       const uint32_t cnt = parked ? (T.cur >> 24) & 0x7fu : 0u, first = T.cur & 0xffffffu;
       bool stop = false;  // any-hit ray found its hit
       for (uint32_t i = 0;; i++) {
