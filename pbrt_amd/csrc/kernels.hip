@@ -309,7 +309,9 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     const bool walking = T.cur != kDone;
     const unsigned long long mwalk = __ballot(walking);
     if (mwalk == 0ull) break;
-    if ((uint32_t)__popcll(mwalk) < tune.min_walkers && __ballot(!walking && alive) != 0ull) break;
+    // (min_walkers is meant for a full wave: it scales with the lanes that still have work at all, so that a wave whose
+    // pixel list has run dry does not visit the service stage for every single ray)
+    if ((uint32_t)__popcll(mwalk) * 64u < tune.min_walkers * (uint32_t)__popcll(__ballot(alive)) && __ballot(!walking && alive) != 0ull) break;
 
     if (EXACT && walking && !trav_parked(T)) {
       // ---- one step: both children of interior node T.cur ----
