@@ -70,7 +70,7 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
 }
 // min_walkers: 36 for deep trees (long walks: C3 +1 % over 32), 20 for shallow ones, where a frame is mostly shading and
 // the shading stage should wait for more lanes (C4 +12 % over 36)
-constexpr uint32_t kMinWalkers = 36, kMinWalkersShallow = 20, kShallowStackNeed = 16, kMinParked = 12, kRenderWorkgroups = 4096;
+constexpr uint32_t kMinWalkers = 36, kMinWalkersShallow = 20, kShallowStackNeed = 16, kMinParked = 16, kRenderWorkgroups = 4096;
 // A frame is rendered in two launches (cost-ordered hand-out, render_device) when a pixel is long (>= this many
 // samples) and a lane renders few of them (< kTwoPhaseMaxPerLane): only then does the order of the tail matter.
 // PBRT_HIP_TWO_PHASE=0 / =1 forces one / two launches (tests, A-B runs).
