@@ -84,14 +84,24 @@ typedef struct {
 #define PBRT_HIP_FLAG_WALK_COUNTERS 2u /* count what the production kernel itself does instead: nodes_visited = 64-byte
                                         child-pair records fetched, tris_tested = triangles tested */
 
+#define PBRT_HIP_SAMPLER_STRATIFIED 0 /* Sampler "stratified" (north_star's sampler) */
+#define PBRT_HIP_SAMPLER_SOBOL 1      /* Sampler "sobol" / "halton" / "02sequence" / "lowdiscrepancy": the (0,2)-sequence
+                                         sampler of DESIGN.md 3.10 (the reference holds only the names, api.rs:235, and the
+                                         generator matrices, sobolmatrices.rs:81) */
+#define PBRT_HIP_MAX_SPP (1u << 20)   /* spp_x * spp_y: the kernels pack the sample index into 20 bits */
+#define PBRT_HIP_MAX_DEPTH 1023u      /* max_depth: the bounce count is packed into 10 bits */
+
 typedef struct {
   uint32_t integrator;
-  uint32_t max_depth;        /* Integrator "integer maxdepth" */
-  uint32_t spp_x, spp_y;     /* Sampler "stratified": pixelsamples = spp_x * spp_y */
+  uint32_t max_depth;        /* Integrator "integer maxdepth" (<= PBRT_HIP_MAX_DEPTH, else PBRT_HIP_ERR_LIMIT) */
+  uint32_t spp_x, spp_y;     /* Sampler "stratified": pixelsamples = spp_x * spp_y (<= PBRT_HIP_MAX_SPP, else PBRT_HIP_ERR_LIMIT) */
   uint64_t seed;
   uint32_t rank, world_size; /* this process renders the 64x64 super-tiles t with t % world_size == rank */
   uint32_t flags;
-  uint32_t pad;
+  uint32_t sampler;          /* PBRT_HIP_SAMPLER_* */
+  float filter_xwidth, filter_ywidth; /* PixelFilter "box" "float xwidth" / "ywidth" (box.rs:57-61).  0 = the default 0.5.
+                                         Only 0.5 is implemented (a sample lands in its own pixel, film.rs:264-273 needs no
+                                         tile overlap); any other radius is refused with PBRT_HIP_ERR_LIMIT */
 } pbrt_hip_render_desc;
 
 typedef struct {
@@ -199,6 +209,9 @@ void pbrt_hip_loaded_free(pbrt_hip_loaded *loaded);
 /* desc / render are filled with pointers INTO `loaded` (valid until it is freed); filename = Film "string filename" */
 int pbrt_hip_loaded_get(const pbrt_hip_loaded *loaded, pbrt_hip_scene_desc *desc, pbrt_hip_render_desc *render,
                         char *filename, size_t filename_cap);
+/* Film "float scale" (film.rs:368-371: every pixel is multiplied by it in Film::write_image): pass it to
+ * pbrt_hip_film_to_rgb.  1 for a NULL handle. */
+float pbrt_hip_loaded_film_scale(const pbrt_hip_loaded *loaded);
 /* warnings (ignored directives / parameters, api.rs:291-332 "log and continue"), '\n'-separated; returns their count */
 int pbrt_hip_loaded_warnings(const pbrt_hip_loaded *loaded, char *buf, size_t cap);
 /* CTM (current_transform[0].m) when parsing stopped, and the directive names stored by the option setters

@@ -33,7 +33,7 @@ class RenderDesc(C.Structure):
     _fields_ = [
         ("integrator", C.c_uint32), ("max_depth", C.c_uint32), ("spp_x", C.c_uint32), ("spp_y", C.c_uint32),
         ("seed", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32), ("flags", C.c_uint32),
-        ("pad", C.c_uint32),
+        ("sampler", C.c_uint32), ("filter_xwidth", C.c_float), ("filter_ywidth", C.c_float),
     ]
 
 
@@ -81,6 +81,7 @@ SYMBOLS = {
     "pbrt_hip_load_string": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.POINTER(_vp)]),
     "pbrt_hip_loaded_free": (None, [_vp]),
     "pbrt_hip_loaded_get": (C.c_int, [_vp, C.POINTER(SceneDesc), C.POINTER(RenderDesc), C.c_char_p, C.c_size_t]),
+    "pbrt_hip_loaded_film_scale": (_f, [_vp]),
     "pbrt_hip_loaded_warnings": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "pbrt_hip_loaded_state": (C.c_int, [_vp, _pf, C.c_char_p, C.c_size_t]),
     "pbrt_hip_tokenize": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),

@@ -97,9 +97,14 @@ def fill_desc(desc, sd, mat_t, light_t, sphere_t):
     return [mats, lights, spheres, sd]
 
 
+SAMPLERS = {"stratified": 0, "sobol": 1}
+
+
 def make_render_desc(desc_t, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
-                     flags=0):
+                     flags=0, sampler="stratified", filter_width=(0.0, 0.0)):
     r = desc_t()
+    r.sampler = SAMPLERS[sampler] if isinstance(sampler, str) else int(sampler)
+    r.filter_xwidth, r.filter_ywidth = float(filter_width[0]), float(filter_width[1])
     r.integrator = integrator
     r.max_depth = max_depth
     r.spp_x, r.spp_y = int(spp[0]), int(spp[1])
@@ -264,11 +269,12 @@ class Scene:
         return nodes[:i["n_nodes"]], order[:self.sd.idx.shape[0]]
 
     def render(self, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
-               counters=False):
+               counters=False, **kw):
         """-> (film[h, w, 4] float32 {X, Y, Z, weight}, stats dict).  counters: False, True (canonical
-        walk, equal to the oracle's counters) or "walk" (what the production kernel itself fetches / tests)."""
+        walk, equal to the oracle's counters) or "walk" (what the production kernel itself fetches / tests).
+        kw: sampler="stratified"|"sobol", filter_width=(xw, yw)."""
         r = make_render_desc(RenderDesc, integrator, max_depth, spp, seed, rank, world_size,
-                             FLAG_WALK_COUNTERS if counters == "walk" else (FLAG_COUNTERS if counters else 0))
+                             FLAG_WALK_COUNTERS if counters == "walk" else (FLAG_COUNTERS if counters else 0), **kw)
         w, h = self.sd.crop_size()
         film = np.zeros((h, w, 4), np.float32)
         st = Stats()

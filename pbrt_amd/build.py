@@ -10,7 +10,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_DIR = os.path.join(HERE, "lib")
+# PBRT_HIP_LIB_DIR: build / load a variant of the library elsewhere in the tree (A-B experiments, tools/ab_variants.sh)
+LIB_DIR = os.path.abspath(os.environ.get("PBRT_HIP_LIB_DIR") or os.path.join(HERE, "lib"))
 LIB_PATH = os.path.join(LIB_DIR, "libpbrt_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "pbrt")  # the C++ command line (csrc/pbrt_main.cpp)
 SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip", "pixel_order.hip", "bvh_gpu.hip"]

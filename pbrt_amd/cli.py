@@ -47,7 +47,7 @@ def main(argv=None):
         t0 = time.time()
         with api.Scene(sd) as sc:
             film, st = sc.render(**kw)
-        rgb = api.film_to_rgb(film)
+        rgb = api.film_to_rgb(film, scale=ls.film_scale)  # Film::write_image multiplies by Film "scale" (film.rs:368-371)
         out = args.outfile or ls.filename
         if not os.path.splitext(out)[1]:
             out += ".png"

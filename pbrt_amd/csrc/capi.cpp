@@ -63,14 +63,17 @@ Shard make_shard(int32_t xres, int32_t yres, const float crop[4], uint32_t rank,
 // are interleaved, never a result; PBRT_HIP_MIN_WALKERS / PBRT_HIP_MIN_PARKED override them for
 // tuning runs.
 uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
-  const char *v = std::getenv(name);
+  const char *v = debug_knob(name);
   if (!v || !*v) return dflt;
   long x = std::strtol(v, nullptr, 10);
   return x < 0 ? 0u : (x > cap ? (uint32_t)cap : (uint32_t)x);
 }
 // min_walkers: 36 for deep trees (long walks: C3 +1 % over 32), 20 for shallow ones, where a frame is mostly shading and
 // the shading stage should wait for more lanes (C4 +12 % over 36)
-constexpr uint32_t kMinWalkers = 36, kMinWalkersShallow = 20, kShallowStackNeed = 16, kMinParked = 16, kRenderWorkgroups = 4096;
+constexpr uint32_t kMinWalkers = 36, kMinWalkersShallow = 20, kShallowStackNeed = 16, kMinParked = 16;
+// persistent one-wave workgroups of the render kernel per CU: what a CU holds at once (4 SIMDs x 4 waves; the 10 KB LDS
+// stack and the 128-VGPR budget both allow exactly that); the grid is this x the device's CU count (hipDeviceProp_t)
+constexpr uint32_t kRenderWavesPerCu = 16;
 // A frame is rendered in two launches (cost-ordered hand-out, render_device) when a pixel is long (>= this many
 // samples) and a lane renders few of them (< kTwoPhaseMaxPerLane): only then does the order of the tail matter.
 // PBRT_HIP_TWO_PHASE=0 / =1 forces one / two launches (tests, A-B runs).
@@ -107,7 +110,7 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
   // each other in depth-first order.  PBRT_HIP_NODE_LAYOUT=dfs restores plain depth-first numbering.
   std::vector<uint32_t> interior_index(n, 0);
   uint32_t n_int = 0;
-  const char *layout = std::getenv("PBRT_HIP_NODE_LAYOUT");
+  const char *layout = debug_knob("PBRT_HIP_NODE_LAYOUT");
   if (layout && std::string(layout) == "dfs") {
     for (size_t i = 0; i < n; i++)
       if ((b.nodes[i].count_axis & 0xffffu) == 0) interior_index[i] = n_int++;
@@ -201,7 +204,7 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
   // Measured (c_tri = 2): C3 40.2 instead of 41.0 fetches per ray but a stack bound of 41 (overflow variant): -1 %;
   // C2 +2 %.  Without the quantisation term the same programme made 11.6 % fewer nodes and C3 6 % slower.
   const bool use_dp = how == kCollapseDp;
-  static const float c_tri = std::getenv("PBRT_HIP_COLLAPSE_CTRI") ? (float)std::atof(std::getenv("PBRT_HIP_COLLAPSE_CTRI")) : 2.0f;
+  static const float c_tri = debug_knob("PBRT_HIP_COLLAPSE_CTRI") ? (float)std::atof(debug_knob("PBRT_HIP_COLLAPSE_CTRI")) : 2.0f;
   const size_t nn = b.nodes.size();
   std::vector<float> F;            // F[(4 * n + (k - 1)) * 3 + (d - 1)]
   std::vector<float> G;            // work below n as a quad node of its own (interior nodes and splittable leaves)
@@ -445,8 +448,8 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
 // = plain).  Measured: dp is 1.5-2 % faster on C2, 1 % slower on C3 (its stack bound of 41 needs the overflow variant)
 // and 2.6 % slower on C4's 19-node tree, and its build takes 50 % longer: greedy stays the default.
 void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, QuadNodes *out) {
-  const char *c = std::getenv("PBRT_HIP_COLLAPSE");
-  const char *g = std::getenv("PBRT_HIP_GREEDY_COLLAPSE");
+  const char *c = debug_knob("PBRT_HIP_COLLAPSE");
+  const char *g = debug_knob("PBRT_HIP_GREEDY_COLLAPSE");
   Collapse how = kCollapseGreedy;
   if ((g && g[0] == '0') || (c && std::strcmp(c, "plain") == 0)) how = kCollapsePlain;
   else if (c && std::strcmp(c, "dp") == 0) how = kCollapseDp;
@@ -473,6 +476,7 @@ struct DevBuf {
 
 struct pbrt_hip_scene {
   int device = 0;
+  uint32_t n_cu = 256;  // hipDeviceProp_t::multiProcessorCount of `device`
   pbrt_hip_scene_desc desc{};  // scalar fields only; pointers are cleared
   Bvh bvh;
   uint32_t n_lights = 0;
@@ -603,6 +607,11 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
 
     std::unique_ptr<pbrt_hip_scene> s(new pbrt_hip_scene());
     s->device = device;
+    {
+      int cus = 0;
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+      s->n_cu = cus > 0 ? (uint32_t)cus : 1u;
+    }
     s->desc = *d;
     s->desc.P = nullptr; s->desc.idx = nullptr; s->desc.mat_id = nullptr;
     s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
@@ -680,7 +689,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     QuadNodes quads;
     if (!s->gpu_built) {
       const auto t0 = std::chrono::steady_clock::now();
-      const char *sl = std::getenv("PBRT_HIP_SPLIT_LEAVES");
+      const char *sl = debug_knob("PBRT_HIP_SPLIT_LEAVES");
       make_quad_nodes(s->bvh, d->P, d->idx, !(sl && sl[0] == '0'), &quads);
       s->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -821,6 +830,15 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (r->spp_x == 0 || r->spp_y == 0) return fail(PBRT_HIP_ERR_INVALID, "render: spp_x and spp_y must be >= 1");
   if (r->world_size == 0 || r->rank >= r->world_size) return fail(PBRT_HIP_ERR_INVALID, "render: rank must be < world_size");
   if (r->integrator > 1) return fail(PBRT_HIP_ERR_INVALID, "render: unknown integrator");
+  if (r->sampler > PBRT_HIP_SAMPLER_SOBOL) return fail(PBRT_HIP_ERR_INVALID, "render: unknown sampler");
+  // the kernels pack the sample index into 20 bits and the bounce count into 10 (kernels.hip path_store): beyond that a
+  // persistent wave would never see its pixel finish
+  if ((uint64_t)r->spp_x * (uint64_t)r->spp_y > PBRT_HIP_MAX_SPP)
+    return fail(PBRT_HIP_ERR_LIMIT, "render: more than 2^20 samples per pixel");
+  if (r->max_depth > PBRT_HIP_MAX_DEPTH) return fail(PBRT_HIP_ERR_LIMIT, "render: maxdepth above 1023");
+  // box filter, box.rs:57-61: only the default radius (a sample lands in its own pixel; film.rs:264-273's tile overlap is 0)
+  const float fx = r->filter_xwidth == 0.f ? 0.5f : r->filter_xwidth, fy = r->filter_ywidth == 0.f ? 0.5f : r->filter_ywidth;
+  if (fx != 0.5f || fy != 0.5f) return fail(PBRT_HIP_ERR_LIMIT, "render: only the box filter of radius 0.5 is implemented");
   return PBRT_HIP_OK;
 }
 
@@ -828,6 +846,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
   int rc = check_render_desc(s, r);
   if (rc) return rc;
   try {
+    // the events, counters and lane-state records of a scene serve one render at a time
+    if (s->pending) return fail(PBRT_HIP_ERR_INVALID, "render_device: a render of this scene is still in flight (call pbrt_hip_render_wait first)");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
     const Shard sh = make_shard(s->desc.xres, s->desc.yres, s->desc.crop, r->rank, r->world_size);
@@ -847,7 +867,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once
     // (256 CUs x 16: the LDS stack allows 4 per SIMD), each lane drawing pixel after pixel from the rank's list.
     R.n_pixels = sh.n_local * 4096u;
-    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", kRenderWorkgroups, 1 << 20)));
+    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * kRenderWavesPerCu, 1 << 20)));
     R.next_pixel = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
     {
@@ -877,7 +897,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     // the unordered tail cost 30 %).  Scheduling only: every pixel still sees its samples in order.
     const uint32_t spp = r->spp_x * r->spp_y;
     const uint32_t per_lane = std::max<uint32_t>(1u, R.n_pixels / std::max<uint32_t>(1u, R.n_workgroups * 64u));  // (a rank may own no tile at all)
-    const char *tp = std::getenv("PBRT_HIP_TWO_PHASE");
+    const char *tp = debug_knob("PBRT_HIP_TWO_PHASE");
     bool two = spp >= kTwoPhaseMinSpp && per_lane < kTwoPhaseMaxPerLane;
     if (tp && tp[0] == '0') two = false;
     if (tp && tp[0] == '1' && spp >= 2u) two = true;
@@ -977,9 +997,14 @@ int pbrt_hip_render(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, float *fil
   rc = pbrt_hip_render_device(s, r, s->d_slab.p, s->stream);
   if (rc) return rc;
   rc = pbrt_hip_film_assemble_device(s, s->d_slab.p, r->rank, r->world_size, s->d_film.p, s->stream);
-  if (rc) return rc;
-  if (n_px) HIP_TRY(hipMemcpyAsync(film, s->d_film.p, n_px * 16, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  hipError_t e = hipSuccess;
+  if (!rc && n_px) e = hipMemcpyAsync(film, s->d_film.p, n_px * 16, hipMemcpyDeviceToHost, s->stream);
+  const hipError_t e2 = hipStreamSynchronize(s->stream);  // (also on failure: the scene must not stay "in flight")
+  if (rc || e != hipSuccess || e2 != hipSuccess) {
+    s->pending = false;
+    if (rc) return rc;
+    return fail(PBRT_HIP_ERR_HIP, std::string("render: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  }
   return pbrt_hip_render_wait(s, stats);
 }
 
@@ -1061,7 +1086,7 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
     B.stack_overflow = s->d_stack_overflow.p;
     B.stack_overflow_entries = extra;
   }
-  const bool timed = std::getenv("PBRT_HIP_TIME_INTERSECT") != nullptr;  // tuning aid: kernel time to stderr
+  const bool timed = debug_knob("PBRT_HIP_TIME_INTERSECT") != nullptr;  // tuning aid: kernel time to stderr
   if (timed) RB_TRY(hipEventRecord(s->ev0, s->stream));
   RB_TRY(launch_intersect(s->dev, B, any, s->bvh.depth, s->stream));
   if (timed) {
@@ -1204,17 +1229,24 @@ int pbrt_hip_load_string(const char *text, size_t len, const char *base_dir, pbr
 
 int pbrt_hip_load_file(const char *path, pbrt_hip_loaded **out) {
   if (!path || !out) return fail(PBRT_HIP_ERR_INVALID, "load_file: null argument");
+  *out = nullptr;
   FILE *f = std::fopen(path, "rb");
   if (!f) return fail(PBRT_HIP_ERR_INVALID, std::string("Io: cannot open '") + path + "'");  // api.rs:392-395
-  std::string text;
-  char buf[65536];
-  size_t n;
-  while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
-  std::fclose(f);
-  std::string p(path);
-  size_t slash = p.rfind('/');
-  std::string dir = slash == std::string::npos ? "" : p.substr(0, slash);
-  return pbrt_hip_load_string(text.data(), text.size(), dir.c_str(), out);
+  try {
+    std::string text;
+    char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    std::fclose(f);
+    f = nullptr;
+    std::string p(path);
+    size_t slash = p.rfind('/');
+    std::string dir = slash == std::string::npos ? "" : p.substr(0, slash);
+    return pbrt_hip_load_string(text.data(), text.size(), dir.c_str(), out);
+  } catch (const std::exception &e) {
+    if (f) std::fclose(f);
+    return fail(PBRT_HIP_ERR_INTERNAL, e.what());
+  }
 }
 
 void pbrt_hip_loaded_free(pbrt_hip_loaded *l) { delete l; }
@@ -1237,10 +1269,14 @@ int pbrt_hip_loaded_get(const pbrt_hip_loaded *l, pbrt_hip_scene_desc *d, pbrt_h
     std::memset(r, 0, sizeof *r);
     r->integrator = s.integrator; r->max_depth = s.max_depth; r->spp_x = s.spp_x; r->spp_y = s.spp_y;
     r->seed = 0; r->rank = 0; r->world_size = 1;
+    r->sampler = s.sampler;
+    r->filter_xwidth = s.filter_radius[0]; r->filter_ywidth = s.filter_radius[1];
   }
   copy_out(s.filename, filename, cap);
   return PBRT_HIP_OK;
 }
+
+float pbrt_hip_loaded_film_scale(const pbrt_hip_loaded *l) { return l ? l->s.film_scale : 1.f; }
 
 int pbrt_hip_loaded_warnings(const pbrt_hip_loaded *l, char *buf, size_t cap) {
   if (!l) return 0;

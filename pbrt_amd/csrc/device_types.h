@@ -14,7 +14,17 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace pbrt_hip {
+
+// Tuning / A-B knobs (PBRT_HIP_MIN_WALKERS, PBRT_HIP_TWO_PHASE, PBRT_HIP_COLLAPSE, ...) are read from the environment
+// only when PBRT_HIP_DEBUG_KNOBS is set (to anything but "0"): a production process is not steered by stray variables.
+inline const char *debug_knob(const char *name) {
+  const char *on = std::getenv("PBRT_HIP_DEBUG_KNOBS");
+  if (!on || !*on || (on[0] == '0' && !on[1])) return nullptr;
+  return std::getenv(name);
+}
 
 #ifndef PBRT_QUAD_LDS_STACK
 #define PBRT_QUAD_LDS_STACK 40

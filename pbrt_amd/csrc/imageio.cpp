@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -92,12 +93,14 @@ bool write_pfm(const char *name, const float *rgb, int w, int h) {
 // PFM, imageio.rs:87-140: header words "PF"|"Pf", width, height, scale separated by ' ', '\n' or '\t';
 // scale < 0 = little-endian floats, |scale| multiplies; rows bottom to top; 1-channel images are
 // replicated to RGB (RGBSpectrum::new(f), imageio.rs:129-133).
+constexpr uint64_t kMaxImagePixels = 1ull << 28;  // 16384 x 16384: 3 GiB of float RGB; anything larger is refused
 bool read_word(FILE *f, std::string *w) {
   w->clear();
   for (;;) {
     int c = std::fgetc(f);
     if (c == EOF) return false;
     if (c == ' ' || c == '\n' || c == '\t') return true;
+    if (w->size() >= 64) return false;  // no header word is that long
     w->push_back((char)c);
   }
 }
@@ -112,6 +115,17 @@ bool read_pfm(const char *name, std::vector<float> *rgb, int *w, int *h) {
   *h = std::atoi(sh.c_str());
   const float scale = (float)std::atof(ss.c_str());
   if (*w <= 0 || *h <= 0 || scale == 0.f) { std::fclose(f); return false; }
+  // the header is untrusted: the pixel data it announces must actually be in the file before anything is allocated
+  if ((uint64_t)*w * (uint64_t)*h > kMaxImagePixels) { std::fclose(f); return false; }
+  {
+    const long at = std::ftell(f);
+    if (at < 0 || std::fseek(f, 0, SEEK_END) != 0) { std::fclose(f); return false; }
+    const long end = std::ftell(f);
+    if (end < at || (uint64_t)(end - at) < (uint64_t)*w * (uint64_t)*h * (uint64_t)nc * 4u || std::fseek(f, at, SEEK_SET) != 0) {
+      std::fclose(f);
+      return false;
+    }
+  }
   const bool file_le = scale < 0.f;
   const float mag = scale < 0.f ? -scale : scale;
   const uint16_t probe = 0x1234;
@@ -142,6 +156,7 @@ struct Inflater {
   uint32_t bitbuf = 0;
   int bitcnt = 0;
   std::vector<uint8_t> out;
+  size_t out_cap = ~(size_t)0;  // the caller knows how many bytes the image needs: more is a decompression bomb
   bool bad = false;
   int bits(int need) {
     uint32_t v = bitbuf;
@@ -187,7 +202,7 @@ struct Inflater {
     for (;;) {
       int sym = decode(lc);
       if (bad) return false;
-      if (sym < 256) out.push_back((uint8_t)sym);
+      if (sym < 256) { if (out.size() >= out_cap) return false; out.push_back((uint8_t)sym); }
       else if (sym == 256) return true;
       else {
         sym -= 257;
@@ -196,7 +211,7 @@ struct Inflater {
         const int ds = decode(dc);
         if (bad || ds < 0 || ds >= 30) return false;
         const size_t dist = dbase[ds] + (size_t)bits(dext[ds]);
-        if (bad || dist > out.size()) return false;
+        if (bad || dist > out.size() || out.size() + (size_t)len > out_cap) return false;
         for (int i = 0; i < len; i++) out.push_back(out[out.size() - dist]);
       }
     }
@@ -212,7 +227,7 @@ struct Inflater {
         if (pos + 4 > n) return false;
         const unsigned len = in[pos] | (in[pos + 1] << 8), nlen = in[pos + 2] | (in[pos + 3] << 8);
         pos += 4;
-        if ((len ^ 0xffffu) != nlen || pos + len > n) return false;
+        if ((len ^ 0xffffu) != nlen || pos + len > n || out.size() + len > out_cap) return false;
         out.insert(out.end(), in + pos, in + pos + len);
         pos += len;
       } else if (type == 1) {
@@ -293,11 +308,13 @@ bool read_png(const char *name, std::vector<float> *rgb, int *w, int *h) {
   }
   const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (depth != 8 || ch == 0 || interlace != 0 || *w <= 0 || *h <= 0 || z.size() < 6) return false;
+  if ((uint64_t)*w * (uint64_t)*h > kMaxImagePixels) return false;
+  const size_t stride = (size_t)*w * ch;
   Inflater inf;
   inf.in = z.data() + 2;  // zlib header
   inf.n = z.size() - 2;
+  inf.out_cap = (stride + 1) * (size_t)*h;
   if (!inf.run()) return false;
-  const size_t stride = (size_t)*w * ch;
   if (inf.out.size() < (stride + 1) * (size_t)*h) return false;
   std::vector<uint8_t> img(stride * (size_t)*h);
   for (int y = 0; y < *h; y++) {
@@ -329,6 +346,7 @@ bool read_png(const char *name, std::vector<float> *rgb, int *w, int *h) {
 // imageio::read_image: two calls, the first with rgb == NULL returns the size
 extern "C" int pbrt_hip_read_image(const char *name, float *rgb, int32_t *width, int32_t *height) {
   if (!name || !width || !height) return PBRT_HIP_ERR_INVALID;
+  try {
   std::string n(name);
   size_t dot = n.rfind('.');
   std::string ext = dot == std::string::npos ? "" : n.substr(dot + 1);
@@ -347,10 +365,15 @@ extern "C" int pbrt_hip_read_image(const char *name, float *rgb, int32_t *width,
   *width = w;
   *height = h;
   return PBRT_HIP_OK;
+  } catch (const std::exception &) {  // std::bad_alloc and friends never cross the C ABI
+    return PBRT_HIP_ERR_INTERNAL;
+  }
 }
 
 extern "C" int pbrt_hip_write_image(const char *name, const float *rgb, int32_t width, int32_t height) {
   if (!name || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
+  if ((uint64_t)width * (uint64_t)height > kMaxImagePixels) return PBRT_HIP_ERR_LIMIT;
+  try {
   std::string n(name);
   size_t dot = n.rfind('.');
   std::string ext = dot == std::string::npos ? "" : n.substr(dot + 1);
@@ -358,4 +381,7 @@ extern "C" int pbrt_hip_write_image(const char *name, const float *rgb, int32_t 
   if (ext == "png") return write_png(name, rgb, width, height) ? PBRT_HIP_OK : PBRT_HIP_ERR_INTERNAL;
   if (ext == "pfm") return write_pfm(name, rgb, width, height) ? PBRT_HIP_OK : PBRT_HIP_ERR_INTERNAL;
   return PBRT_HIP_ERR_INVALID;  // imageio.rs:272-280: exr / tga unimplemented, unknown extension
+  } catch (const std::exception &) {
+    return PBRT_HIP_ERR_INTERNAL;
+  }
 }

@@ -168,13 +168,21 @@ __device__ __forceinline__ bool sphere_hit(const DevScene &S, uint32_t s, V3 o, 
 constexpr uint32_t kDone = 0xffffffffu;
 constexpr uint32_t kLeafRef = 0x80000000u;  // ref = kLeafRef | n_prims << 24 | first slot (n_prims <= 64)
 
+// The production walk addresses its LDS stack by 32-bit LDS byte addresses kept in a register (one v_add per push, no
+// shift / or to form an address: tools/ubench/valu_issue.hip shows v_lshl_or_b32 and friends issue at half rate).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) { return (uint32_t)(uintptr_t)(const lds_u32 *)p; }
+__device__ __forceinline__ void lds_store(uint32_t a, uint32_t v) { *(lds_u32 *)(uintptr_t)a = v; }
+__device__ __forceinline__ uint32_t lds_load(uint32_t a) { return *(const lds_u32 *)(uintptr_t)a; }
+constexpr uint32_t kRowBytes = 256u;  // one stack row = 64 lanes x 4 bytes: consecutive entries of a lane are one row apart
+
 // Per-lane traversal state.  It lives in registers across iterations of the kernels' outer loops,
 // so a lane can be suspended in the middle of a walk while other lanes of the wave are served.
 struct Trav {
   V3 o, d;
   float tmax;
   uint32_t cur;       // ref to process next: interior = step, leaf = the lane is PARKED there; kDone = walk over
-  uint32_t sp;        // LDS stack entries in use
+  uint32_t sp;        // exact walk: stack entries in use; production walk: LDS byte address of the lane's first free entry
   uint32_t any;       // any-hit (shadow) ray
   uint32_t occluded;  // any-hit result
   HitRec h;           // closest-hit result
@@ -215,19 +223,25 @@ __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt
     }
     return kDone;
   }
-  if (T.sp == 0u) return kDone;
-  T.sp--;
-  if (!OVF) return stk[T.sp * 64u];
-  return T.sp < kQuadLdsEntries ? stk[T.sp * 64u] : ovf[(T.sp - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)];
+  // production walk: entry 0 is the sentinel kDone (trav_begin), so a pop needs no emptiness test
+  T.sp -= kRowBytes;
+  if (!OVF) return lds_load(T.sp);
+  const uint32_t e = (T.sp - lds_addr(stk)) / kRowBytes;
+  return e < kQuadLdsEntries ? lds_load(T.sp) : ovf[(e - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)];
 }
 // production walk: the LDS part of a lane's stack has kQuadLdsStack rows = kQuadLdsEntries entries (the
 // sentinel first) + one scratch row, which the branch-free pushes below write when they do not push.  Only for
 // trees whose worst-case bound exceeds that (OVF) do the deeper entries go to a per-lane HBM area.
 template <bool OVF>
 __device__ __forceinline__ void trav_push(Trav &T, uint32_t *stk, uint32_t *ovf, uint32_t ref) {
-  if (!OVF || T.sp < kQuadLdsEntries) stk[T.sp * 64u] = ref;
-  else ovf[(T.sp - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)] = ref;
-  T.sp++;
+  if (!OVF) {
+    lds_store(T.sp, ref);
+  } else {
+    const uint32_t e = (T.sp - lds_addr(stk)) / kRowBytes;
+    if (e < kQuadLdsEntries) lds_store(T.sp, ref);
+    else ovf[(e - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)] = ref;
+  }
+  T.sp += kRowBytes;
 }
 
 __device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) { T.cur = ref; }
@@ -249,8 +263,8 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
   T.tmax = tmax;
   T.sp = 0;
   if (!EXACT) {  // production walk: entry 0 is a sentinel, so that popping needs no emptiness test
-    stk[0] = kDone;
-    T.sp = 1;
+    lds_store(lds_addr(stk), kDone);
+    T.sp = lds_addr(stk) + kRowBytes;
   }
   T.any = any ? 1u : 0u;
   T.occluded = 0;
@@ -372,6 +386,14 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       if (COUNT) cn++;  // one 64-byte fetch
       T.work++;
       const float tfar = fminf(T.h.t, T.tmax);
+#ifdef PBRT_EXTRA_VALU  // A-B experiment: PBRT_EXTRA_VALU extra independent VALU instructions per node step
+      {
+        float x0 = __uint_as_float(W0.x), x1 = __uint_as_float(W0.y);
+#pragma unroll
+        for (int k = 0; k < PBRT_EXTRA_VALU / 2; k++) asm volatile("v_fma_f32 %0, %0, %2, %2\n\tv_fma_f32 %1, %1, %2, %2" : "+v"(x0), "+v"(x1) : "v"(tfar));
+        if (x0 == 1.2345f && x1 == 5.4321f) T.tmax = 0.f;
+      }
+#endif
       // Node-relative slab test.  A decoded plane is the REAL number origin + q * cell (the builder
       // checks in exact arithmetic that these planes enclose the true box), so
       //     t = (origin + q*cell - o) * inv = q * (cell*inv) - (o - origin)*inv = fma(q, ci, -gi):
@@ -416,7 +438,8 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
 #pragma unroll
       for (int k = 0; k < 4; k++) key[k] = hit[k] ? key[k] : kInf;
       // The nearest child hit is entered, the other hit ones are stacked in slot order.  Order affects only
-      // speed (tie rule of 3.4); sorting the stacked ones cost more than it saved.
+      // speed (tie rule of 3.4) -- but a lot: visiting the hit children in slot order alone costs C3 49 node steps per
+      // ray instead of 41 (measured, r02), and sorting the stacked ones cost more than it saved (r01).
       const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
       const bool n0 = key[0] == kmin, n1 = !n0 && key[1] == kmin, n2 = !n0 && !n1 && key[2] == kmin;
       const bool n3 = !n0 && !n1 && !n2;
@@ -425,7 +448,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // OVF (trees whose worst-case stack bound exceeds the LDS part): one wave-uniform test per step -- is any lane
       // within four entries of the end of its LDS part? -- picks the slow form with predicated pushes that spill
       // to HBM; stacks rarely get that deep, so nearly every step takes the branch-free form below.
-      if (OVF && __ballot(T.sp + 4u > kQuadLdsEntries) != 0ull) {
+      if (OVF && __ballot(T.sp + 4u * kRowBytes > lds_addr(stk) + kQuadLdsEntries * kRowBytes) != 0ull) {
         if (hit[3] && !n3) trav_push<true>(T, stk, ovf, W3.w);
         if (hit[2] && !n2) trav_push<true>(T, stk, ovf, W3.z);
         if (hit[1] && !n1) trav_push<true>(T, stk, ovf, W3.y);
@@ -433,14 +456,15 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         trav_enter(T, any_hit ? nearest : trav_pop<false, true>(T, stk, stkt, ovf, cn));
       } else {
         // branch-free: each ref is written above the stack top in any case (one LDS row beyond the entries is
-        // scratch) and the top advances by the hit mask; entry 0 is the sentinel kDone, so T.sp >= 1 while the
-        // lane walks and the top can be read in any case
-        stk[T.sp * 64u] = W3.w; T.sp += (hit[3] && !n3) ? 1u : 0u;
-        stk[T.sp * 64u] = W3.z; T.sp += (hit[2] && !n2) ? 1u : 0u;
-        stk[T.sp * 64u] = W3.y; T.sp += (hit[1] && !n1) ? 1u : 0u;
-        stk[T.sp * 64u] = W3.x; T.sp += (hit[0] && !n0) ? 1u : 0u;
-        const uint32_t top = stk[(T.sp - 1u) * 64u];
-        T.sp -= any_hit ? 0u : 1u;
+        // scratch) and the top advances by the hit mask; entry 0 is the sentinel kDone, so the entry below the top
+        // can be read in any case.  T.sp is the LDS ADDRESS of the top: a push is one ds_write + one v_add, no
+        // address arithmetic (v_lshl_or_b32 and the other three-operand integer forms issue at half rate on gfx950).
+        lds_store(T.sp, W3.w); T.sp += (hit[3] && !n3) ? kRowBytes : 0u;
+        lds_store(T.sp, W3.z); T.sp += (hit[2] && !n2) ? kRowBytes : 0u;
+        lds_store(T.sp, W3.y); T.sp += (hit[1] && !n1) ? kRowBytes : 0u;
+        lds_store(T.sp, W3.x); T.sp += (hit[0] && !n0) ? kRowBytes : 0u;
+        const uint32_t top = lds_load(T.sp - kRowBytes);
+        T.sp -= any_hit ? 0u : kRowBytes;
         trav_enter(T, any_hit ? nearest : top);
       }
     }
@@ -1075,7 +1099,7 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
   if (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
     // node steps per scheduling check: 3 for deep trees (C3 +1 %, C2 +2 % over 2), 2 for shallow ones whose walks
     // are a few steps long (C4: 3 would cost 5 %)
-    static const bool force_ovf = std::getenv("PBRT_HIP_FORCE_OVERFLOW_VARIANT") != nullptr;  // A-B runs
+    static const bool force_ovf = debug_knob("PBRT_HIP_FORCE_OVERFLOW_VARIANT") != nullptr;  // A-B runs
     if (S.quad_stack_need + 2u > kQuadLdsStack || force_ovf) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
     else if (!COUNT && S.quad_stack_need <= 16u) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0, 2>), grid, block, 0, st, S, R);
     else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, 0, st, S, R);

@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
     pbrt_hip_render_desc rd;
     char filename[4096];
     pbrt_hip_loaded_get(loaded, &desc, &rd, filename, sizeof filename);
+    const float film_scale = pbrt_hip_loaded_film_scale(loaded);  // Film "float scale", applied by Film::write_image (film.rs:368-371)
     if (quick) {
       rd.spp_x = rd.spp_x > 1 ? rd.spp_x / 2 : 1;
       rd.spp_y = rd.spp_y > 1 ? rd.spp_y / 2 : 1;
@@ -87,7 +88,7 @@ int main(int argc, char **argv) {
     rc = pbrt_hip_render(scene, &rd, film.data(), &st);
     pbrt_hip_scene_destroy(scene);
     if (rc != 0) { logf(1, "%s: %s", path.c_str(), pbrt_hip_last_error()); return 1; }
-    pbrt_hip_film_to_rgb(film.data(), (int64_t)w * h, 1.f, rgb.data());  // Film::write_image, film.rs:340-372
+    pbrt_hip_film_to_rgb(film.data(), (int64_t)w * h, film_scale, rgb.data());  // Film::write_image, film.rs:340-372
     std::string out = outfile.empty() ? filename : outfile;
     if (out.rfind('.') == std::string::npos || out.rfind('.') < out.rfind('/') + 1) out += ".png";
     if (pbrt_hip_write_image(out.c_str(), rgb.data(), w, h) != 0) { logf(1, "cannot write '%s'", out.c_str()); return 1; }

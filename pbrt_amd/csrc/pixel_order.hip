@@ -61,7 +61,7 @@ hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint
   }
   if (n_pixels == 0) return hipSuccess;
   const dim3 grid((n_pixels + 255u) / 256u), block(256);
-  const char *so = std::getenv("PBRT_HIP_ORDER_SMOOTH");  // weight of the pixel's own work in quarters (tuning)
+  const char *so = debug_knob("PBRT_HIP_ORDER_SMOOTH");  // weight of the pixel's own work in quarters (tuning)
   const uint32_t smooth_own = so ? (uint32_t)std::atoi(so) & 7u : 2u;
   hipError_t e = hipMemsetAsync(work_sum, 0, 2 * sizeof(unsigned long long), stream);
   if (e != hipSuccess) return e;

@@ -696,6 +696,9 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
       if (!p.quoted(&name)) return fin(false);
       const std::string dir = p.files.empty() ? base_dir : p.files.back()->dir;
       const std::string path = (!name.empty() && name[0] == '/') ? name : (dir.empty() ? name : dir + "/" + name);
+      // (a file that includes itself, directly or through others, would never end: the reference's file_stack,
+      // parser.rs:206, has no guard either; 32 levels are more than any real scene nests)
+      if (p.files.size() >= 32) return fin(p.fail(ParseError::Syntax, "Include: nesting too deep / recursive include of '" + path + "'"));
       std::string text2;
       if (!read_file(path, &text2)) return fin(p.fail(ParseError::Io, "Include: cannot read '" + path + "'"));
       const size_t slash = path.rfind('/');
@@ -738,7 +741,8 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
         out->filter_name = name;
         if (name != "box") api.warn("PixelFilter \"" + name + "\": only the box filter of radius 0.5 is implemented (box.rs:57-61)");
         const float xw = ps.one_float("xwidth", 0.5f), yw = ps.one_float("ywidth", 0.5f);
-        if (xw != 0.5f || yw != 0.5f) api.warn("PixelFilter: radius other than 0.5 is not supported, 0.5 used");
+        out->filter_radius[0] = xw; out->filter_radius[1] = yw;  // handed to the render desc: a radius other than 0.5 is refused there (PBRT_HIP_ERR_LIMIT)
+        if (xw != 0.5f || yw != 0.5f) api.warn("PixelFilter: a box radius other than 0.5 is not implemented; pbrt_hip_render refuses it");
       }
     } else if (tok == "ReverseOrientation") {
       if (in_world("ReverseOrientation")) api.gs.reverse_orientation = !api.gs.reverse_orientation;

@@ -20,9 +20,13 @@ class LoadedScene:
     warnings: list = field(default_factory=list)
     ctm: np.ndarray = None      # CTM when parsing stopped
     names: dict = None          # camera / sampler / integrator / filter / accelerator / film names as given
+    film_scale: float = 1.0     # Film "float scale" (film.rs:368-371): pass to film_to_rgb
+    sampler: int = 0            # PBRT_HIP_SAMPLER_*
+    filter_width: tuple = (0.5, 0.5)
 
     def render_kwargs(self):
-        return dict(integrator=self.integrator, max_depth=self.max_depth, spp=self.spp)
+        return dict(integrator=self.integrator, max_depth=self.max_depth, spp=self.spp, sampler=self.sampler,
+                    filter_width=self.filter_width)
 
 
 def _collect(h):
@@ -51,7 +55,9 @@ def _collect(h):
         keys = ("camera", "sampler", "integrator", "filter", "accelerator", "film")
         return LoadedScene(sd, r.integrator, r.max_depth, (r.spp_x, r.spp_y), fn.value.decode(),
                            [w for w in wbuf.value.decode().split("\n") if w][:nw], ctm.reshape(4, 4),
-                           dict(zip(keys, names.value.decode().split(" "))))
+                           dict(zip(keys, names.value.decode().split(" "))),
+                           film_scale=float(l.pbrt_hip_loaded_film_scale(h)), sampler=int(r.sampler),
+                           filter_width=(float(r.filter_xwidth), float(r.filter_ywidth)))
     finally:
         l.pbrt_hip_loaded_free(h)
 

@@ -297,3 +297,71 @@ def test_dp_collapse_option_builds_a_valid_tree():
         assert r.returncode == 0, r.stderr[-2000:]
         n[mode] = int(r.stdout.split()[-1])
     assert n["dp"] < n["greedy"]
+
+
+def _kernel_notes():
+    """(name, vgpr_count, vgpr_spill_count, private_segment_fixed_size) of every kernel in the library's gfx950 code objects."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as td:
+        so = shutil.copy(_lib.LIB_PATH, td)
+        # one code object per translation unit lands beside the input as <name>.<n>.hipv4-amdgcn-amd-amdhsa--gfx950
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", os.path.basename(so)], cwd=td, check=True, capture_output=True)
+        cos = sorted(glob.glob(os.path.join(td, "*gfx950")))
+        assert cos, "no gfx950 code object in the library"
+        notes = "".join(subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+                        for co in cos)
+    out = []
+    for blk in notes.split(".agpr_count:")[1:]:
+        f = {k: re.search(r"\." + k + r":\s+(\S+)", blk) for k in ("name", "vgpr_count", "vgpr_spill_count", "private_segment_fixed_size")}
+        if all(f.values()):
+            out.append((f["name"].group(1), int(f["vgpr_count"].group(1)), int(f["vgpr_spill_count"].group(1)),
+                        int(f["private_segment_fixed_size"].group(1))))
+    return out
+
+
+@pytest.mark.xfail(reason="r02 work in progress: the service stage still spills 4-6 VGPRs", strict=False)
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm llvm tools")
+def test_production_kernels_do_not_spill():
+    """the production instantiations of render_kernel (no counters, no exact walk) and
+    intersect_kernel must stay under the register budget of their launch bounds: no VGPR spills, no scratch."""
+    import subprocess
+    notes = _kernel_notes()
+    assert notes, "no kernel notes found in the code object"
+    demangled = subprocess.run(["c++filt"], input="\n".join(n[0] for n in notes), capture_output=True, text=True, check=True).stdout.split("\n")
+    prod = [(d, n) for d, n in zip(demangled, notes)
+            if ("render_kernel<" in d and re.search(r"render_kernel<(true|false), false, false,", d)) or "intersect_kernel<" in d and ", false," in d]
+    assert len(prod) >= 4, demangled
+    for d, (_, vgpr, spill, scratch) in prod:
+        assert spill == 0 and scratch == 0, f"{d}: {vgpr} VGPRs, {spill} spilled, {scratch} B scratch"
+
+
+def test_image_readers_refuse_hostile_headers(tmp_path):
+    """a header that announces more pixels than the file holds must come back as an error code,
+    not as std::bad_alloc through the C ABI."""
+    w, h = C.c_int32(0), C.c_int32(0)
+    bomb = tmp_path / "bomb.pfm"
+    bomb.write_bytes(b"PF\n60000 60000\n-1\n")
+    assert _lib.lib().pbrt_hip_read_image(str(bomb).encode(), None, C.byref(w), C.byref(h)) < 0
+    short = tmp_path / "short.pfm"
+    short.write_bytes(b"PF\n4 4\n-1\n" + b"\0" * 100)  # 192 bytes announced, 100 present
+    assert _lib.lib().pbrt_hip_read_image(str(short).encode(), None, C.byref(w), C.byref(h)) < 0
+    # a PNG whose IDAT inflates to far more than its IHDR needs (decompression bomb): zeros behind a 1x1 header
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 1, 1, 8, 2, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(b"\0" * (1 << 24), 9)) + chunk(b"IEND", b"")
+    p = tmp_path / "bomb.png"
+    p.write_bytes(png)
+    assert _lib.lib().pbrt_hip_read_image(str(p).encode(), None, C.byref(w), C.byref(h)) < 0
+    # and a legitimate file still reads
+    rgb = np.linspace(0, 1, 4 * 3 * 3, dtype=np.float32).reshape(3, 4, 3)
+    ok = tmp_path / "ok.pfm"
+    pbrt_amd.write_image(str(ok), rgb)
+    assert np.array_equal(pbrt_amd.read_image(str(ok)), rgb)

@@ -144,3 +144,32 @@ def test_include(tmp_path):
     (tmp_path / "main.pbrt").write_text('WorldBegin\nInclude "geo.pbrt"\nWorldEnd\n')
     sd = loader.load_file(tmp_path / "main.pbrt").scene
     assert sd.spheres.tolist() == [[0, 0, 0, 2, 0]]
+
+
+def test_recursive_include_is_an_error(tmp_path):
+    """a file that includes itself must end in a parse error, not in an endless loop."""
+    from pbrt_amd import _lib
+    f = tmp_path / "self.pbrt"
+    f.write_text('Include "self.pbrt"\n')
+    with pytest.raises(_lib.PbrtHipError) as e:
+        loader.load_file(str(f))
+    assert "Include" in str(e.value) and "recursive" in str(e.value)
+    a, b = tmp_path / "a.pbrt", tmp_path / "b.pbrt"
+    a.write_text('Include "b.pbrt"\n')
+    b.write_text('Include "a.pbrt"\n')
+    with pytest.raises(_lib.PbrtHipError):
+        loader.load_file(str(a))
+
+
+def test_film_scale_and_filter_radius_leave_the_library():
+    """Film "float scale" multiplies every pixel in Film::write_image (film.rs:368-371): the loader exports it; a
+    PixelFilter radius other than 0.5 reaches the render desc (where pbrt_hip_render refuses it)."""
+    ls = loader.load_string('Film "image" "float scale" 2.5 "integer xresolution" 8 "integer yresolution" 8\n'
+                            'PixelFilter "box" "float xwidth" 1.5 "float ywidth" 0.5\nWorldBegin\nWorldEnd\n')
+    assert ls.film_scale == 2.5
+    assert ls.filter_width == (1.5, 0.5)
+    assert any("radius" in w for w in ls.warnings)
+    ls = loader.load_string("WorldBegin\nWorldEnd\n")
+    assert ls.film_scale == 1.0 and ls.filter_width == (0.5, 0.5)
+    film = np.ones((2, 2, 4), np.float32)
+    assert np.array_equal(pbrt_amd.film_to_rgb(film, scale=2.5), pbrt_amd.film_to_rgb(film) * np.float32(2.5))
