@@ -118,13 +118,6 @@ def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0, gpu_film=N
     }
 
 
-def launches_per_step(spp, local_pixels):
-    """capi.cpp render_device: two launches (cost-ordered pixel hand-out) for frames of >= 128 spp whose ranks
-    hold fewer than 16 pixels per lane of the 4096 persistent waves; else one."""
-    per_lane = max(1, local_pixels // (4096 * 64))
-    return 2 if spp >= 128 and per_lane < 16 else 1
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,14 +215,12 @@ def main():
         rays = cst["camera_rays"] + cst["bounce_rays"] + cst["shadow_rays"]
         roof.update({
             "achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel": "render_kernel", "kernel_ms": avg_kernel_ms,
-            "launches_per_step": launches_per_step(spp[0] * spp[1], local_samples // (spp[0] * spp[1])),
             "bytes_per_sample": bps, "algorithmic_bytes_per_launch": alg_bytes,
             "rays_per_sample": rays / cst["samples"], "nodes_per_ray": cst["nodes_visited"] / rays,
             "tris_per_ray": cst["tris_tested"] / rays, "mrays_per_s": rays / (avg_kernel_ms * 1e-3) / 1e6,
             "frac_of_measured_stream_6290": ach / 6290.0,
             "note": "algorithmic bytes = SURVEY 8d formula on the CANONICAL binary-BVH walk (exact counters, equal to the "
-                    "oracle's) / HIP-event kernel time of one frame (one launch of render_kernel; on >= 2 GPUs two launches "
-                    "plus a pixel sort, see launches_per_step, and kernel_ms spans them); it can exceed the HBM peak because the scene "
+                    "oracle's) / HIP-event kernel time of one frame (one launch of render_kernel + the merge of the partial sums); it can exceed the HBM peak because the scene "
                     f"({info['device_bytes'] / 1e6:.0f} MB) sits in the 256 MiB Infinity Cache and the production kernel walks a "
                     "quantised 4-wide form of the tree that moves fewer bytes (see kernel_*)",
         })

@@ -174,6 +174,24 @@ int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], ui
 int pbrt_hip_slab_pixel_index(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world_size,
                               int64_t *out);
 
+/* ---- every GPU of the node behind one call: what a single-process host (the reference's world_end, api.rs:432-473,
+ * reached from bin/pbrt.rs:72-83) needs to render on 8 MI355X.  The scene is built once on GPU 0 and copied device to
+ * device (xGMI); GPU g renders the super-tiles t with t % n_gpus == g on its own stream from its own host thread; ONE
+ * RCCL gather (ncclGather, communicators from ncclCommInitAll) brings the slabs to GPU 0, where they are assembled into
+ * the film.  n_gpus <= 0: all visible devices.  desc->rank / world_size are ignored (the library sets them).
+ * film_xyzw (host, crop_w * crop_h * 4 floats) may be NULL when only the device film is wanted;
+ * per_gpu (n_gpus entries) may be NULL.  flags as pbrt_hip_scene_create_ex. ---- */
+typedef struct pbrt_hip_multi pbrt_hip_multi;
+int pbrt_hip_multi_create(const pbrt_hip_scene_desc *desc, int n_gpus, uint32_t flags, pbrt_hip_multi **out);
+int pbrt_hip_multi_gpus(const pbrt_hip_multi *multi);
+int pbrt_hip_multi_render(pbrt_hip_multi *multi, const pbrt_hip_render_desc *desc, float *film_xyzw, pbrt_hip_stats *per_gpu);
+/* the assembled film of the last pbrt_hip_multi_render on GPU 0 (float4 per pixel, row-major) */
+int pbrt_hip_multi_film_device(pbrt_hip_multi *multi, void **d_film_xyzw);
+void pbrt_hip_multi_destroy(pbrt_hip_multi *multi);
+/* create + render + destroy: the whole of `world_end` in one call */
+int pbrt_hip_render_multi(const pbrt_hip_scene_desc *desc, const pbrt_hip_render_desc *render, int n_gpus, float *film_xyzw,
+                          pbrt_hip_stats *per_gpu);
+
 /* Ray-batch entry points: the traversal kernels on their own (parity + roofline of the
  * dominant loop).  Host SoA-of-xyz arrays, n rays.  prim = 0xffffffff on a miss. */
 int pbrt_hip_intersect(pbrt_hip_scene *scene, int64_t n, const float *o, const float *d, const float *tmax, float *t,

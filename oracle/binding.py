@@ -40,7 +40,7 @@ class RenderDesc(C.Structure):
     _fields_ = [
         ("integrator", C.c_uint32), ("max_depth", C.c_uint32), ("spp_x", C.c_uint32), ("spp_y", C.c_uint32),
         ("seed", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32), ("flags", C.c_uint32),
-        ("pad", C.c_uint32),
+        ("sampler", C.c_uint32),
     ]
 
 
@@ -99,6 +99,9 @@ def lib(native=False):
         l.orc_rng_default_threshold.argtypes = [C.c_uint32, C.c_void_p, C.c_int]
         l.orc_rng_seq_u32.argtypes = [C.c_uint64, C.c_void_p, C.c_int]
         l.orc_rng_seq_float.argtypes = [C.c_uint64, C.c_void_p, C.c_int]
+        l.orc_sobol_dims.restype = C.c_int
+        l.orc_sobol_matrix.argtypes = [C.c_int, C.c_void_p]
+        l.orc_sobol_points.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
         _libs[native] = l
     return _libs[native]
 
@@ -121,6 +124,19 @@ def rng_default_threshold(b, n):
 
 def rng_seq_u32(seq, n):
     out = np.zeros(n, np.uint32); lib().orc_rng_seq_u32(seq, _p(out), n); return out
+
+
+def sobol_matrices():
+    """(dims, 52) uint32: the generator matrices the oracle builds from the Joe-Kuo direction numbers."""
+    n = lib().orc_sobol_dims()
+    out = np.zeros((n, 52), np.uint32)
+    for d in range(n):
+        lib().orc_sobol_matrix(d, _p(out[d]))
+    return out
+
+
+def sobol_points(n):
+    out = np.zeros((n, 2), np.float32); lib().orc_sobol_points(0, n, _p(out)); return out
 
 
 def rng_seq_float(seq, n):
@@ -236,18 +252,24 @@ class OracleScene:
         o = np.zeros(3, np.float32); d = np.zeros(3, np.float32)
         self.l.orc_camera_ray(self.h, fx, fy, _p(o), _p(d)); return o, d
 
-    def _rd(self, integrator, max_depth, spp, seed, rank, world_size):
+    def _rd(self, integrator, max_depth, spp, seed, rank, world_size, sampler=0):
         r = RenderDesc(); r.integrator = integrator; r.max_depth = max_depth; r.spp_x, r.spp_y = spp
         r.seed = seed; r.rank = rank; r.world_size = world_size
+        r.sampler = {"stratified": 0, "sobol": 1}.get(sampler, sampler)
         return r
 
-    def pixel_samples(self, x, y, integrator=0, max_depth=5, spp=(1, 1), seed=0):
-        r = self._rd(integrator, max_depth, spp, seed, 0, 1)
+    def pixel_samples(self, x, y, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler=0):
+        r = self._rd(integrator, max_depth, spp, seed, 0, 1, sampler)
         out = np.zeros((spp[0] * spp[1], 3), np.float32)
         self.l.orc_pixel_samples(self.h, C.byref(r), x, y, _p(out)); return out
 
-    def render(self, integrator=0, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1, n_threads=None):
-        r = self._rd(integrator, max_depth, spp, seed, rank, world_size)
+    def render(self, integrator=0, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1, n_threads=None, sampler=0,
+               filter_width=None):
+        """sampler: "stratified" / "sobol" (or 0 / 1).  filter_width is accepted for symmetry with pbrt_amd's render
+        (the oracle, like the product, only has the box filter of radius 0.5)."""
+        if filter_width is not None and tuple(filter_width) not in ((0.5, 0.5), (0.0, 0.0)):
+            raise ValueError("the oracle only implements the box filter of radius 0.5")
+        r = self._rd(integrator, max_depth, spp, seed, rank, world_size, sampler)
         w, h = self.sd.crop_size()
         film = np.zeros((h, w, 4), np.float32); st = Stats()
         rc = self.l.orc_render(self.h, C.byref(r), _p(film), C.byref(st), n_threads or os.cpu_count())

@@ -15,20 +15,51 @@ namespace orc {
 static bool g_debug_li = false;  // ORC_DEBUG_LI=1: orc_pixel_samples traces every bounce to stderr (parity debugging)
 
 
-// -------- Sampler: stratified pixel position + independent later dimensions --------
-class StratifiedSampler {
+// -------- Samplers --------
+// A pixel's spp samples are cut into kSampleChunks CHUNKS: chunk c holds the samples s with
+// floor(c * spp / 8) <= s < floor((c + 1) * spp / 8) and is a unit of its own -- its own PCG32 stream
+// Rng::new((seed * W * H + y * W + x) * 8 + c) (rng.rs:46-59 fixes only set_sequence) and its own partial film sum;
+// the pixel's contrib_sum is the sum of the eight partial sums in chunk order.  (Round 1 ran all samples of a
+// pixel on one stream; the chunks exist so that the GPU can hand out work in pieces of spp / 8 samples: the frame no
+// longer waits for the sequential samples of its most expensive pixels.)
+constexpr uint32_t kSampleChunks = 8;
+static inline uint32_t chunk_begin(uint32_t c, uint32_t spp) { return (uint32_t)(((uint64_t)c * spp) / kSampleChunks); }
+
+// lowbias32 (integer hash; every operation is defined on uint32): the scrambles of the Sobol sampler come from it
+static inline uint32_t mix32(uint32_t v) {
+  v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+  return v;
+}
+
+// Interface of pbrt-v3's samplers as far as PathIntegrator::Li uses it.
+class Sampler {
+ public:
+  virtual ~Sampler() {}
+  virtual void StartChunk(int x, int y, uint32_t chunk) = 0;  // positions the sampler on the chunk's first sample
+  virtual bool ChunkDone() const = 0;
+  virtual void GetCameraSample(float *fx, float *fy) = 0;
+  virtual float Get1D() = 0;
+  virtual void Get2D(float *u1, float *u2) = 0;
+  virtual void StartNextSample() = 0;
+};
+
+// stratified pixel position + independent later dimensions
+class StratifiedSampler : public Sampler {
  public:
   StratifiedSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s)
       : nx_(nx), ny_(ny), seed_(seed), w_((uint64_t)s.xres), h_((uint64_t)s.yres) {
     inv_nx_ = 1.0f / (float)nx;
     inv_ny_ = 1.0f / (float)ny;
   }
-  void StartPixel(int x, int y) {
-    rng_.set_sequence(seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x);
-    px_ = x; py_ = y; s_ = 0;
+  void StartChunk(int x, int y, uint32_t chunk) override {
+    rng_.set_sequence((seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x) * kSampleChunks + chunk);
+    px_ = x; py_ = y;
+    s_ = chunk_begin(chunk, nx_ * ny_);
+    s_end_ = chunk_begin(chunk + 1, nx_ * ny_);
   }
+  bool ChunkDone() const override { return s_ >= s_end_; }
   // film position of the current sample: stratum (s mod nx, s div nx), jittered
-  void GetCameraSample(float *fx, float *fy) {
+  void GetCameraSample(float *fx, float *fy) override {
     const float one_minus_eps = 1.0f - std::numeric_limits<float>::epsilon();
     uint32_t sx = s_ % nx_, sy = s_ / nx_;
     float u1 = rng_.uniform_float();
@@ -40,9 +71,9 @@ class StratifiedSampler {
     *fx = (float)px_ + jx;
     *fy = (float)py_ + jy;
   }
-  float Get1D() { return rng_.uniform_float(); }
-  bool StartNextSample() { return ++s_ < nx_ * ny_; }
-  uint32_t SamplesPerPixel() const { return nx_ * ny_; }
+  float Get1D() override { return rng_.uniform_float(); }
+  void Get2D(float *u1, float *u2) override { *u1 = rng_.uniform_float(); *u2 = rng_.uniform_float(); }
+  void StartNextSample() override { ++s_; }
 
  private:
   uint32_t nx_, ny_;
@@ -50,7 +81,98 @@ class StratifiedSampler {
   float inv_nx_, inv_ny_;
   Rng rng_;
   int px_ = 0, py_ = 0;
-  uint32_t s_ = 0;
+  uint32_t s_ = 0, s_end_ = 0;
+};
+
+// Generator matrices of the Sobol' sequence from the Joe-Kuo direction numbers (S. Joe, F. Y. Kuo, "Constructing
+// Sobol sequences with better two-dimensional projections", SIAM J. Sci. Comput. 30, 2008; table new-joe-kuo-6):
+// dimension 1 is the van der Corput sequence, dimension j >= 2 has a primitive polynomial of degree s with
+// coefficient bits a and initial numbers m_1 .. m_s.  Column i (1-based) of the 32-bit matrix is m_i * 2^(32 - i)
+// (m_i >> (i - 32) beyond column 32), with m_i = 2 a_1 m_{i-1} ^ 4 a_2 m_{i-2} ^ ... ^ 2^s m_{i-s} ^ m_{i-s}.
+// The same layout as the reference's SOBOL_MATRICES32 (sobolmatrices.rs:81: 52 columns per dimension), which a
+// test compares it with where the reference is mounted.
+struct JoeKuo { uint32_t s, a; uint32_t m[8]; };
+static const JoeKuo kJoeKuo[] = {
+    {1, 0, {1}},                  // dimension 2
+    {2, 1, {1, 3}},               // 3
+    {3, 1, {1, 3, 1}},            // 4
+    {3, 2, {1, 1, 1}},            // 5
+    {4, 1, {1, 1, 3, 3}},         // 6
+    {4, 4, {1, 3, 5, 13}},        // 7
+    {5, 2, {1, 1, 5, 5, 17}},     // 8
+    {5, 4, {1, 1, 5, 5, 5}},      // 9
+    {5, 7, {1, 1, 7, 11, 19}},    // 10
+};
+constexpr int kSobolDims = 1 + (int)(sizeof(kJoeKuo) / sizeof(kJoeKuo[0]));
+constexpr int kSobolColumns = 52;
+static void sobol_matrix(int dim, uint32_t out[kSobolColumns]) {
+  if (dim == 0) {
+    for (int i = 0; i < kSobolColumns; i++) out[i] = i < 32 ? 1u << (31 - i) : 0u;
+    return;
+  }
+  const JoeKuo &d = kJoeKuo[dim - 1];
+  uint64_t m[kSobolColumns + 1];
+  for (uint32_t i = 1; i <= d.s; i++) m[i] = d.m[i - 1];
+  for (uint32_t i = d.s + 1; i <= (uint32_t)kSobolColumns; i++) {
+    uint64_t v = m[i - d.s] ^ (m[i - d.s] << d.s);
+    for (uint32_t k = 1; k < d.s; k++)
+      if ((d.a >> (d.s - 1 - k)) & 1u) v ^= m[i - k] << k;
+    m[i] = v;
+  }
+  for (int i = 1; i <= kSobolColumns; i++) out[i - 1] = i <= 32 ? (uint32_t)(m[i] << (32 - i)) : (uint32_t)(m[i] >> (i - 32));
+}
+
+// Padded (0,2)-sequence sampler: every request j of a sample (0: the camera sample; then light pick,
+// light point, BSDF direction, roulette ... in program order) takes point number (s ^ mask_j) of the first two
+// Sobol' dimensions, XOR-scrambled: the 2^k points of a pixel are the same (0,2)-net in every request, visited in a
+// different order and with different digit scrambles (keys from mix32 of the pixel and j).  No state besides (pixel, s,
+// j): any chunk of a pixel's samples can be generated on its own.
+class SobolSampler : public Sampler {
+ public:
+  SobolSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s) : spp_(nx * ny), seed_(seed), w_((uint64_t)s.xres), h_((uint64_t)s.yres) {
+    sobol_matrix(1, c1_);
+    log2_ = 0;
+    while ((1u << log2_) < spp_) log2_++;
+  }
+  void StartChunk(int x, int y, uint32_t chunk) override {
+    const uint64_t q = seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x;
+    key_ = mix32((uint32_t)q ^ mix32((uint32_t)(q >> 32) + 0x9e3779b9u));
+    px_ = x; py_ = y;
+    s_ = chunk_begin(chunk, spp_);
+    s_end_ = chunk_begin(chunk + 1, spp_);
+    j_ = 0;
+  }
+  bool ChunkDone() const override { return s_ >= s_end_; }
+  void GetCameraSample(float *fx, float *fy) override {
+    float u1, u2;
+    Get2D(&u1, &u2);
+    *fx = (float)px_ + u1;
+    *fy = (float)py_ + u2;
+  }
+  float Get1D() override { float u1, u2; Get2D(&u1, &u2); return u1; }
+  void Get2D(float *u1, float *u2) override {
+    const float one_minus_eps = 1.0f - std::numeric_limits<float>::epsilon();
+    const uint32_t a = mix32(key_ + j_ * 0x9e3779b9u);
+    j_++;
+    const uint32_t i = s_ ^ (a & ((1u << log2_) - 1u));
+    uint32_t x = 0, y = 0;
+    for (uint32_t b = 0; b < 32 && (i >> b) != 0u; b++)
+      if ((i >> b) & 1u) { x ^= 1u << (31 - b); y ^= c1_[b]; }
+    x ^= mix32(a ^ 0x68e31da4u);
+    y ^= mix32(a ^ 0xb5297a4du);
+    float f1 = (float)x * 2.3283064365386963e-10f, f2 = (float)y * 2.3283064365386963e-10f;
+    *u1 = f1 > one_minus_eps ? one_minus_eps : f1;
+    *u2 = f2 > one_minus_eps ? one_minus_eps : f2;
+  }
+  void StartNextSample() override { ++s_; j_ = 0; }
+
+ private:
+  uint32_t spp_, log2_ = 0;
+  uint64_t seed_, w_, h_;
+  uint32_t c1_[kSobolColumns];
+  uint32_t key_ = 0, j_ = 0;
+  int px_ = 0, py_ = 0;
+  uint32_t s_ = 0, s_end_ = 0;
 };
 
 // pbrt-v3 ConcentricSampleDisk with the fixed polynomials instead of libm sin/cos
@@ -102,7 +224,7 @@ class PathIntegrator {
 
   // PathIntegrator::Li.  `direct_only_` turns it into the direct-lighting
   // integrator: first non-specular vertex gets its one-light estimate and the path ends.
-  Vec3 Li(Ray ray, StratifiedSampler &sampler, RayStats &st) const {
+  Vec3 Li(Ray ray, Sampler &sampler, RayStats &st) const {
     if (g_debug_li) std::fprintf(stderr, "ORC sample begins\n");
     Vec3 L = {0, 0, 0}, beta = {1, 1, 1};
     bool specular = false;
@@ -155,8 +277,8 @@ class PathIntegrator {
       if (m->type == 0) {  // matte
         if (nL > 0) {
           float xi = sampler.Get1D();
-          float u1 = sampler.Get1D();
-          float u2 = sampler.Get1D();
+          float u1, u2;
+          sampler.Get2D(&u1, &u2);
           uint32_t li = (uint32_t)(xi * nLf);
           if (li > nL - 1) li = nL - 1;
           Vec3 Ld;
@@ -169,8 +291,8 @@ class PathIntegrator {
           }
         }
         if (direct_only_) break;
-        float u1 = sampler.Get1D();
-        float u2 = sampler.Get1D();
+        float u1, u2;
+        sampler.Get2D(&u1, &u2);
         float z = cosine_sample_about(nf, u1, u2, &wi);
         if (g_debug_li) {
           float dx, dy; concentric_sample_disk(u1, u2, &dx, &dy);
@@ -274,25 +396,28 @@ static inline Vec3 sanitize(Vec3 L) {
 
 static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_render_desc &r, int x, int y,
                          float out_xyzw[4], float *per_sample, RayStats &st) {
-  StratifiedSampler sampler(r.spp_x, r.spp_y, r.seed, s);
-  sampler.StartPixel(x, y);
+  StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s);
+  SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s);
+  Sampler &sampler = r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat;
   Vec3 sum = {0, 0, 0};
-  float wsum = 0.f;
   uint32_t i = 0;
-  do {
-    float fx, fy;
-    sampler.GetCameraSample(&fx, &fy);
-    Ray ray = s.camera_ray(fx, fy);
-    Vec3 L = sanitize(integ.Li(ray, sampler, st));
-    if (per_sample) { per_sample[3 * i] = L.x; per_sample[3 * i + 1] = L.y; per_sample[3 * i + 2] = L.z; }
-    sum = sum + L;     // FilmTile::AddSample with the box filter: weight 1, this pixel only
-    wsum = wsum + 1.0f;
-    i++;
-  } while (sampler.StartNextSample());
-  // Film::merge_film_tile (film.rs:313-326): xyz += to_xyz(contrib_sum); weight += filter_weight_sum
+  for (uint32_t c = 0; c < kSampleChunks; c++) {
+    Vec3 part = {0, 0, 0};
+    for (sampler.StartChunk(x, y, c); !sampler.ChunkDone(); sampler.StartNextSample()) {
+      float fx, fy;
+      sampler.GetCameraSample(&fx, &fy);
+      Ray ray = s.camera_ray(fx, fy);
+      Vec3 L = sanitize(integ.Li(ray, sampler, st));
+      if (per_sample) { per_sample[3 * i] = L.x; per_sample[3 * i + 1] = L.y; per_sample[3 * i + 2] = L.z; }
+      part = part + L;  // FilmTile::AddSample with the box filter: weight 1, this pixel only
+      i++;
+    }
+    sum = sum + part;  // the chunks' partial sums in chunk order
+  }
+  // Film::merge_film_tile (film.rs:313-326): xyz += to_xyz(contrib_sum); weight += filter_weight_sum (= spp)
   float rgb[3] = {sum.x, sum.y, sum.z}, xyz[3];
   rgb_to_xyz(rgb, xyz);
-  out_xyzw[0] = xyz[0]; out_xyzw[1] = xyz[1]; out_xyzw[2] = xyz[2]; out_xyzw[3] = wsum;
+  out_xyzw[0] = xyz[0]; out_xyzw[1] = xyz[1]; out_xyzw[2] = xyz[2]; out_xyzw[3] = (float)(r.spp_x * r.spp_y);
 }
 
 }  // namespace orc
@@ -304,6 +429,22 @@ struct orc_scene {
 };
 
 extern "C" {
+
+int orc_sobol_dims(void) { return kSobolDims; }
+void orc_sobol_matrix(int dim, uint32_t *out52) { sobol_matrix(dim, out52); }
+void orc_sobol_points(uint32_t key_seed, uint32_t n, float *out2n) {
+  // the first n points of the unscrambled (0,2)-sequence (dimensions 1 and 2), for the net-property test
+  uint32_t c1[kSobolColumns];
+  sobol_matrix(1, c1);
+  (void)key_seed;
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t x = 0, y = 0;
+    for (uint32_t b = 0; b < 32 && (i >> b) != 0u; b++)
+      if ((i >> b) & 1u) { x ^= 1u << (31 - b); y ^= c1[b]; }
+    out2n[2 * i] = (float)x * 2.3283064365386963e-10f;
+    out2n[2 * i + 1] = (float)y * 2.3283064365386963e-10f;
+  }
+}
 
 void orc_rng_default_u32(uint32_t *out, int n) { Rng r; for (int i = 0; i < n; i++) out[i] = r.uniform_u32(); }
 void orc_rng_default_float(float *out, int n) { Rng r; for (int i = 0; i < n; i++) out[i] = r.uniform_float(); }
@@ -453,7 +594,7 @@ void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int
 
 int orc_render(const orc_scene *sc, const orc_render_desc *r, float *film, orc_stats *out, int n_threads) {
   const Scene &s = sc->s;
-  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size) return -1;
+  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 1) return -1;
   PathIntegrator integ(s, r->max_depth, r->integrator == 1);
   const int x0 = s.cropped[0], y0 = s.cropped[1], x1 = s.cropped[2], y1 = s.cropped[3];
   const int W = x1 - x0, H = y1 - y0;

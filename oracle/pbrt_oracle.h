@@ -70,7 +70,7 @@ typedef struct {
   uint64_t seed;
   uint32_t rank, world_size; /* which 64x64 super-tiles to render (t % world == rank) */
   uint32_t flags;
-  uint32_t pad;
+  uint32_t sampler;    /* 0 = stratified, 1 = padded (0,2)-sequence "sobol" (3.10) */
 } orc_render_desc;
 
 typedef struct {
@@ -80,6 +80,12 @@ typedef struct {
 } orc_stats;
 
 typedef struct orc_scene orc_scene;
+
+/* ---- Sobol' generator matrices from the Joe-Kuo direction numbers: 52 columns per dimension, the layout of the
+ * reference's SOBOL_MATRICES32 (sobolmatrices.rs:81) ---- */
+int orc_sobol_dims(void);
+void orc_sobol_matrix(int dim, uint32_t *out52);
+void orc_sobol_points(uint32_t key_seed, uint32_t n, float *out2n);
 
 /* ---- reference-pinned primitives ---- */
 void orc_rng_default_u32(uint32_t *out, int n);

@@ -68,6 +68,12 @@ SYMBOLS = {
     "pbrt_hip_film_assemble_device": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "pbrt_hip_slab_floats": (_i64, [_i32, _i32, _pf, _u32, _u32]),
     "pbrt_hip_slab_pixel_index": (C.c_int, [_i32, _i32, _pf, _u32, _u32, _pi64]),
+    "pbrt_hip_multi_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, _u32, C.POINTER(_vp)]),
+    "pbrt_hip_multi_gpus": (C.c_int, [_vp]),
+    "pbrt_hip_multi_render": (C.c_int, [_vp, C.POINTER(RenderDesc), _pf, C.POINTER(Stats)]),
+    "pbrt_hip_multi_film_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "pbrt_hip_multi_destroy": (None, [_vp]),
+    "pbrt_hip_render_multi": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(RenderDesc), C.c_int, _pf, C.POINTER(Stats)]),
     "pbrt_hip_intersect": (C.c_int, [_vp, _i64, _pf, _pf, _pf, _pf, _pu32, _pf, _pf, _pu64]),
     "pbrt_hip_occluded": (C.c_int, [_vp, _i64, _pf, _pf, _pf, _pu8]),
     "pbrt_hip_film_cropped_bounds": (None, [_i32, _i32, _pf, _pi32]),

@@ -206,6 +206,66 @@ def slab_pixel_index(xres, yres, crop, rank, world_size):
     return out
 
 
+class MultiScene:
+    """A scene replicated on n GPUs of this node inside ONE process (pbrt_hip_multi_*): GPU g renders the super-tiles
+    t % n == g from its own host thread and stream, one RCCL gather assembles the film on GPU 0."""
+
+    def __init__(self, sd, n_gpus=0, builder="host"):
+        self._h = None
+        self.sd = sd.normalized()
+        desc = SceneDesc()
+        keep = fill_desc(desc, self.sd, Material, Light, Sphere)
+        h = C.c_void_p()
+        check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), {"host": 0, "gpu": SCENE_GPU_BUILD}[builder], C.byref(h)),
+              "pbrt_hip_multi_create")
+        del keep
+        self._h = h
+        self.n_gpus = lib().pbrt_hip_multi_gpus(h)
+
+    def render(self, host_film=True, **kw):
+        """-> (film[h, w, 4] or None, [stats dict per GPU]).  kw as Scene.render (rank / world_size are set by the library)."""
+        r = make_render_desc(RenderDesc, **kw)
+        w, h = self.sd.crop_size()
+        film = np.zeros((h, w, 4), np.float32) if host_film else None
+        st = (Stats * self.n_gpus)()
+        check(lib().pbrt_hip_multi_render(self._h, C.byref(r), _fp(film) if host_film else None, st), "pbrt_hip_multi_render")
+        return film, [{k: getattr(s, k) for k, _ in Stats._fields_} for s in st]
+
+    def film_device_ptr(self):
+        p = C.c_void_p()
+        check(lib().pbrt_hip_multi_film_device(self._h, C.byref(p)), "pbrt_hip_multi_film_device")
+        return p.value
+
+    def close(self):
+        if self._h:
+            lib().pbrt_hip_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def render_multi(sd, n_gpus=0, **kw):
+    """pbrt_hip_render_multi: create + render on n GPUs + destroy in one call -> (film, [stats per GPU])."""
+    sd = sd.normalized()
+    desc = SceneDesc()
+    keep = fill_desc(desc, sd, Material, Light, Sphere)
+    r = make_render_desc(RenderDesc, **kw)
+    n = n_gpus if n_gpus > 0 else device_count()
+    w, h = sd.crop_size()
+    film = np.zeros((h, w, 4), np.float32)
+    st = (Stats * max(n, 1))()
+    check(lib().pbrt_hip_render_multi(C.byref(desc), C.byref(r), int(n_gpus), _fp(film), st), "pbrt_hip_render_multi")
+    del keep
+    return film, [{k: getattr(s, k) for k, _ in Stats._fields_} for s in st]
+
+
 class Scene:
     """A scene resident in HBM (flattened BVH + leaf-ordered triangles + tables)."""
 

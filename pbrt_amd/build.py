@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.abspath(os.environ.get("PBRT_HIP_LIB_DIR") or os.path.join(HERE, "lib"))
 LIB_PATH = os.path.join(LIB_DIR, "libpbrt_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "pbrt")  # the C++ command line (csrc/pbrt_main.cpp)
-SOURCES = ["capi.cpp", "bvh_build.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip", "pixel_order.hip", "bvh_gpu.hip"]
+SOURCES = ["capi.cpp", "multi_gpu.cpp", "bvh_build.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip", "bvh_gpu.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -49,7 +49,7 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as pool:  # the translation units are independent
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -17,6 +17,7 @@
 
 #include "../../include/pbrt_hip.h"
 #include "bvh_build.hpp"
+#include "capi_internal.hpp"
 #include "device_types.h"
 #include "host_math.hpp"
 #include "scene_parser.hpp"
@@ -27,17 +28,17 @@ namespace {
 
 thread_local std::string g_err;
 
+}  // namespace
+
+namespace pbrt_hip {
 int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
 }
+const char *last_error_message() { return g_err.c_str(); }
+}  // namespace pbrt_hip
 
-#define HIP_TRY(expr)                                                                           \
-  do {                                                                                          \
-    hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess)                                                                       \
-      return fail(PBRT_HIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
-  } while (0)
+namespace {
 
 // number of 64x64 super-tiles a rank owns, and the grid of super-tiles
 struct Shard {
@@ -73,12 +74,7 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
 constexpr uint32_t kMinWalkers = 36, kMinWalkersShallow = 20, kShallowStackNeed = 16, kMinParked = 16;
 // persistent one-wave workgroups of the render kernel per CU: what a CU holds at once (4 SIMDs x 4 waves; the 10 KB LDS
 // stack and the 128-VGPR budget both allow exactly that); the grid is this x the device's CU count (hipDeviceProp_t)
-constexpr uint32_t kRenderWavesPerCu = 16;
-// A frame is rendered in two launches (cost-ordered hand-out, render_device) when a pixel is long (>= this many
-// samples) and a lane renders few of them (< kTwoPhaseMaxPerLane): only then does the order of the tail matter.
-// PBRT_HIP_TWO_PHASE=0 / =1 forces one / two launches (tests, A-B runs).
-constexpr uint32_t kTwoPhaseMinSpp = 128, kTwoPhaseMaxPerLane = 16;
-
+constexpr uint32_t kRenderWavesPerCu = 16, kRenderWavesPerCuSpheres = 12;
 constexpr uint32_t kLeafRef = 0x80000000u;
 
 // A vertex that a triangle uses and that is NaN or infinite would send the builders' bucket index out of range:
@@ -456,63 +452,7 @@ void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool spl
   make_quad_nodes_as(b, P, idx, split_leaves, how, out);
 }
 
-template <class T>
-struct DevBuf {
-  T *p = nullptr;
-  size_t n = 0;
-  hipError_t alloc(size_t count) {
-    n = count;
-    if (count == 0) return hipSuccess;
-    return hipMalloc((void **)&p, count * sizeof(T));
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-};
-
 }  // namespace
-
-struct pbrt_hip_scene {
-  int device = 0;
-  uint32_t n_cu = 256;  // hipDeviceProp_t::multiProcessorCount of `device`
-  pbrt_hip_scene_desc desc{};  // scalar fields only; pointers are cleared
-  Bvh bvh;
-  uint32_t n_lights = 0;
-  DevScene dev{};
-  // device allocations
-  DevBuf<float> d_P;
-  DevBuf<uint32_t> d_idx, d_order;
-  DevBuf<uint16_t> d_mat_id;
-  DevBuf<uint4> d_nodes, d_quads;
-  DevBuf<uint32_t> d_stack_overflow;  // per-lane spill area of the quad walk's stack beyond its LDS part
-  DevBuf<float4> d_tris, d_mats, d_lights, d_spheres;
-  DevBuf<float4> d_slab, d_film;          // scratch of pbrt_hip_render()
-  DevBuf<float4> d_lane_state;            // per-lane path state records of the render kernel
-  DevBuf<float4> d_pixel_state;           // two-launch frames: parked pixels (2 records each)
-  DevBuf<uint32_t> d_pixel_sort;          // keys, sorted keys, pixel ids, pixel order
-  DevBuf<unsigned char> d_sort_tmp;       // radix sort scratch
-  DevBuf<unsigned long long> d_counters;  // 5
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t stream = nullptr;  // own stream of pbrt_hip_render()
-  bool pending = false;
-  bool pending_counters = false;
-  uint32_t n_quads_gpu = 0;
-  bool gpu_built = false;  // accelerator built on the device (no canonical tree: counter flags refused)
-  double build_ms = 0.0;
-  uint64_t pending_samples = 0;
-  uint64_t device_bytes = 0;
-
-  ~pbrt_hip_scene() {
-    d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release(); d_quads.release(); d_stack_overflow.release();
-    d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
-    d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release(); d_pixel_state.release(); d_pixel_sort.release(); d_sort_tmp.release();
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-};
 
 extern "C" {
 
@@ -522,7 +462,7 @@ int pbrt_hip_device_count(void) {
   return n;
 }
 
-const char *pbrt_hip_last_error(void) { return g_err.c_str(); }
+const char *pbrt_hip_last_error(void) { return pbrt_hip::last_error_message(); }
 const char *pbrt_hip_version(void) { return "pbrt_hip 0.1 (gfx950)"; }
 
 int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, uint32_t *nodes,
@@ -862,18 +802,29 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.world = r->world_size;
     R.inv_nx = 1.0f / (float)r->spp_x;
     R.inv_ny = 1.0f / (float)r->spp_y;
-    R.slab = (float4 *)d_slab;
     R.counters = s->d_counters.p;
-    // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once
-    // (256 CUs x 16: the LDS stack allows 4 per SIMD), each lane drawing pixel after pixel from the rank's list.
-    R.n_pixels = sh.n_local * 4096u;
-    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * kRenderWavesPerCu, 1 << 20)));
-    R.next_pixel = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
+    R.sampler = r->sampler;
+    const uint32_t spp = r->spp_x * r->spp_y;
+    R.spp_mask = 0;
+    while (R.spp_mask + 1u < spp) R.spp_mask = 2u * R.spp_mask + 1u;
+    // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once (16 per CU: the
+    // LDS stack and the register budget both allow 4 per SIMD), each lane drawing item after item from the rank's list.
+    // An item is one CHUNK (an eighth of the samples) of one pixel: DESIGN.md 3.1.
+    R.n_items = sh.n_local * 4096u * 8u;
+    // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
+    const uint32_t waves_per_cu = s->dev.n_spheres ? kRenderWavesPerCuSpheres : kRenderWavesPerCu;
+    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u * 8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
+    R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
     {
-      const size_t need = (size_t)R.n_workgroups * 320;  // float4 records: 64 workgroups per super-tile x 5 x 64
+      const size_t need = (size_t)R.n_workgroups * 320;  // float4 records: 5 x 64 per one-wave workgroup
       if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
       R.lane_state = s->d_lane_state.p;
+    }
+    {
+      const size_t need = (size_t)sh.n_local * 4096u * 8u;  // one float4 per item
+      if (s->d_partials.n < need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
+      R.partials = s->d_partials.p;
     }
     {
       // the quad walk keeps kQuadLdsStack entries per lane in LDS; deeper entries (rare) spill here
@@ -889,48 +840,10 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     if (counters == 1 && s->gpu_built)
       return fail(PBRT_HIP_ERR_INVALID, "render: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 80 * sizeof(unsigned long long), st));
-    // One launch renders samples [s_begin, s_end) of every pixel.  A frame of few, long pixels per lane is rendered
-    // in two launches: the first takes spp/32 samples of every pixel and parks each pixel (film sum, RNG state)
-    // with the traversal work it took; the pixels are then ordered by that cost, most expensive first, and the
-    // second launch resumes them in that order -- the cheap pixels go out last and the persistent waves run dry
-    // together (a pixel's samples are sequential, ~0.4 s for C3's 512: with 2 pixels per lane, as on 8 GPUs,
-    // the unordered tail cost 30 %).  Scheduling only: every pixel still sees its samples in order.
-    const uint32_t spp = r->spp_x * r->spp_y;
-    const uint32_t per_lane = std::max<uint32_t>(1u, R.n_pixels / std::max<uint32_t>(1u, R.n_workgroups * 64u));  // (a rank may own no tile at all)
-    const char *tp = debug_knob("PBRT_HIP_TWO_PHASE");
-    bool two = spp >= kTwoPhaseMinSpp && per_lane < kTwoPhaseMaxPerLane;
-    if (tp && tp[0] == '0') two = false;
-    if (tp && tp[0] == '1' && spp >= 2u) two = true;
-    if (sh.n_local == 0) two = false;  // a rank that owns no tile has nothing to order
-    const uint32_t s_split = two ? std::max<uint32_t>(1u, spp / 32u) : 0u;
-    R.pixel_state = nullptr;
-    R.pixel_order = nullptr;
-    size_t sort_bytes = 0;
-    if (s_split) {
-      const size_t n = R.n_pixels;
-      if (s->d_pixel_state.n < 2 * n) { s->d_pixel_state.release(); HIP_TRY(s->d_pixel_state.alloc(2 * n)); }
-      if (s->d_pixel_sort.n < 4 * n) { s->d_pixel_sort.release(); HIP_TRY(s->d_pixel_sort.alloc(4 * n)); }
-      HIP_TRY(launch_pixel_order(nullptr, R.n_pixels, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sort_bytes, st));
-      if (s->d_sort_tmp.n < sort_bytes) { s->d_sort_tmp.release(); HIP_TRY(s->d_sort_tmp.alloc(sort_bytes)); }
-      R.pixel_state = s->d_pixel_state.p;
-      HIP_TRY(hipMemsetAsync(s->d_pixel_state.p, 0, 2 * n * sizeof(float4), st));  // cost 0 = pixel outside the film
-    }
     HIP_TRY(hipEventRecord(s->ev0, st));
-    R.s_begin = 0;
-    R.s_end = s_split ? s_split : spp;
+    // one launch renders every item of the rank; the merge adds each pixel's eight partial sums in chunk order
     HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
-    if (s_split) {
-      uint32_t *keys = s->d_pixel_sort.p, *keys_out = keys + R.n_pixels, *vals = keys + 2 * (size_t)R.n_pixels, *order = keys + 3 * (size_t)R.n_pixels;
-      // finer cost buckets the fewer pixels a lane renders (pixel_order.hip): 2 at 16 pixels per lane, 16 at 2
-      const uint32_t buckets = std::min<uint32_t>(32u, std::max<uint32_t>(1u, tuning("PBRT_HIP_ORDER_BUCKETS", 32u / per_lane, 64)));
-      HIP_TRY(launch_pixel_order(R.pixel_state, R.n_pixels, buckets, s->d_counters.p + 6, keys, keys_out, vals, order, s->d_sort_tmp.p, &sort_bytes, st));
-      HIP_TRY(hipMemsetAsync(R.next_pixel, 0, 64 * sizeof(unsigned long long), st));
-      R.pixel_order = order;
-      R.n_regions = 1;  // the cost-ordered list is handed out front to back
-      R.s_begin = s_split;
-      R.s_end = spp;
-      HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
-    }
+    HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
     s->pending_counters = counters != 0;

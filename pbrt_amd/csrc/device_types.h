@@ -56,20 +56,18 @@ struct RenderParams {
   uint64_t seed;
   uint32_t rank, world;
   float inv_nx, inv_ny;
-  float4 *slab;
   unsigned long long *counters;  // 5: camera, bounce, shadow rays, nodes visited, triangles tested
   uint32_t min_walkers, min_parked;  // traversal scheduling thresholds (kernels.hip trav_run)
   float4 *lane_state;                // 5 x 64 float4 per workgroup: path state parked in HBM (kernels.hip PathState)
   uint32_t *stack_overflow;          // [workgroup][entry][lane]: stack entries beyond the LDS part
   uint32_t stack_overflow_entries;
-  uint32_t *next_pixel;   // hand-out counters of the render kernel's pixel list, one per region, 16 words apart (zeroed before the launch)
-  uint32_t n_regions;     // contiguous parts of the list, one per XCD (kernels.hip fetch step); 1: a single ordered list
-  uint32_t n_pixels;      // n_local_super * 4096
+  uint32_t *next_item;    // hand-out counters of the render kernel's item list, one per region, 16 words apart (zeroed before the launch)
+  uint32_t n_regions;     // contiguous parts of the list, one per XCD (kernels.hip fetch step)
+  uint32_t n_items;       // n_local_super * 4096 pixels * 8 chunks (kernels.hip: item = block, chunk, pixel in block)
   uint32_t n_workgroups;  // one-wave workgroups launched: what the device holds at once, not one per tile
-  // A frame may be rendered in two launches (capi.cpp render_device): samples [s_begin, s_end) of every pixel.
-  uint32_t s_begin, s_end;
-  float4 *pixel_state;        // [n_pixels][2]: {sum.xyz, rays traced}{rng state lo, hi, -, -} between the launches
-  const uint32_t *pixel_order;  // the order in which pixels are handed out (null: 0, 1, 2, ...)
+  float4 *partials;       // [slab position][8]: the partial film sums of the chunks (merge_kernel adds them in order)
+  uint32_t sampler;       // PBRT_HIP_SAMPLER_*
+  uint32_t spp_mask;      // Sobol sampler: 2^ceil(log2(spp)) - 1
 };
 
 struct RayBatch {
@@ -91,11 +89,9 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);
-// Orders the pixels of a two-launch frame for the second launch (pixel_order.hip): keys[q] = work of pixel q in
-// the first launch in units of 1/buckets of the mean (0 = not rendered), vals[q] = q; vals sorted by descending key
-// (stable) into `order`.  `work_sum`: 2 counters of scratch.  `tmp` / `tmp_bytes`: sort scratch (query with tmp == nullptr).
-hipError_t launch_pixel_order(const float4 *pixel_state, uint32_t n_pixels, uint32_t buckets, unsigned long long *work_sum, uint32_t *keys,
-                              uint32_t *keys_out, uint32_t *vals, uint32_t *order, void *tmp, size_t *tmp_bytes, hipStream_t stream);
+// adds the eight partial sums of every pixel of a rank's slab in chunk order and converts to XYZ (Film::merge_film_tile)
+hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
+                        uint32_t n_local_super, uint32_t spp, hipStream_t stream);
 // bvh_gpu.hip: the accelerator built on the device.  d_order (n_tris) and d_quads (>= n_tris nodes of 4 uint4) are outputs.
 struct GpuBuildInfo {
   uint32_t n_quads, stack_need, levels;

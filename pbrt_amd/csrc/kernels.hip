@@ -183,10 +183,8 @@ struct Trav {
   float tmax;
   uint32_t cur;       // ref to process next: interior = step, leaf = the lane is PARKED there; kDone = walk over
   uint32_t sp;        // exact walk: stack entries in use; production walk: LDS byte address of the lane's first free entry
-  uint32_t any;       // any-hit (shadow) ray
-  uint32_t occluded;  // any-hit result
+  uint32_t any;       // bit 0: any-hit (shadow) ray; bit 1: its result, occluded
   HitRec h;           // closest-hit result
-  uint32_t work;      // node steps + triangle tests of this walk (production walk: a pixel's cost estimate)
 };
 
 struct TravTuning {
@@ -267,8 +265,6 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
     T.sp = lds_addr(stk) + kRowBytes;
   }
   T.any = any ? 1u : 0u;
-  T.occluded = 0;
-  T.work = 0;
   T.h.t = kInf;
   T.h.prim = kNoPrim;
   T.h.slot = kNoPrim;
@@ -384,7 +380,6 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       }
 #endif
       if (COUNT) cn++;  // one 64-byte fetch
-      T.work++;
       const float tfar = fminf(T.h.t, T.tmax);
 #ifdef PBRT_EXTRA_VALU  // A-B experiment: PBRT_EXTRA_VALU extra independent VALU instructions per node step
       {
@@ -489,8 +484,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
           const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
           if (COUNT) ct++;
-          T.work++;
-          // Moeller-Trumbore, operation order of DESIGN.md 3.5
+              // Moeller-Trumbore, operation order of DESIGN.md 3.5
           const V3 p0 = xyz(a);
           const V3 e1 = xyz(b) - p0, e2 = xyz(c) - p0;
           const V3 pv = cross(d, e2);
@@ -504,7 +498,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
             const float th = dot(e2, qv) * idet;
             if ((u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax)) {
               if (T.any) {
-                T.occluded = 1u;  // the walk ends at the first valid hit
+                T.any = 3u;  // occluded: the walk ends at the first valid hit
                 stop = true;
               } else {
                 const uint32_t id = __float_as_uint(a.w);
@@ -531,11 +525,11 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
 // Spheres are tested after the BVH walk, with the same tie rule.
 __device__ __forceinline__ void trav_spheres(const DevScene &S, Trav &T) {
   for (uint32_t s = 0; s < S.n_spheres; s++) {
-    if (T.any && T.occluded) break;
+    if (T.any == 3u) break;
     float th;
     if (sphere_hit(S, s, T.o, T.d, T.tmax, th)) {
       if (T.any) {
-        T.occluded = 1u;
+        T.any = 3u;
       } else {
         const uint32_t id = S.n_tris + s;
         if (th < T.h.t || (th == T.h.t && id < T.h.prim)) {
@@ -617,43 +611,74 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FET
 __device__ float4 *g_raylog = nullptr;
 __device__ unsigned long long g_raylog_n = 0, g_raylog_cap = 0;
 #endif
-// Path state of one pixel while its lane is busy walking the BVH: five 16-byte records per lane in
-// HBM, laid out [record][lane] per wave so that a wave's access is one coalesced 1 KB transaction.
-// It is loaded and stored only in the service stage (once per ray, against ~76 gather steps), which
-// keeps these 20 dwords out of the registers that are live across the traversal loop.
+// Path state of one work item (a CHUNK of a pixel's samples) while its lane is busy walking the BVH:
+// five 16-byte records per lane in HBM, laid out [record][lane] per wave so that a wave's access is one coalesced
+// 1 KB transaction.  It is loaded and stored only in the service stage (once per ray, against ~41 gather steps),
+// which keeps these 20 dwords out of the registers that are live across the traversal loop.
 struct PathState {
-  V3 sum;      // Film contrib_sum of this pixel so far
   V3 L, beta;  // radiance and throughput of the sample in flight
   V3 wi_next;  // prepared bounce direction (taken after the shadow ray returns)
-  V3 Lpend;    // beta * Ld, added if the shadow ray is unoccluded
-  Pcg rng;     // rng.inc is recomputed from the pixel, only the state is stored
+  Pcg rng;     // stratified sampler: rng.inc is recomputed from the item, only the state is stored.  Sobol sampler:
+               // rng.state = the pixel's scramble key | the request counter of the sample in flight << 32
   uint32_t s, bounces;
   bool specular, cont;
-  uint32_t work;  // node steps + triangle tests + 16 per ray spent on this pixel so far (two-launch frames: its cost estimate)
 };
+// Records 0..2 hold what every visit of the service stage needs; record 3 (beta * Ld of the light sample, added if the
+// shadow ray comes back unoccluded) and record 4 (the chunk's partial film sum so far) are read and written only where
+// they are used -- by the lanes whose ray was a shadow ray, and once per finished sample -- and never sit in registers
+// beside the shading arithmetic (r01 loaded all five on every visit: 6 more live VGPRs, 40 % more record traffic).
+constexpr uint32_t kRecLpend = 192u, kRecSum = 256u;
 __device__ __forceinline__ void path_store(float4 *rec, const PathState &P) {
-  rec[0] = make_float4(P.sum.x, P.sum.y, P.sum.z, P.L.x);
-  rec[64] = make_float4(P.L.y, P.L.z, P.beta.x, P.beta.y);
-  rec[128] = make_float4(P.beta.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
-  rec[192] = make_float4(P.Lpend.x, P.Lpend.y, P.Lpend.z,
-                         __uint_as_float(P.s | (P.bounces << 20) | (P.specular ? 1u << 30 : 0u) | (P.cont ? 1u << 31 : 0u)));
-  rec[256] = make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)),
-                         __uint_as_float(P.work), 0.f);
+  rec[0] = make_float4(P.L.x, P.L.y, P.L.z,
+                       __uint_as_float(P.s | (P.bounces << 20) | (P.specular ? 1u << 30 : 0u) | (P.cont ? 1u << 31 : 0u)));
+  rec[64] = make_float4(P.beta.x, P.beta.y, P.beta.z, __uint_as_float((uint32_t)P.rng.state));
+  rec[128] = make_float4(P.wi_next.x, P.wi_next.y, P.wi_next.z, __uint_as_float((uint32_t)(P.rng.state >> 32)));
 }
 __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
-  const float4 a = rec[0], b = rec[64], c = rec[128], d = rec[192], e = rec[256];
-  P.sum = {a.x, a.y, a.z};
-  P.L = {a.w, b.x, b.y};
-  P.beta = {b.z, b.w, c.x};
-  P.wi_next = {c.y, c.z, c.w};
-  P.Lpend = {d.x, d.y, d.z};
-  const uint32_t w = __float_as_uint(d.w);
+  const float4 a = rec[0], b = rec[64], c = rec[128];
+  P.L = {a.x, a.y, a.z};
+  P.beta = {b.x, b.y, b.z};
+  P.wi_next = {c.x, c.y, c.z};
+  const uint32_t w = __float_as_uint(a.w);
   P.s = w & 0xfffffu;
   P.bounces = (w >> 20) & 0x3ffu;
   P.specular = (w >> 30) & 1u;
   P.cont = (w >> 31) & 1u;
-  P.rng.state = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
-  P.work = __float_as_uint(e.z);
+  P.rng.state = (uint64_t)__float_as_uint(b.w) | ((uint64_t)__float_as_uint(c.w) << 32);
+}
+
+// ---- samplers (DESIGN.md 3.1 stratified, 3.10 padded (0,2)-sequence) ----
+constexpr uint32_t kSampleChunks = 8u;  // a pixel's samples are cut into 8 chunks, each a work item with its own RNG stream
+__device__ __forceinline__ uint32_t chunk_begin(uint32_t c, uint32_t spp) { return (c * spp) >> 3; }  // spp <= 2^20
+__device__ __forceinline__ uint32_t mix32(uint32_t v) {  // lowbias32
+  v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+  return v;
+}
+// One 2-D request of the sample in flight.  Sobol: point (s ^ mask_j) of the first two Sobol' dimensions -- the
+// van der Corput sequence (bit reversal) and the dimension whose generator matrix has the columns v, v ^ v >> 1, ...
+// (Joe-Kuo s = 1, a = 0, m = 1) -- XOR-scrambled with keys hashed from the pixel and the request number j.
+__device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const uint32_t spp_mask, float &u1, float &u2) {
+  if (!sobol) {
+    u1 = pcg_float(P.rng);
+    u2 = pcg_float(P.rng);
+    return;
+  }
+  const uint32_t a = mix32((uint32_t)P.rng.state + (uint32_t)(P.rng.state >> 32) * 0x9e3779b9u);
+  P.rng.state += 1ull << 32;  // next request
+  const uint32_t i = P.s ^ (a & spp_mask);
+  uint32_t x = __builtin_bitreverse32(i), y = 0u;
+  for (uint32_t k = i, v = 0x80000000u; k != 0u; k >>= 1, v ^= v >> 1)
+    if (k & 1u) y ^= v;
+  x ^= mix32(a ^ 0x68e31da4u);
+  y ^= mix32(a ^ 0xb5297a4du);
+  u1 = fminf(kOneMinusEps, (float)x * 2.3283064365386963e-10f);
+  u2 = fminf(kOneMinusEps, (float)y * 2.3283064365386963e-10f);
+}
+__device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const uint32_t spp_mask) {
+  if (!sobol) return pcg_float(P.rng);
+  float u1, u2;
+  sample_2d(P, true, spp_mask, u1, u2);
+  return u1;
 }
 
 // COUNT: accumulate ray / visit counters.  EXACT (needs COUNT): walk the tree in exactly the oracle's
@@ -663,7 +688,9 @@ __device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
 // STACK: LDS entries of the exact walk; for the production walk it only says whether the HBM overflow
 // area is compiled in (STACK != 0).
 template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK>
-__global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) render_kernel(const DevScene S, const RenderParams R) {
+// (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
+// of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
+__global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
   __shared__ uint32_t lds_stack[EXACT ? STACK : kQuadLdsStack][64];
   __shared__ float lds_tn[EXACT ? STACK : 1][64];  // entry distances: exact walk only
   const uint32_t lane = threadIdx.x;
@@ -671,20 +698,28 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   float *stkt = &lds_tn[0][lane];
   uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u;  // wave-uniform (SGPRs); the lane is added at use
 
-  // Pixels are handed out dynamically (see the fetch step of the service stage): pixel number `pix` of this
-  // rank is pixel (pix & 63) of 8x8 block ((pix >> 6) & 63) of local super-tile (pix >> 12), both row-major,
-  // which is also its place in the slab.
+  // Work is handed out dynamically (see the fetch step of the service stage) in ITEMS: item number `item` of this rank
+  // is chunk ((item >> 6) & 7) of pixel (item & 63) of 8x8 block (item >> 9) -- the 512 items of a block are its 64
+  // pixels at chunk 0, then at chunk 1, ... so a wave that draws 64 consecutive items holds one 8x8 block at one
+  // chunk.  Pixel number q = block * 64 + pixel is pixel (q & 63) of 8x8 block ((q >> 6) & 63) of local super-tile
+  // (q >> 12), both row-major.
   const int32_t W = S.cx1 - S.cx0, H = S.cy1 - S.cy0;
   const uint32_t stx = (uint32_t)(W + 63) >> 6;
   const uint64_t seq0 = R.seed * (uint64_t)S.xres * (uint64_t)S.yres;
-  uint32_t pix = 0;
+  uint32_t item = 0;
   auto pixel_xy = [&](uint32_t q, int32_t &xr, int32_t &yr) {
     const uint32_t tsup = R.rank + (q >> 12) * R.world;
     xr = (int32_t)((tsup % stx) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u));
     yr = (int32_t)((tsup / stx) * 64u + ((q >> 9) & 7u) * 8u + ((q >> 3) & 7u));
   };
-
+  auto item_pixel = [](uint32_t it) { return ((it >> 9) << 6) | (it & 63u); };
+  // place of pixel q in the rank's slab (super-tiles back to back, row-major inside) and so of its 8 partial sums
+  auto slab_pos = [](uint32_t q) {
+    return (size_t)(q >> 12) * 4096u + (((q >> 9) & 7u) * 8u + ((q >> 3) & 7u)) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u);
+  };
+  const bool sobol = R.sampler == 1u;
   const uint32_t spp = R.spp_x * R.spp_y;
+  const uint32_t spp_mask = R.spp_mask;  // Sobol: 2^ceil(log2 spp) - 1
   const uint32_t nL = S.n_lights;
   const float nLf = (float)nL;
   const bool direct_only = R.integrator == 1u;
@@ -701,9 +736,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
   T.cur = kDone;
   T.sp = 0;
   T.any = 0;
-  T.occluded = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
-  T.work = 0;
 
 #ifdef PBRT_PHASE_PROBE
   if (lane < 8) s_probe[lane] = 0;
@@ -719,18 +752,20 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
     int32_t xr = 0, yr = 0;
     if (serve && state != ST_FETCH) {
       path_load(rec, P);
-      pixel_xy(pix, xr, yr);
-      P.rng.inc = ((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) << 1) | 1u;
+      pixel_xy(item_pixel(item), xr, yr);
+      P.rng.inc = (((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) * kSampleChunks + ((item >> 6) & 7u)) << 1) | 1u;
       if (state != ST_NEW) {
         if (SPH) trav_spheres(S, T);
-        P.work += T.work + 16u;  // + the ray's share of the service stage, in step units
         bool advance = false;  // take the prepared bounce (or end the sample)
         if (state == ST_SHADOW) {
 #ifdef PBRT_DEBUG_PIXEL_X
           if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
-            printf("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(P.Lpend.x), T.occluded, T.tmax);
+            printf("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(rec[kRecLpend].x), T.any >> 1, T.tmax);
 #endif
-          if (!T.occluded) P.L = P.L + P.Lpend;
+          if (T.any != 3u) {  // unoccluded: the light sample counts
+            const float4 lp = rec[kRecLpend];
+            P.L = P.L + mk(lp.x, lp.y, lp.z);
+          }
           advance = true;
         } else {
           const HitRec h = T.h;
@@ -786,19 +821,23 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
             bool alive = true;
             if (__float_as_uint(m0.x) == 0u) {  // matte
               if (nL > 0u) {
-                const float xi = pcg_float(P.rng), u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
+                const float xi = sample_1d(P, sobol, spp_mask);
+                float u1, u2;
+                sample_2d(P, sobol, spp_mask, u1, u2);
                 uint32_t li = (uint32_t)(xi * nLf);
                 if (li > nL - 1u) li = nL - 1u;
                 V3 Ld;
                 if (sample_light(S, li, po, nf, k, u1, u2, nLf, Ld, sh_d, sh_tmax)) {
                   need_shadow = true;
-                  P.Lpend = P.beta * Ld;
+                  const V3 lpend = P.beta * Ld;
+                  rec[kRecLpend] = make_float4(lpend.x, lpend.y, lpend.z, 0.f);
                 }
               }
               if (direct_only) {
                 alive = false;
               } else {
-                const float u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
+                float u1, u2;
+                sample_2d(P, sobol, spp_mask, u1, u2);
                 const float z = cosine_about(nf, u1, u2, P.wi_next);
 #ifdef PBRT_DEBUG_PIXEL_X
                 if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
@@ -817,7 +856,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
             if (alive && P.bounces > 3u) {
               const float mx = fmaxf(P.beta.x, fmaxf(P.beta.y, P.beta.z));
               const float q = fmaxf(0.05f, 1.0f - mx);
-              if (pcg_float(P.rng) < q) alive = false;
+              if (sample_1d(P, sobol, spp_mask) < q) alive = false;
               else P.beta = P.beta / (1.0f - q);
             }
             P.cont = alive;
@@ -855,48 +894,43 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
             if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
               printf("SAMPLE %u %08x %08x %08x\n", P.s, __float_as_uint(P.L.x), __float_as_uint(P.L.y), __float_as_uint(P.L.z));
 #endif
-            P.sum = P.sum + P.L;
+            // FilmTile::AddSample with the box filter: this pixel, weight 1.  The chunk's partial sum lives in its record.
+            const float4 sm = rec[kRecSum];
+            const V3 sum = mk(sm.x, sm.y, sm.z) + P.L;
             P.s++;
-            state = ST_NEW;
+            if (sobol) P.rng.state &= 0xffffffffull;  // request counter of the next sample
+            if (P.s == chunk_begin(((item >> 6) & 7u) + 1u, spp)) {
+              // the chunk is complete: its partial sum goes to the item's slot; merge_kernel adds a pixel's eight in
+              // chunk order (Film::merge_film_tile, core/film.rs:313-326)
+              R.partials[slab_pos(item_pixel(item)) * kSampleChunks + ((item >> 6) & 7u)] = make_float4(sum.x, sum.y, sum.z, 0.f);
+              state = ST_FETCH;  // this lane takes another item
+            } else {
+              rec[kRecSum] = make_float4(sum.x, sum.y, sum.z, 0.f);
+              state = ST_NEW;
+            }
           }
           P.cont = false;
         }
       }
-      if (state == ST_NEW && P.s == R.s_end) {
-        if (R.s_end == spp) {
-          // Film::merge_film_tile (core/film.rs:313-326): xyz = rgb_to_xyz(contrib_sum), weight = spp
-          float4 o;
-          o.x = 0.412453f * P.sum.x + 0.357580f * P.sum.y + 0.180423f * P.sum.z;
-          o.y = 0.212671f * P.sum.x + 0.715160f * P.sum.y + 0.072169f * P.sum.z;
-          o.z = 0.019334f * P.sum.x + 0.119193f * P.sum.y + 0.950227f * P.sum.z;
-          o.w = (float)spp;
-          R.slab[(size_t)(pix >> 12) * 4096u + (((pix >> 9) & 7u) * 8u + ((pix >> 3) & 7u)) * 64u + ((pix >> 6) & 7u) * 8u + (pix & 7u)] = o;
-        } else {
-          // first launch of a two-launch frame: park the pixel (the second launch resumes it at sample s_end)
-          // together with the traversal work it took, the cost estimate by which the second launch orders the pixels
-          R.pixel_state[2 * (size_t)pix] = make_float4(P.sum.x, P.sum.y, P.sum.z, __uint_as_float(P.work));
-          R.pixel_state[2 * (size_t)pix + 1] =
-              make_float4(__uint_as_float((uint32_t)P.rng.state), __uint_as_float((uint32_t)(P.rng.state >> 32)), 0.f, 0.f);
-        }
-        state = ST_FETCH;  // this lane takes another pixel
-      }
     }
-    // ---- fetch: lanes without a pixel draw the next ones of this rank's pixel list (wave-uniform; one
-    // atomic per wave and round).  A pixel stays with its lane for all its samples, so its RNG stream, sample
-    // order and film sum are those of DESIGN.md 3.1 whichever lane happens to take it; what the dynamic
-    // hand-out removes is the idling of lanes whose pixels have short paths (sky) beside long ones. ----
+    // ---- fetch: lanes without an item draw the next ones of this rank's item list (wave-uniform; one atomic per
+    // wave and round).  An item stays with its lane for all its samples, so its RNG stream, sample order and partial
+    // sum are those of DESIGN.md 3.1 whichever lane happens to take it; what the dynamic hand-out removes is the
+    // idling of lanes whose pixels have short paths (sky) beside long ones, and -- items being an eighth of a pixel --
+    // the wait for the sequential samples of the frame's most expensive pixels at its end. ----
     for (;;) {
       const unsigned long long mw = __ballot(state == ST_FETCH);
       if (mw == 0ull) break;
       // XCD-aware hand-out: workgroup w runs on XCD w mod 8 (each XCD has its own 4 MiB L2), so the list is cut into
       // n_regions contiguous parts and a wave draws from the part of its XCD -- the waves that share an L2 render
-      // one part of the image -- and helps the next part when its own is exhausted.  (n_regions = 1: the second
-      // launch of a two-launch frame, whose list is ordered by cost.)
-      uint32_t base = 0, lim = R.n_pixels;
+      // one part of the image -- and helps the next part when its own is exhausted.
+      uint32_t base = 0, lim = R.n_items;
       for (uint32_t tries = 0; tries < R.n_regions; tries++) {
-        const uint32_t lo = (uint32_t)(((uint64_t)R.n_pixels * region) / R.n_regions);
-        const uint32_t hi = (uint32_t)(((uint64_t)R.n_pixels * (region + 1u)) / R.n_regions);
-        if (lane == 0) base = atomicAdd(R.next_pixel + 16u * region, (uint32_t)__popcll(mw));
+        // (parts are cut at multiples of 512 items = whole 8x8 blocks)
+        const uint32_t nblk = R.n_items >> 9;
+        const uint32_t lo = (uint32_t)(((uint64_t)nblk * region) / R.n_regions) << 9;
+        const uint32_t hi = (uint32_t)(((uint64_t)nblk * (region + 1u)) / R.n_regions) << 9;
+        if (lane == 0) base = atomicAdd(R.next_item + 16u * region, (uint32_t)__popcll(mw));
         base = __builtin_amdgcn_readfirstlane(base) + lo;
         lim = hi;
         if (base < hi) break;
@@ -904,32 +938,31 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
         base = lim;
       }
       if (state == ST_FETCH) {
-        const uint32_t qi = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
-        if (qi >= lim) {
+        const uint32_t it = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+        if (it >= lim) {
           if (base >= lim) state = ST_DONE;  // every part exhausted (else: this lane draws again in the next round)
         } else {
-          const uint32_t q = R.pixel_order ? R.pixel_order[qi] : qi;
+          const uint32_t q = item_pixel(it), chunk = (it >> 6) & 7u;
           pixel_xy(q, xr, yr);
           if (xr < W && yr < H) {  // (pixels of a ragged super-tile outside the image are skipped)
-            pix = q;
-            P.L = {0.f, 0.f, 0.f};
-            P.beta = {1.f, 1.f, 1.f};
-            P.wi_next = {0.f, 0.f, 0.f};
-            P.Lpend = {0.f, 0.f, 0.f};
-            pcg_seq(P.rng, seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr));
-            if (R.s_begin == 0u) {
-              P.sum = {0.f, 0.f, 0.f};
-            } else {  // resume the pixel where the first launch parked it
-              const float4 a = R.pixel_state[2 * (size_t)q], b = R.pixel_state[2 * (size_t)q + 1];
-              P.sum = {a.x, a.y, a.z};
-              P.rng.state = (uint64_t)__float_as_uint(b.x) | ((uint64_t)__float_as_uint(b.y) << 32);
+            if (chunk_begin(chunk, spp) == chunk_begin(chunk + 1u, spp)) {
+              // an empty chunk (fewer than 8 samples per pixel): its partial sum is zero; the lane draws again
+              R.partials[slab_pos(q) * kSampleChunks + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+              item = it;
+              rec[kRecSum] = make_float4(0.f, 0.f, 0.f, 0.f);
+              P.L = {0.f, 0.f, 0.f};
+              P.beta = {1.f, 1.f, 1.f};
+              P.wi_next = {0.f, 0.f, 0.f};
+              const uint64_t pixel_seq = seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr);
+              if (sobol) P.rng.state = mix32((uint32_t)pixel_seq ^ mix32((uint32_t)(pixel_seq >> 32) + 0x9e3779b9u));
+              else pcg_seq(P.rng, pixel_seq * kSampleChunks + chunk);
+              P.s = chunk_begin(chunk, spp);
+              P.bounces = 0;
+              P.specular = false;
+              P.cont = false;
+              state = ST_NEW;
             }
-            P.work = 0;
-            P.s = R.s_begin;
-            P.bounces = 0;
-            P.specular = false;
-            P.cont = false;
-            state = ST_NEW;
           }
         }
       }
@@ -938,10 +971,14 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : PBRT_RENDER_WAVES_PER_SIMD)) 
       if (state == ST_NEW) {
         if (true) {
           // stratified camera sample and PerspectiveCamera ray (3.2)
-          const uint32_t sx = P.s % R.spp_x, sy = P.s / R.spp_x;
-          const float u1 = pcg_float(P.rng), u2 = pcg_float(P.rng);
-          const float jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
-          const float jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
+          float u1, u2;
+          sample_2d(P, sobol, spp_mask, u1, u2);
+          float jx = u1, jy = u2;  // Sobol: the (0,2)-net point is the film offset
+          if (!sobol) {
+            const uint32_t sx = P.s % R.spp_x, sy = P.s / R.spp_x;
+            jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
+            jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
+          }
           const float fx = (float)(S.cx0 + xr) + jx, fy = (float)(S.cy0 + yr) + jy;
           const V3 dc = unit(mk(fx * S.cam_ax + S.cam_bx, fy * S.cam_ay + S.cam_by, 1.0f));
           rd = {(S.c2w[0] * dc.x + S.c2w[1] * dc.y) + S.c2w[2] * dc.z,
@@ -1024,15 +1061,13 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
   T.cur = kDone;
   T.sp = 0;
   T.any = 0;
-  T.occluded = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
-  T.work = 0;
   for (;;) {
     if (T.cur == kDone) {
       if (have) {
         if (SPH) trav_spheres(S, T);
         if (any_hit) {
-          B.occluded[idx] = T.occluded ? 1 : 0;
+          B.occluded[idx] = T.any == 3u ? 1 : 0;
         } else {
           B.t[idx] = T.h.t;
           B.prim[idx] = T.h.prim;
@@ -1089,14 +1124,39 @@ __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int
   if (x < w && y < h) film[(size_t)y * w + x] = slab[i];
 }
 
+// Film::merge_film_tile (core/film.rs:313-326) for one pixel of a rank's slab: contrib_sum = the eight partial sums of
+// its chunks added in chunk order, xyz = rgb_to_xyz(contrib_sum) (spectrum.rs:139-145), weight = spp.
+__global__ void merge_kernel(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
+                             uint32_t n_local_super, float weight) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_local_super * 4096u) return;
+  const uint32_t j = i >> 12, pys = (i >> 6) & 63u, pxs = i & 63u;
+  const uint32_t stx = (uint32_t)(w + 63) >> 6;
+  const uint32_t t = rank + j * world;
+  const int32_t x = (int32_t)((t % stx) * 64u + pxs), y = (int32_t)((t / stx) * 64u + pys);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x < w && y < h) {  // (pixels of a ragged super-tile outside the image were never rendered)
+    V3 sum = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (uint32_t c = 0; c < kSampleChunks; c++) {
+      const float4 p = partials[(size_t)i * kSampleChunks + c];
+      sum = sum + mk(p.x, p.y, p.z);
+    }
+    o.x = 0.412453f * sum.x + 0.357580f * sum.y + 0.180423f * sum.z;
+    o.y = 0.212671f * sum.x + 0.715160f * sum.y + 0.072169f * sum.z;
+    o.z = 0.019334f * sum.x + 0.119193f * sum.y + 0.950227f * sum.z;
+    o.w = weight;
+  }
+  slab[i] = o;
+}
+
 }  // namespace
 
 template <bool SPH, bool COUNT, bool EXACT>
 static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t depth,
                                   hipStream_t st) {
   const dim3 grid(R.n_workgroups), block(64);
-  // the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
-  if (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
+  if constexpr (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
     // node steps per scheduling check: 3 for deep trees (C3 +1 %, C2 +2 % over 2), 2 for shallow ones whose walks
     // are a few steps long (C4: 3 would cost 5 %)
     static const bool force_ovf = debug_knob("PBRT_HIP_FORCE_OVERFLOW_VARIANT") != nullptr;  // A-B runs
@@ -1104,14 +1164,16 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
     else if (!COUNT && S.quad_stack_need <= 16u) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0, 2>), grid, block, 0, st, S, R);
     else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, 0, st, S, R);
     return hipGetLastError();
+  } else {
+    // exact walk: the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
+    const uint32_t need = depth > 0 ? depth - 1 : 0;
+    if (need > 40) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
+    else if (need > 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 40>), grid, block, 0, st, S, R);
+    else if (need > 26) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);
+    else if (need > 20) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 26>), grid, block, 0, st, S, R);
+    else hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 20>), grid, block, 0, st, S, R);
+    return hipGetLastError();
   }
-  const uint32_t need = depth > 0 ? depth - 1 : 0;
-  if (need > 40) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
-  else if (need > 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 40>), grid, block, 0, st, S, R);
-  else if (need > 26) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);
-  else if (need > 20) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 26>), grid, block, 0, st, S, R);
-  else hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 20>), grid, block, 0, st, S, R);
-  return hipGetLastError();
 }
 
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
@@ -1185,6 +1247,15 @@ hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t 
   if (n_tris == 0) return hipSuccess;
   hipLaunchKernelGGL(pack_tris_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, stream, P, idx, mat_id, order, n_tris,
                      tris);
+  return hipGetLastError();
+}
+
+hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
+                        uint32_t n_local_super, uint32_t spp, hipStream_t stream) {
+  if (n_local_super == 0) return hipSuccess;
+  const uint32_t n = n_local_super * 4096u;
+  hipLaunchKernelGGL(merge_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partials, slab, w, h, rank, world, n_local_super,
+                     (float)spp);
   return hipGetLastError();
 }
 

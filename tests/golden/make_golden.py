@@ -1,7 +1,8 @@
 """Generates tests/golden/render_golden.npz with the CPU oracle (self-generated fixtures: the
 reference has no renderer to generate them from, SURVEY.md section 8c "parity unpinned").
 Run from the repo root:  python tests/golden/make_golden.py
-Key format: scene-integrator-maxdepth-sppx-sppy-seed."""
+Key format: scene-integrator-maxdepth-sppx-sppy-seed-sampler (sampler: 0 stratified, 1 sobol).
+Regenerated in round 2: a pixel's samples now run in eight chunks with their own RNG streams."""
 import os
 import sys
 
@@ -14,11 +15,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import binding as ob  # noqa: E402
 from util import SMALL_SCENES  # noqa: E402
 
-CASES = [("mesh1k", 0, 8, 2, 2, 11), ("cornell", 0, 16, 2, 2, 12), ("check_sphere", 0, 5, 2, 1, 13),
-         ("sphere", 1, 5, 2, 2, 14)]
+CASES = [("mesh1k", 0, 8, 2, 2, 11, 0), ("cornell", 0, 16, 5, 3, 12, 0), ("check_sphere", 0, 5, 2, 1, 13, 0),
+         ("sphere", 1, 5, 4, 4, 14, 0), ("cornell", 0, 6, 4, 4, 15, 1), ("mesh1k", 0, 8, 3, 2, 16, 1)]
 out = {}
-for name, integ, depth, sx, sy, seed in CASES:
-    film, _ = ob.OracleScene(SMALL_SCENES[name]()).render(integrator=integ, max_depth=depth, spp=(sx, sy), seed=seed)
-    out[f"{name}-{integ}-{depth}-{sx}-{sy}-{seed}"] = film
+for name, integ, depth, sx, sy, seed, sampler in CASES:
+    film, _ = ob.OracleScene(SMALL_SCENES[name]()).render(integrator=integ, max_depth=depth, spp=(sx, sy), seed=seed, sampler=sampler)
+    out[f"{name}-{integ}-{depth}-{sx}-{sy}-{seed}-{sampler}"] = film
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "render_golden.npz"), **out)
 print({k: v.shape for k, v in out.items()})

@@ -102,26 +102,41 @@ def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
     assert psnr(gpu.film_to_rgb(film), oracle.film_write_rgb(ref)) >= 50.0
 
 
-def test_two_launch_frame_is_scheduling_only(gpu, oracle, monkeypatch):
-    """Frames of few long pixels per lane are rendered in two launches with the pixels re-ordered by cost in
-    between (capi.cpp render_device; forced here with PBRT_HIP_TWO_PHASE=1).  The film must not depend on it: ragged
-    image, three ranks, and the one-launch path forced through PBRT_HIP_TWO_PHASE=0, all bit-equal to the oracle."""
+def test_item_handout_is_scheduling_only(gpu, oracle, monkeypatch):
+    """A pixel's samples run in eight chunks (work items with their own RNG stream and partial film sum)
+    that any lane of any wave may take in any order.  The film must not depend on who takes what: ragged image, three
+    ranks, a grid of 5 one-wave workgroups (every lane renders hundreds of items) and one of a single hand-out region,
+    all bit-equal to the oracle, with the oracle's canonical counters."""
     sd = scenes.cornell_scene(200, 136)
     ref, rst = oracle.OracleScene(sd).render(max_depth=4, spp=(8, 9), seed=5)
-    monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "1")
     with gpu.Scene(sd) as sc:
         full, st = sc.render(max_depth=4, spp=(8, 9), seed=5, counters=True)
         acc = np.zeros_like(full)
         for r in range(3):
             part, _ = sc.render(max_depth=4, spp=(8, 9), seed=5, rank=r, world_size=3)
             acc += part
-        monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "0")
+        monkeypatch.setenv("PBRT_HIP_RENDER_WORKGROUPS", "5")
+        few, _ = sc.render(max_depth=4, spp=(8, 9), seed=5)
+        monkeypatch.setenv("PBRT_HIP_RENDER_WORKGROUPS", "300")
+        monkeypatch.setenv("PBRT_HIP_REGIONS", "1")
         one, _ = sc.render(max_depth=4, spp=(8, 9), seed=5)
-    assert_bit_equal(full, ref, "two-launch film")
-    assert_bit_equal(acc, ref, "two-launch film, union of 3 ranks")
-    assert_bit_equal(one, ref, "one-launch film")
+    assert_bit_equal(full, ref, "film")
+    assert_bit_equal(acc, ref, "film, union of 3 ranks")
+    assert_bit_equal(few, ref, "film from 5 persistent waves")
+    assert_bit_equal(one, ref, "film from one hand-out region")
     for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
+
+
+@pytest.mark.parametrize("spp", [(1, 1), (3, 1), (7, 1), (3, 3), (5, 5), (13, 5)])
+def test_sample_chunks(gpu, oracle, spp):
+    """Chunk boundaries floor(c * spp / 8): fewer samples than chunks (empty chunks), spp not a multiple of 8."""
+    sd = SMALL_SCENES["cornell"]()
+    ref, _ = oracle.OracleScene(sd).render(max_depth=5, spp=spp, seed=21)
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(max_depth=5, spp=spp, seed=21)
+    assert_bit_equal(film, ref, f"cornell at {spp[0]}x{spp[1]} spp")
+    assert (film[..., 3] == spp[0] * spp[1]).all()
 
 
 @pytest.mark.parametrize("name,integrator,depth,spp,seed", [
@@ -129,35 +144,103 @@ def test_two_launch_frame_is_scheduling_only(gpu, oracle, monkeypatch):
     ("sphere", INTEGRATOR_DIRECT, 5, (8, 4), 0),        # direct lighting
     ("deep", INTEGRATOR_PATH, 6, (8, 4), 6),            # HBM-overflow variant of the walk
     ("ties", INTEGRATOR_PATH, 8, (6, 6), 5),            # duplicated / coplanar / degenerate geometry
+    ("cornell", INTEGRATOR_PATH, 16, (6, 5), 3),        # shallow tree: two node steps per scheduling check
 ])
-def test_two_launch_frames_on_other_kernel_variants(gpu, oracle, monkeypatch, name, integrator, depth, spp, seed):
-    """The forced two-launch path (pixels parked after spp/32 samples, cost-ordered, resumed) on the other
-    instantiations of the render kernel: film and canonical counters equal the oracle's."""
+@pytest.mark.parametrize("sampler", ["stratified", "sobol"])
+def test_kernel_variants_and_samplers(gpu, oracle, name, integrator, depth, spp, seed, sampler):
+    """Every instantiation of the render kernel (spheres, overflow stack, shallow / deep trees, exact walk) with both
+    samplers -- the stratified one of DESIGN.md 3.1 and the padded (0,2)-sequence of 3.10: film and canonical counters
+    equal the oracle's."""
     sd = SMALL_SCENES[name]()
-    ref, rst = oracle.OracleScene(sd).render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
-    monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "1")
+    ref, rst = oracle.OracleScene(sd).render(integrator=integrator, max_depth=depth, spp=spp, seed=seed, sampler=sampler)
     with gpu.Scene(sd) as sc:
-        film, st = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed, counters=True)
-        film2, _ = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
-    assert_bit_equal(film, ref, f"{name} film (two launches, exact walk)")
-    assert_bit_equal(film2, ref, f"{name} film (two launches)")
+        film, st = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed, counters=True, sampler=sampler)
+        film2, _ = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed, sampler=sampler)
+    assert_bit_equal(film, ref, f"{name} film ({sampler}, exact walk)")
+    assert_bit_equal(film2, ref, f"{name} film ({sampler})")
     for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
 
 
-def test_rank_without_tiles(gpu, oracle, monkeypatch):
+def test_sobol_sampler_converges_faster(gpu, oracle):
+    """Sanity of the (0,2)-sequence sampler as a sampler: at equal sample counts the image is closer to a converged
+    reference than the stratified one's on a directly lit scene (smooth integrand, where low discrepancy pays)."""
+    sd = SMALL_SCENES["sphere"]()
+    with gpu.Scene(sd) as sc:
+        conv, _ = sc.render(integrator=INTEGRATOR_DIRECT, spp=(32, 32), seed=1)
+        a, _ = sc.render(integrator=INTEGRATOR_DIRECT, spp=(4, 4), seed=2)
+        b, _ = sc.render(integrator=INTEGRATOR_DIRECT, spp=(4, 4), seed=2, sampler="sobol")
+    def mse(f):
+        return float(((f[..., :3] / f[..., 3:4] - conv[..., :3] / conv[..., 3:4]) ** 2).mean())
+    assert mse(b) < 1.5 * mse(a)  # (never much worse; usually better)
+
+
+def test_render_limits(gpu):
+    """sample counts beyond the 20-bit field, depths beyond the 10-bit field, a box filter radius other than 0.5
+    and a second render while one is in flight are refused with an error instead of hanging the device."""
+    from pbrt_amd import _lib
+    sd = SMALL_SCENES["cornell"]()
+    with gpu.Scene(sd) as sc:
+        for kw, code in ((dict(spp=(2048, 1024)), -4), (dict(spp=(1, 1), max_depth=1024), -4), (dict(spp=(1, 1), filter_width=(1.0, 0.5)), -4),
+                         (dict(spp=(1, 1), sampler=7), -1)):
+            with pytest.raises(_lib.PbrtHipError) as e:
+                sc.render(**kw)
+            assert e.value.code == code, (kw, str(e.value))
+        film, _ = sc.render(spp=(1024, 1024 // 1024), max_depth=1023)  # the limits themselves are fine (2^10 samples here)
+        assert np.isfinite(film).all()
+        import torch
+        slab = torch.empty(max(sc.slab_floats() // 4, 1), 4, device="cuda")
+        sc.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, spp=(2, 2))
+        with pytest.raises(_lib.PbrtHipError) as e:
+            sc.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, spp=(2, 2))
+        assert "in flight" in str(e.value)
+        sc.render_wait()
+        sc.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, spp=(2, 2))
+        sc.render_wait()
+
+
+@pytest.mark.parametrize("n_gpus", [1, 2])
+def test_multi_gpu_render_in_one_process(gpu, oracle, n_gpus):
+    """pbrt_hip_multi_*: the scene replicated device to device, one host thread + stream per GPU, ONE RCCL gather
+    (ncclGather on communicators from ncclCommInitAll) and the assembly on GPU 0 -- the film must equal the oracle's
+    and the single-GPU path's bit for bit.  n_gpus = 1 runs the same RCCL calls on a one-rank communicator, so the
+    path is exercised on a single-GPU box as well; n_gpus = 2 needs two devices."""
+    if gpu.device_count() < n_gpus:
+        pytest.skip(f"needs {n_gpus} GPUs")
+    sd = scenes.cornell_scene(200, 136)  # 4 x 3 super-tiles, ragged edges
+    kw = dict(max_depth=4, spp=(3, 2), seed=8)
+    ref, _ = oracle.OracleScene(sd).render(**kw)
+    with gpu.MultiScene(sd, n_gpus) as ms:
+        assert ms.n_gpus == n_gpus
+        film, stats = ms.render(**kw)
+        again, _ = ms.render(**kw)
+        import torch
+        w, h = sd.crop_size()
+        dev = np.empty((h, w, 4), np.float32)
+        torch.cuda.synchronize()
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(dev.ctypes.data_as(C.c_void_p), C.c_void_p(ms.film_device_ptr()), dev.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    assert_bit_equal(film, ref, f"film of {n_gpus} GPU(s) in one process")
+    assert_bit_equal(again, ref, "second frame of the same handle")
+    assert_bit_equal(dev, ref, "the assembled film on GPU 0")
+    assert len(stats) == n_gpus and sum(s["samples"] for s in stats) == 200 * 136 * 6
+    one, _ = gpu.render_multi(sd, n_gpus, **kw)  # create + render + destroy in one call (what world_end would do)
+    assert_bit_equal(one, ref, "pbrt_hip_render_multi")
+    with pytest.raises(gpu.api._lib.PbrtHipError):
+        gpu.MultiScene(sd, gpu.device_count() + 1)
+
+
+def test_rank_without_tiles(gpu, oracle):
     """A frame of one 64x64 super-tile split over three ranks: ranks 1 and 2 own nothing and must return an empty
-    (all-zero) film, with and without the two-launch path (found by the randomised tests: a division by the zero
-    workgroups of such a rank)."""
+    (all-zero) film (found by the randomised tests of round 1: a division by the zero workgroups of such a rank)."""
     sd = scenes.cornell_scene(40, 33)
     ref, _ = oracle.OracleScene(sd).render(max_depth=3, spp=(2, 2), seed=4)
-    for two in ("0", "1"):
-        monkeypatch.setenv("PBRT_HIP_TWO_PHASE", two)
-        with gpu.Scene(sd) as sc:
-            parts = [sc.render(max_depth=3, spp=(2, 2), seed=4, rank=r, world_size=3) for r in range(3)]
-        assert_bit_equal(parts[0][0], ref, "rank 0 holds the whole frame")
-        for film, st in parts[1:]:
-            assert not film.any() and st["samples"] == 0
+    with gpu.Scene(sd) as sc:
+        parts = [sc.render(max_depth=3, spp=(2, 2), seed=4, rank=r, world_size=3) for r in range(3)]
+    assert_bit_equal(parts[0][0], ref, "rank 0 holds the whole frame")
+    for film, st in parts[1:]:
+        assert not film.any() and st["samples"] == 0
 
 
 def test_golden_fixture(gpu):
@@ -166,10 +249,10 @@ def test_golden_fixture(gpu):
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_golden.npz"))
     for key in g.files:
-        name, integ, depth, sx, sy, seed = key.split("-")
+        name, integ, depth, sx, sy, seed, sampler = key.split("-")
         sd = SMALL_SCENES[name]()
         with gpu.Scene(sd) as sc:
-            film, _ = sc.render(integrator=int(integ), max_depth=int(depth), spp=(int(sx), int(sy)), seed=int(seed))
+            film, _ = sc.render(integrator=int(integ), max_depth=int(depth), spp=(int(sx), int(sy)), seed=int(seed), sampler=int(sampler))
         assert_bit_equal(film, g[key], key)
 
 
@@ -254,9 +337,8 @@ def test_full_size_properties_c2(gpu, oracle):
 
 
 def test_c2_full_frame_eight_rank_shares_add_up(gpu):
-    """BASELINE config C2 at its full size and sample count: the frame rendered by one rank (one launch) equals, bit
-    for bit, the sum of the eight shares of an 8-GPU job (each rendered in two launches with the cost-ordered
-    hand-out): sharding, parking / resuming pixels and the XCD-aware hand-out change no sample."""
+    """BASELINE config C2 at its full size and sample count: the frame rendered by one rank equals, bit for bit, the sum
+    of the eight shares of an 8-GPU job: sharding and the dynamic, XCD-aware hand-out of work items change no sample."""
     sd = scenes.random_mesh_scene(100_000, 1024, 1024)
     with gpu.Scene(sd) as sc:
         full, st = sc.render(max_depth=8, spp=(16, 16), seed=0)
@@ -351,6 +433,41 @@ def test_full_size_properties_c3(gpu, oracle):
         win = scenes.random_mesh_scene(1_000_000, 2048, 2048, crop=crop)
         ref, _ = oracle.OracleScene(win).render(max_depth=8, spp=(2, 1), seed=0)
         assert_bit_equal(film[y0:y0 + 16, x0:x0 + 16], ref, f"window at {x0},{y0}")
+
+
+def test_full_size_properties_c1(gpu, oracle):
+    """BASELINE config C1 at its full size and sample count (analytic sphere + point light, 1024x1024, 8x8 = 64 spp,
+    direct lighting): weight == spp, finite, idempotent; three 32x32 windows of the frame against the oracle."""
+    sd = scenes.sphere_scene(1024, 1024)
+    kw = dict(integrator=INTEGRATOR_DIRECT, max_depth=5, spp=(8, 8), seed=0)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(**kw)
+        again, _ = sc.render(**kw)
+    assert film.shape == (1024, 1024, 4) and (film[..., 3] == 64).all() and np.isfinite(film).all() and (film[..., 1] >= 0).all()
+    assert_bit_equal(film, again, "idempotence")
+    assert st["samples"] == 1024 * 1024 * 64
+    assert film[..., 1].max() > 0  # the lit sphere is in the frame
+    for (x0, y0) in [(0, 0), (480, 512), (992, 992)]:
+        crop = (x0 / 1024, (x0 + 32) / 1024, y0 / 1024, (y0 + 32) / 1024)
+        ref, _ = oracle.OracleScene(scenes.sphere_scene(1024, 1024, crop=crop)).render(**kw)
+        assert_bit_equal(film[y0:y0 + 32, x0:x0 + 32], ref, f"C1 window at {x0},{y0}")
+
+
+def test_full_size_properties_c4(gpu, oracle):
+    """BASELINE config C4's full 4096x4096 frame (Cornell-style box, path, maxdepth 16) at 2x2 spp: weight == spp,
+    finite, idempotent; three 32x32 windows of the frame against the oracle."""
+    sd = scenes.cornell_scene(4096, 4096)
+    kw = dict(max_depth=16, spp=(2, 2), seed=0)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(**kw)
+        again, _ = sc.render(**kw)
+    assert film.shape == (4096, 4096, 4) and (film[..., 3] == 4).all() and np.isfinite(film).all() and (film[..., 1] >= 0).all()
+    assert_bit_equal(film, again, "idempotence")
+    assert st["samples"] == 4096 * 4096 * 4
+    for (x0, y0) in [(0, 0), (2048, 1024), (4064, 4064)]:
+        crop = (x0 / 4096, (x0 + 32) / 4096, y0 / 4096, (y0 + 32) / 4096)
+        ref, _ = oracle.OracleScene(scenes.cornell_scene(4096, 4096, crop=crop)).render(**kw)
+        assert_bit_equal(film[y0:y0 + 32, x0:x0 + 32], ref, f"C4 window at {x0},{y0}")
 
 
 def test_c4_window_at_full_spp(gpu, oracle):
@@ -458,22 +575,24 @@ def _random_scene(seed):
 def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     """Triangle counts 0..300 (with duplicates and degenerate triangles), random materials (mirrors, emitters),
     0-3 lights of every kind, 0-2 spheres, random camera / resolution / crop / strata / depth / integrator /
-    seed / rank split; odd seeds force the two-launch frame, every third builds the tree on the device."""
+    seed / rank split; odd seeds use the Sobol sampler, every fourth a tiny grid of persistent waves, every third
+    builds the tree on the device."""
     sd, rng = _random_scene(seed)
     integ = INTEGRATOR_DIRECT if seed % 5 == 4 else INTEGRATOR_PATH
     depth, spp, rseed = int(rng.integers(0, 12)), (int(rng.integers(1, 7)), int(rng.integers(1, 6))), int(rng.integers(0, 1 << 20))
     world = int(rng.integers(1, 4))
-    ref, rst = oracle.OracleScene(sd).render(integrator=integ, max_depth=depth, spp=spp, seed=rseed)
-    if seed % 2 and spp[0] * spp[1] >= 2:
-        monkeypatch.setenv("PBRT_HIP_TWO_PHASE", "1")
+    sampler = "sobol" if seed % 2 else "stratified"
+    ref, rst = oracle.OracleScene(sd).render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, sampler=sampler)
+    if seed % 4 == 3:
+        monkeypatch.setenv("PBRT_HIP_RENDER_WORKGROUPS", "3")
     with gpu.Scene(sd, builder="gpu" if seed % 3 == 2 else "host") as sc:
         acc = None
         for r in range(world):
-            part, _ = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, rank=r, world_size=world)
+            part, _ = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, rank=r, world_size=world, sampler=sampler)
             acc = part if acc is None else acc + part
         st = None
         if not sc.build_info()["gpu_built"]:
-            _, st = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, counters=True)
+            _, st = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, counters=True, sampler=sampler)
         o, d, tmax = random_rays(3000, seed, inside=2.5)
         hit = sc.intersect(o, d, tmax)
         occ = sc.occluded(o, d, tmax)

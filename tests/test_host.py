@@ -52,6 +52,37 @@ def test_no_device_fails_loudly():
     assert e.value.code == -2 and "no CPU fallback" in str(e.value)
 
 
+@pytest.mark.skipif(pbrt_amd.device_count() > 0, reason="checks the no-device behaviour")
+def test_multi_gpu_entry_points_fail_loudly_without_a_device():
+    """The in-library multi-GPU path (pbrt_hip_multi_* / pbrt_hip_render_multi) has no CPU fallback either."""
+    sd = scenes.cornell_scene(8, 8)
+    with pytest.raises(_lib.PbrtHipError) as e:
+        pbrt_amd.MultiScene(sd, 2)
+    assert e.value.code == -2
+    with pytest.raises(_lib.PbrtHipError) as e:
+        pbrt_amd.render_multi(sd, 0, spp=(1, 1))
+    assert e.value.code == -2
+
+
+def test_shards_partition_the_film_for_any_gpu_count():
+    """Host-side partition / gather index math of the multi-GPU path (pbrt_hip_slab_floats, pbrt_hip_slab_pixel_index): for
+    1..9 ranks and ragged or cropped films every pixel belongs to exactly one rank's slab, rank 0's slab is the
+    largest (the gather's common count), and a slab is whole 64x64 super-tiles."""
+    for (xres, yres, crop) in [(200, 136, (0, 1, 0, 1)), (64, 64, (0, 1, 0, 1)), (1000, 700, (0.1, 0.77, 0.2, 0.9)), (130, 513, (0, 1, 0, 1))]:
+        b = pbrt_amd.film_cropped_bounds(xres, yres, crop)
+        n_px = (b[2] - b[0]) * (b[3] - b[1])
+        for world in range(1, 10):
+            seen = np.zeros(n_px, int)
+            sizes = []
+            for r in range(world):
+                idx = pbrt_amd.slab_pixel_index(xres, yres, crop, r, world)
+                assert len(idx) % 4096 == 0
+                assert len(idx) * 4 == _lib.lib().pbrt_hip_slab_floats(xres, yres, (C.c_float * 4)(*crop), r, world)
+                sizes.append(len(idx))
+                seen[idx[idx >= 0]] += 1
+            assert (seen == 1).all() and sizes[0] == max(sizes)
+
+
 def test_bad_arguments_are_rejected_before_any_device_work():
     sd = scenes.cornell_scene(8, 8)
     sd.mat_id = sd.mat_id.copy()
@@ -323,7 +354,6 @@ def _kernel_notes():
     return out
 
 
-@pytest.mark.xfail(reason="r02 work in progress: the service stage still spills 4-6 VGPRs", strict=False)
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm llvm tools")
 def test_production_kernels_do_not_spill():
     """the production instantiations of render_kernel (no counters, no exact walk) and

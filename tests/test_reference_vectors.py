@@ -1,6 +1,8 @@
 """Pins the oracle (and the product's host pieces) against every known-answer vector the
 reference crate holds for code adjacent to the path.  Each test cites the
 reference file:line the literal values are taken from."""
+import os
+
 import numpy as np
 import pytest
 
@@ -216,3 +218,31 @@ def test_png_reader_decodes_compressed_filtered_files(tmp_path):
         pbrt_amd.read_image(tmp_path / "missing.png")
     with pytest.raises(pbrt_amd._lib.PbrtHipError):
         pbrt_amd.read_image(tmp_path / "x.tga")  # imageio.rs:180
+
+
+def test_sobol_generator_matrices(oracle):
+    """The Sobol' generator matrices the oracle builds from the Joe-Kuo direction numbers (oracle.cpp sobol_matrix;
+    DESIGN.md 3.10): structural properties always, and equality with the reference's SOBOL_MATRICES32
+    (src/core/sobolmatrices.rs:81, 52 columns per dimension; its size test is at :60808-60814) where /root/reference is
+    mounted.  (The reference never uses the table: no sampler exists in the crate.)"""
+    m = oracle.sobol_matrices()
+    assert m.shape[1] == 52 and m.shape[0] >= 2
+    assert [int(v) for v in m[0, :32]] == [1 << (31 - i) for i in range(32)] and not m[0, 32:].any()  # van der Corput
+    for d in range(m.shape[0]):  # column i has its leading one at bit 31 - i: an upper-triangular, invertible matrix
+        for i in range(32):
+            assert int(m[d, i]) >> (31 - i) == 1 or (int(m[d, i]) >> (31 - i)) & 1 == 1
+            assert int(m[d, i]) & ((1 << (31 - i)) - 1) == 0
+    # the first 2^k points of dimensions (1, 2) are a (0, 2)-net: one point in every elementary interval of area 2^-k
+    pts = oracle.sobol_points(64)
+    for a in range(7):
+        nx, ny = 1 << a, 1 << (6 - a)
+        assert len({(int(x * nx), int(y * ny)) for x, y in pts}) == 64
+    path = "/root/reference/src/core/sobolmatrices.rs"
+    if not os.path.exists(path):
+        pytest.skip("reference not mounted")
+    import re
+    text = open(path).read()
+    start = text.index("const SOBOL_MATRICES32")
+    body = text[text.index("[", text.index("=", start)):text.index("];", start)]
+    ref = np.array([int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", body)[:m.size]], np.uint32).reshape(m.shape)
+    assert np.array_equal(m, ref), np.argwhere(m != ref)[:5]
