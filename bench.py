@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the BVH-traversal + path-tracing hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|c4]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|c4|big] [--single-process]
 
 A "step" is one pass of the hot path over the whole workload: every rank renders its 64x64
-super-tiles (one HIP kernel launch) and the film is gathered on rank 0 (one RCCL gather for N>1).
-Default workload = BASELINE.json configs[3], the one the metric/target is quoted on: 1M random
-triangles, 2048x2048, 512 spp (32x16 strata), path integrator maxdepth 8; it fits one GPU, so N=1
-runs all of it and N>1 shards the same frame (strong scaling).  Scene build / upload and image
-writing are outside the timed region; inputs are resident in HBM when timing starts.
+super-tiles (one launch of render_kernel + the merge of the partial sums) and the film is gathered on
+rank 0 (one RCCL gather for N>1).  Default workload = BASELINE.json configs[3], the one the
+metric/target is quoted on: 1M random triangles, 2048x2048, 512 spp (32x16 strata), path integrator
+maxdepth 8; it fits one GPU, so N=1 runs all of it and N>1 shards the same frame (strong scaling).
+Scene build / upload and image writing are outside the timed region; inputs are resident in HBM when
+timing starts.  N>1: one process per GPU under torch.distributed.run (the driver's contract), or
+`--single-process`: all N GPUs from this one process through pbrt_hip_multi_* (one host thread per GPU,
+ncclGather inside the library).
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel = render_kernel, algorithmic bytes
-from the exact visit counters / HIP-event kernel time) and, at N=1, `cpu_baseline` (the CPU oracle
-timed on this box's host cores on a bounded sample of the same workload).
+Rank 0 prints ONE JSON line.  `roofline` (dominant kernel = render_kernel):
+  bound "valu"  the resource the counters show binding: vector-instruction issue.  achieved =
+                VALU issue cycles the launch needs (instructions per ray from the committed PMC profile, priced with the
+                per-class issue costs measured by tools/ubench/valu_issue.hip, x the rays of this launch, counted live)
+                / the kernel's HIP-event time; peak = SIMDs x clock.  frac <= 1 by construction of a roof.
+  hbm           SURVEY 8(d)'s contract figure kept beside it: algorithmic bytes of the CANONICAL walk / kernel time
+                against 8 TB/s (can exceed 1: the scene is cache-resident and the production walk moves fewer bytes),
+                and what the memory-side counters saw (`traffic`, hbm_counter_frac).
+`cpu_baseline` (N=1): the CPU oracle timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -23,7 +32,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured stream)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured stream)
+CLOCK_GHZ = 2.4         # max shader clock (same guide); the clock a kernel holds is lower, so frac is conservative
+SIMDS_PER_CU = 4
 
 WORKLOADS = {
     # name: (scene factory args, integrator, maxdepth, (spp_x, spp_y), description)
@@ -31,6 +42,8 @@ WORKLOADS = {
     "c2": (("mesh", 100_000, 1024), 0, 8, (16, 16), "C2: 100k random triangles in a box, 1024x1024, 256 spp, path maxdepth 8"),
     "c1": (("sphere", 0, 1024), 1, 5, (8, 8), "C1: analytic sphere + point light, 1024x1024, 64 spp, direct lighting"),
     "c4": (("cornell", 0, 4096), 0, 16, (64, 64), "C4: Cornell-style box, 4096x4096, 4096 spp, path maxdepth 16"),
+    # not a BASELINE config: the out-of-cache regime (0.9 GB of nodes + triangles against the 256 MiB Infinity Cache)
+    "big": (("mesh", 12_000_000, 2048), 0, 8, (8, 8), "BIG (out of cache): 12M random triangles in a box, 2048x2048, 64 spp, path maxdepth 8"),
 }
 
 
@@ -126,9 +139,12 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, nargs=2, default=None, help="override strata (diagnostics; invalid as a headline)")
     ap.add_argument("--builder", default="host", choices=["host", "gpu"],
-                    help="accelerator builder: host binned SAH (headline) or the device LBVH (same film, no canonical counters)")
+                    help="accelerator builder: host binned SAH (headline) or the device builder (same film)")
+    ap.add_argument("--sampler", default="stratified", choices=["stratified", "sobol"])
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from ONE process through pbrt_hip_multi_* (ncclGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-counters", action="store_true", help="skip the untimed counting pass (roofline.achieved = null)")
+    ap.add_argument("--no-counters", action="store_true", help="skip the untimed counting passes (roofline.achieved = null)")
     args = ap.parse_args()
 
     import torch
@@ -140,9 +156,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    in_process = args.single_process and args.gpus > 1
+    if world != args.gpus and not in_process:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (or --single-process)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available() or pbrt_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: pbrt_amd has no CPU fallback")
@@ -152,8 +169,12 @@ def main():
     if backend == "nccl" and world > torch.cuda.device_count():
         raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s): RCCL needs one GPU per rank")
     torch.cuda.set_device(device_index)
-    if world > 1:
+    # under torch.distributed.run the process group is ALWAYS initialised, also for one rank: the RCCL path
+    # (init with device_id, barrier, all_reduce, gather) then runs on single-GPU boxes as well
+    use_pg = "RANK" in os.environ and not in_process
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
@@ -164,22 +185,29 @@ def main():
         spp = tuple(args.spp)
     t0 = time.time()
     sd = make_scene_data(kind, n, res)
-    scene = pbrt_amd.Scene(sd, device=device_index, builder=args.builder)
+    if in_process:
+        scene = pbrt_amd.MultiScene(sd, args.gpus, builder=args.builder)
+        args.no_counters = True
+        info = {"n_nodes": None, "depth": None, "device_bytes": None}
+    else:
+        scene = pbrt_amd.Scene(sd, device=device_index, builder=args.builder)
+        info = scene.info()
     if args.builder == "gpu":
         args.no_counters = True  # the canonical counters exist only for the host-built tree
-    info = scene.info()
     build_s = time.time() - t0
-    kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=0)
+    kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=0, sampler=args.sampler)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
-        film, st = pdist.render_sharded(scene, rank, world, **kw)
-        return film, st
+        if in_process:
+            film, sts = scene.render(host_film=False, **kw)
+            return None, {"kernel_ms": max(s["kernel_ms"] for s in sts), "samples": sum(s["samples"] for s in sts)}
+        return pdist.render_sharded(scene, rank, world, **kw)
 
     for _ in range(args.warmup):
         step()
@@ -193,18 +221,27 @@ def main():
         local_samples = st["samples"]
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     total_samples = res * res * spp[0] * spp[1]
     value = total_samples * args.steps / elapsed / 1e6
+    if in_process:  # the host copy of the film for the checks below (outside the timed region)
+        film_np, _ = scene.render(host_film=True, **kw)
+        film = torch.from_numpy(film_np)
 
-    # untimed counting pass: exact nodes-visited / triangles-tested of THIS rank's share (the
-    # counting instantiation of the same kernel; equal to the oracle's counters, tests/test_gpu_parity.py)
-    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+    n_simd = torch.cuda.get_device_properties(device_index).multi_processor_count * SIMDS_PER_CU
+    peak = n_simd * CLOCK_GHZ  # G issue-cycles/s
+    roof = {"bound": "valu", "achieved": None, "peak": peak, "unit": "G VALU issue-cycles/s", "frac": None, "traffic": None,
+            "kernel": "render_kernel"}
     avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    roof["kernel_ms"] = avg_kernel_ms
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
     if not args.no_counters:
+        # untimed counting pass: exact nodes-visited / triangles-tested of THIS rank's share (the counting instantiation
+        # of the same kernel; equal to the oracle's counters, tests/test_gpu_parity.py) and the rays of the launch
         slab = torch.empty(max(scene.slab_floats(rank, world) // 4, 1), 4, device="cuda")
         scene.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, rank=rank, world_size=world,
                             counters=True, **kw)
@@ -213,51 +250,59 @@ def main():
         alg_bytes = bps * local_samples  # per launch of this rank's kernel
         ach = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         rays = cst["camera_rays"] + cst["bounce_rays"] + cst["shadow_rays"]
-        roof.update({
-            "achieved": ach, "frac": ach / HBM_PEAK_GBS, "kernel": "render_kernel", "kernel_ms": avg_kernel_ms,
-            "bytes_per_sample": bps, "algorithmic_bytes_per_launch": alg_bytes,
-            "rays_per_sample": rays / cst["samples"], "nodes_per_ray": cst["nodes_visited"] / rays,
-            "tris_per_ray": cst["tris_tested"] / rays, "mrays_per_s": rays / (avg_kernel_ms * 1e-3) / 1e6,
-            "frac_of_measured_stream_6290": ach / 6290.0,
-            "note": "algorithmic bytes = SURVEY 8d formula on the CANONICAL binary-BVH walk (exact counters, equal to the "
-                    "oracle's) / HIP-event kernel time of one frame (one launch of render_kernel + the merge of the partial sums); it can exceed the HBM peak because the scene "
-                    f"({info['device_bytes'] / 1e6:.0f} MB) sits in the 256 MiB Infinity Cache and the production kernel walks a "
-                    "quantised 4-wide form of the tree that moves fewer bytes (see kernel_*)",
-        })
-        # what the production kernel itself fetches: 64-byte quad nodes + 48-byte triangles (+ the per-ray path-state
-        # record traffic, 160 B), from its own walk counters
+        rays_per_s = rays / (avg_kernel_ms * 1e-3)
+        roof.update({"rays_per_launch": rays, "rays_per_sample": rays / cst["samples"], "mrays_per_s": rays_per_s / 1e6})
+        # what the production kernel itself fetches: 64-byte quad nodes + 48-byte triangles + the path-state records
+        # (3 x 16 B read + written per ray, + 2 x 16 B of light-sample / partial-sum records now and then: ~112 B), from its own counters
         scene.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, rank=rank, world_size=world,
                             counters="walk", **kw)
         wst = scene.render_wait()
-        kbytes = (64.0 * wst["nodes_visited"] + 48.0 * wst["tris_tested"] + 160.0 * rays) / wst["samples"] + 28.0 + 16.0 / (spp[0] * spp[1])
-        roof.update({"kernel_bytes_per_sample": kbytes, "kernel_fetches_per_ray": wst["nodes_visited"] / rays,
-                     "kernel_tris_per_ray": wst["tris_tested"] / rays,
-                     "kernel_gbps": kbytes * local_samples / (avg_kernel_ms * 1e-3) / 1e9})
-    else:
-        roof.update({"kernel": "render_kernel", "kernel_ms": avg_kernel_ms})
+        kbytes = (64.0 * wst["nodes_visited"] + 48.0 * wst["tris_tested"] + 112.0 * rays) / wst["samples"] + 28.0 + 128.0 / (spp[0] * spp[1])
+        roof["hbm"] = {
+            "note": "SURVEY 8(d) contract figure: algorithmic bytes of the CANONICAL binary-BVH walk (exact counters, equal to the "
+                    "oracle's) / HIP-event kernel time, against the 8 TB/s HBM spec.  It is not a roof of this workload when "
+                    f"cache_resident: the scene ({info['device_bytes'] / 1e6:.0f} MB) then sits in the 256 MiB Infinity Cache and the "
+                    "production kernel walks a quantised 4-wide form of the tree that moves fewer bytes (kernel_*)",
+            "cache_resident": bool(info["device_bytes"] < 256 * 2 ** 20),
+            "achieved_gbps": ach, "peak_gbps": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS, "bytes_per_sample": bps,
+            "algorithmic_bytes_per_launch": alg_bytes, "nodes_per_ray": cst["nodes_visited"] / rays, "tris_per_ray": cst["tris_tested"] / rays,
+            "kernel_bytes_per_sample": kbytes, "kernel_fetches_per_ray": wst["nodes_visited"] / rays,
+            "kernel_tris_per_ray": wst["tris_tested"] / rays, "kernel_gbps": kbytes * local_samples / (avg_kernel_ms * 1e-3) / 1e9,
+        }
+        if pmc and "valu_issue_cycles_per_ray" in pmc:
+            # VALU roof: the launch's issue-cycle demand (per ray from the committed profile x rays counted live) / time
+            roof["achieved"] = pmc["valu_issue_cycles_per_ray"] * rays_per_s / 1e9
+            roof["frac"] = roof["achieved"] / peak
+            roof["valu"] = {k: pmc.get(k) for k in ("valu_instructions_per_ray", "valu_issue_cycles_per_ray", "mean_issue_cycles_per_instruction",
+                                                    "valu_busy_frac_at_profile_clock", "valu_busy_bracket", "lane_utilisation", "l2_hit_rate",
+                                                    "clock_ghz_in_profile", "round")}
+            roof["valu"]["source"] = f"{os.path.relpath(pmc_path, ROOT)} (rocprofv3 --pmc passes of tools/measure_round.sh) + profiles/r02_valu_issue_ubench.txt"
     # HBM-side traffic cannot be read in-process: it comes from the separate rocprofv3 --pmc passes of this same
-    # workload whose summary is committed under profiles/ (tools/summarize_profile.py); null when there is none.
-    pmc = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-    if world == 1 and not args.spp and os.path.exists(pmc):
-        p = json.load(open(pmc))
-        roof["traffic"] = p["traffic_bytes_raw"]
-        roof["traffic_note"] = (f"(FETCH_SIZE + WRITE_SIZE) x 1024 per frame from {os.path.relpath(pmc, ROOT)} "
-                                f"(round {p.get('round', '?')} kernel, {p['avg_ms']:.0f} ms); FETCH_SIZE counts L2-miss requests "
-                                "incl. Infinity-Cache hits and is uncalibrated for 16-B gathers (x2 if the wide-stream correction applied)")
+    # workload whose summary is committed under profiles/; null when there is none.
+    if pmc and world == 1 and not args.spp and "traffic_bytes_raw" in pmc:
+        roof["traffic"] = pmc["traffic_bytes_raw"]
+        roof["hbm_counter_frac"] = pmc["traffic_bytes_raw"] / (pmc["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["traffic_note"] = (f"(FETCH_SIZE + WRITE_SIZE) x 1024 per frame from {os.path.relpath(pmc_path, ROOT)} "
+                                f"(round {pmc.get('round', '?')} kernel, {pmc['avg_ms']:.0f} ms per frame); FETCH_SIZE counts L2-miss requests "
+                                "incl. Infinity-Cache hits and is uncalibrated for 16-B gathers (x2 if the wide-stream correction applied); "
+                                "hbm_counter_frac = that traffic / that time / 8 TB/s")
 
     out = {
         "metric": "Msamples/sec (rays/sec) at 1/2/4/8 GPUs; PSNR vs CPU reference",
-        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": descr, "triangles": int(sd.idx.shape[0]), "resolution": [res, res], "spp": spp[0] * spp[1],
-                   "maxdepth": depth, "sharding": f"64x64 super-tiles round-robin over {world} rank(s), one gather",
+                   "maxdepth": depth, "sampler": args.sampler,
+                   "sharding": (f"64x64 super-tiles round-robin over {args.gpus} GPU(s), one gather"
+                                + (" (one process, ncclGather inside the library)" if in_process else " (one rank per GPU)")),
                    "bvh_nodes": info["n_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
-                   "scene_build_s": round(build_s, 2), "accelerator": dict(scene.build_info(), builder=args.builder)},
+                   "scene_build_s": round(build_s, 2),
+                   "accelerator": dict(scene.build_info(), builder=args.builder) if not in_process else {"builder": args.builder}},
         "roofline": roof,
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not in_process and not args.no_cpu_baseline and args.workload != "big":
             out["cpu_baseline"] = cpu_baseline(kind, n, res, integrator, depth, spp,
                                                gpu_film=film.cpu().numpy() if film is not None else None)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
@@ -268,7 +313,7 @@ def main():
                                  "mean_Y": float(f[..., 1].mean() / (spp[0] * spp[1]))}
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -33,12 +33,14 @@ void usage() {
                "      --quick           quick render: a quarter of the samples per pixel\n"
                "  -q, --quiet           squelch all non-error output\n"
                "  -v, --verbose         enable extra logging output\n"
-               "  -o, --outfile <FILE>  path to store the rendered output\n");
+               "  -o, --outfile <FILE>  path to store the rendered output\n"
+               "      --gpus <N>        GPUs of this node to render on (default: all visible ones; one process, RCCL gather)\n");
 }
 }  // namespace
 
 int main(int argc, char **argv) {
   bool quick = false, quiet = false, verbose = false;
+  int gpus = 0;  // 0 = all visible
   std::string outfile;
   std::vector<std::string> scenes;
   for (int i = 1; i < argc; i++) {
@@ -52,6 +54,7 @@ int main(int argc, char **argv) {
     else if (a == "-q" || a == "--quiet") quiet = true;
     else if (a == "-v" || a == "--verbose") verbose = true;
     else if (a == "-o" || a == "--outfile") outfile = value("--outfile");
+    else if (a == "--gpus") gpus = std::atoi(value("--gpus"));
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "error: unknown option %s\n", a.c_str()); usage(); return 2; }
     else scenes.push_back(a);
@@ -76,18 +79,19 @@ int main(int argc, char **argv) {
     logf(2, "%s: %u triangles, %u spheres, %u lights, %dx%d, %u spp", path.c_str(), desc.n_tris, desc.n_spheres, desc.n_lights,
          desc.xres, desc.yres, rd.spp_x * rd.spp_y);
     const auto t0 = std::chrono::steady_clock::now();
-    pbrt_hip_scene *scene = nullptr;
-    int rc = pbrt_hip_scene_create(&desc, -1, &scene);
     int32_t b[4];
     pbrt_hip_film_cropped_bounds(desc.xres, desc.yres, desc.crop, b);
     const int w = b[2] - b[0], h = b[3] - b[1];
+    std::vector<float> film((size_t)w * h * 4), rgb((size_t)w * h * 3);
+    // every GPU of the node from this one process (the reference binary is one process, bin/pbrt.rs:72-83): the scene
+    // is copied device to device, GPU g renders the super-tiles t % n == g, one ncclGather assembles the film
+    const int n = gpus > 0 ? gpus : pbrt_hip_device_count();
+    std::vector<pbrt_hip_stats> per_gpu(n > 0 ? n : 1);
+    const int rc = pbrt_hip_render_multi(&desc, &rd, n, film.data(), per_gpu.data());
     pbrt_hip_loaded_free(loaded);
     if (rc != 0) { logf(1, "%s: %s", path.c_str(), pbrt_hip_last_error()); return 1; }
-    std::vector<float> film((size_t)w * h * 4), rgb((size_t)w * h * 3);
-    pbrt_hip_stats st;
-    rc = pbrt_hip_render(scene, &rd, film.data(), &st);
-    pbrt_hip_scene_destroy(scene);
-    if (rc != 0) { logf(1, "%s: %s", path.c_str(), pbrt_hip_last_error()); return 1; }
+    pbrt_hip_stats st = per_gpu[0];
+    for (int g = 1; g < n; g++) { st.samples += per_gpu[g].samples; if (per_gpu[g].kernel_ms > st.kernel_ms) st.kernel_ms = per_gpu[g].kernel_ms; }
     pbrt_hip_film_to_rgb(film.data(), (int64_t)w * h, film_scale, rgb.data());  // Film::write_image, film.rs:340-372
     std::string out = outfile.empty() ? filename : outfile;
     if (out.rfind('.') == std::string::npos || out.rfind('.') < out.rfind('/') + 1) out += ".png";

@@ -754,12 +754,25 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
       if (in_options("Sampler")) {
         out->sampler_name = name;
         if (name == "stratified") {
+          out->sampler = PBRT_HIP_SAMPLER_STRATIFIED;
           out->spp_x = (uint32_t)std::max(1, ps.one_int("xsamples", 4));
           out->spp_y = (uint32_t)std::max(1, ps.one_int("ysamples", 4));
           ps.find("jitter", "bool"); ps.find("dimensions", "integer");
-        } else {  // every other sampler name is served by the stratified sampler
+        } else {
+          // the low-discrepancy names ("halton" is the reference's default, api.rs:235; it ships Sobol' matrices,
+          // sobolmatrices.rs:81, and no sampler) are served by the padded (0,2)-sequence sampler of DESIGN.md 3.10,
+          // "random" and anything unknown by the stratified one; pixelsamples = spp_x * spp_y either way
           auto s = strata_for(ps.one_int("pixelsamples", 16));
           out->spp_x = s.first; out->spp_y = s.second;
+          if (name == "halton" || name == "sobol" || name == "02sequence" || name == "lowdiscrepancy" || name == "zerotwosequence" ||
+              name == "maxmindist") {
+            out->sampler = PBRT_HIP_SAMPLER_SOBOL;
+            if (name != "sobol" && name != "02sequence" && name != "lowdiscrepancy" && name != "zerotwosequence")
+              api.warn("Sampler \"" + name + "\": served by the (0,2)-sequence (Sobol') sampler");
+          } else {
+            out->sampler = PBRT_HIP_SAMPLER_STRATIFIED;
+            if (name != "random") api.warn("Sampler \"" + name + "\" is unknown: the stratified sampler is used");
+          }
         }
         api.report_unused("Sampler", ps);
       }

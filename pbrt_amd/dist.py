@@ -13,33 +13,51 @@ import numpy as np
 from . import api
 
 
-def slab_index_tensor(xres, yres, crop, rank, world_size, device="cpu"):
-    """int64 tensor: for every float4 slot of `rank`'s slab, the row-major pixel index in the
-    cropped film, or -1 for padding (host geometry from pbrt_hip_slab_pixel_index)."""
+_index_cache = {}
+
+
+def slab_index_tensors(xres, yres, crop, world_size, device="cpu"):
+    """Per rank: (int64 index tensor of the slab's pixels inside the film, boolean mask of the slab slots that are
+    inside) -- built once per (film geometry, world size, device) and kept: the geometry of a job never changes, and
+    ADVICE r01 found the per-step rebuild + host-to-device copy inside bench.py's timed region."""
     import torch
-    return torch.from_numpy(api.slab_pixel_index(xres, yres, crop, rank, world_size)).to(device)
+    key = (xres, yres, tuple(float(c) for c in crop), world_size, str(device))
+    if key not in _index_cache:
+        per_rank = []
+        for r in range(world_size):
+            idx = torch.from_numpy(api.slab_pixel_index(xres, yres, crop, r, world_size))
+            keep = idx >= 0
+            per_rank.append((idx[keep].to(device), keep.to(device)))
+        _index_cache[key] = per_rank
+    return _index_cache[key]
 
 
 def max_slab_slots(xres, yres, crop, world_size):
     """slab slots of the rank that owns the most super-tiles (rank 0): the gather's common size"""
-    return len(api.slab_pixel_index(xres, yres, crop, 0, world_size))
+    import ctypes as C
+    from ._lib import lib
+    return int(lib().pbrt_hip_slab_floats(xres, yres, (C.c_float * 4)(*crop), 0, world_size)) // 4
 
 
-def assemble_film(slabs, xres, yres, crop, world_size):
-    """Scatter the gathered slabs (list indexed by rank, each [slots, 4], possibly padded at the
-    end) into the row-major film [h, w, 4]."""
+def assemble_film(slabs, xres, yres, crop, world_size, scene=None):
+    """Scatter the gathered slabs (list indexed by rank, each [slots, 4], possibly padded at the end) into the
+    row-major film [h, w, 4].  Device slabs of a `scene` go through the library's scatter kernel
+    (pbrt_hip_film_assemble_device); host slabs (the gloo tests) through cached index tensors."""
     import torch
     b = api.film_cropped_bounds(xres, yres, crop)
     w, h = max(b[2] - b[0], 0), max(b[3] - b[1], 0)
     film = torch.zeros(h * w, 4, dtype=torch.float32, device=slabs[0].device)
-    for r in range(world_size):
-        idx = slab_index_tensor(xres, yres, crop, r, world_size, device=film.device)
-        keep = idx >= 0
-        film[idx[keep]] = slabs[r][: idx.numel()][keep]
+    if scene is not None and film.is_cuda:
+        stream = torch.cuda.current_stream().cuda_stream
+        for r in range(world_size):
+            scene.film_assemble_device(slabs[r].data_ptr(), r, world_size, film.data_ptr(), stream)
+        return film.view(h, w, 4)
+    for r, (idx, keep) in enumerate(slab_index_tensors(xres, yres, crop, world_size, film.device)):
+        film[idx] = slabs[r][: keep.numel()][keep]
     return film.view(h, w, 4)
 
 
-def gather_film(local_slab, xres, yres, crop, rank, world_size, group=None):
+def gather_film(local_slab, xres, yres, crop, rank, world_size, group=None, scene=None):
     """Gather every rank's slab on rank 0 and assemble the film there (None elsewhere).
     `local_slab`: [slots_of_this_rank, 4] float32 tensor on the rank's device."""
     import torch
@@ -48,15 +66,19 @@ def gather_film(local_slab, xres, yres, crop, rank, world_size, group=None):
     dev = local_slab.device
     if world_size > 1 and dist.get_backend(group) == "gloo":
         dev = torch.device("cpu")  # gloo cannot gather device tensors: stage through the host
-    send = torch.zeros(n, 4, dtype=torch.float32, device=dev)
-    send[: local_slab.shape[0]] = local_slab.to(dev)
-    if world_size == 1:
-        return assemble_film([send], xres, yres, crop, 1)
+    if local_slab.shape[0] == n and local_slab.device == dev:
+        send = local_slab  # (rank 0's slab has the common size already)
+    else:
+        send = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+        send[: local_slab.shape[0]] = local_slab.to(dev)
+    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+        return assemble_film([send], xres, yres, crop, 1, scene)
+    # (a one-rank process group still gathers: under torch.distributed.run the RCCL path runs on single-GPU boxes too)
     recv = [torch.empty_like(send) for _ in range(world_size)] if rank == 0 else None
     dist.gather(send, recv, dst=0, group=group)
     if rank != 0:
         return None
-    return assemble_film(recv, xres, yres, crop, world_size)
+    return assemble_film(recv, xres, yres, crop, world_size, scene)
 
 
 def render_sharded(scene, rank, world_size, group=None, **render_kw):
@@ -68,6 +90,6 @@ def render_sharded(scene, rank, world_size, group=None, **render_kw):
     slab = torch.empty(max(n_floats // 4, 1), 4, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     scene.render_device(slab.data_ptr(), stream, rank=rank, world_size=world_size, **render_kw)
-    film = gather_film(slab[: n_floats // 4], sd.xres, sd.yres, sd.crop, rank, world_size, group)
+    film = gather_film(slab[: n_floats // 4], sd.xres, sd.yres, sd.crop, rank, world_size, group, scene)
     stats = scene.render_wait()
     return film, stats

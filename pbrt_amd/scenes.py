@@ -166,3 +166,10 @@ def cornell_scene(xres=4096, yres=4096, crop=(0.0, 1.0, 0.0, 1.0)):
         materials=np.array(mats, np.float32),
         cam_to_world=_camera((0, -3.6, 0), (0, 0, 0), (0, 0, 1)), fov=40.0, xres=xres, yres=yres, crop=crop,
     ).normalized()
+
+
+def big_mesh_scene(xres=2048, yres=2048, crop=(0.0, 1.0, 0.0, 1.0), n_tris=12_000_000):
+    """The OUT-OF-CACHE workload of bench.py (`--workload big`): the C2 / C3 scene with 12M triangles -- 0.31 GB of
+    quantised nodes + 0.58 GB of triangle records, well past the 256 MiB Infinity Cache -- the one regime in which HBM
+    bandwidth is a real roof for this path."""
+    return random_mesh_scene(n_tris, xres, yres, crop=crop)

@@ -24,13 +24,16 @@ use std::os::raw::{c_char, c_int, c_void};
 }
 #[repr(C)] pub struct HipRenderDesc {
     pub integrator: u32, pub max_depth: u32, pub spp_x: u32, pub spp_y: u32,
-    pub seed: u64, pub rank: u32, pub world_size: u32, pub flags: u32, pub pad: u32,
+    pub seed: u64, pub rank: u32, pub world_size: u32, pub flags: u32,
+    pub sampler: u32,                                // 0 stratified, 1 the (0,2)-sequence sampler
+    pub filter_xwidth: f32, pub filter_ywidth: f32,  // box filter radii; 0 = 0.5; anything else is refused
 }
 #[repr(C)] #[derive(Default)] pub struct HipStats {
     pub camera_rays: u64, pub bounce_rays: u64, pub shadow_rays: u64,
     pub nodes_visited: u64, pub tris_tested: u64, pub kernel_ms: f64, pub samples: u64,
 }
 #[repr(C)] pub struct HipScene { _private: [u8; 0] }
+#[repr(C)] pub struct HipMulti { _private: [u8; 0] }
 #[repr(C)] pub struct HipLoaded { _private: [u8; 0] }
 
 extern "C" {
@@ -44,6 +47,10 @@ extern "C" {
     pub fn pbrt_hip_render_device(scene: *mut HipScene, desc: *const HipRenderDesc,
                                   d_slab: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn pbrt_hip_render_wait(scene: *mut HipScene, stats: *mut HipStats) -> c_int;
+    // every GPU of the node from this one process: scene copied device to device, one host thread + stream per GPU,
+    // one ncclGather to GPU 0 (create + render + destroy in one call; pbrt_hip_multi_* keep the handle)
+    pub fn pbrt_hip_render_multi(desc: *const HipSceneDesc, render: *const HipRenderDesc, n_gpus: c_int,
+                                 film_xyzw: *mut f32, per_gpu: *mut HipStats) -> c_int;
     pub fn pbrt_hip_intersect(scene: *mut HipScene, n: i64, o: *const f32, d: *const f32, tmax: *const f32,
                               t: *mut f32, prim: *mut u32, b1: *mut f32, b2: *mut f32, counters: *mut u64) -> c_int;
     // scene ingestion, should the crate prefer this library's parser to completing its own (parser.rs:226-313):
@@ -64,9 +71,6 @@ fn world_end(&mut self) {
     // ... existing attribute / transform stack checks (api.rs:434-444) ...
     let ro = &self.render_options;
     let desc = ro.to_hip_scene_desc();              // section 1: arrays collected while parsing
-    let mut scene: *mut HipScene = std::ptr::null_mut();
-    let rc = unsafe { pbrt_hip_scene_create(&desc, -1, &mut scene) };
-    if rc != 0 { error!("pbrt_hip_scene_create: {}", hip_last_error()); return; }   // api.rs:291-332 style: log, continue
 
     // Film::new (film.rs:82-137) keeps owning the pixels; the library fills them.
     let film = Film::new(res, crop, filter, diagonal, filename, scale, max_lum);
@@ -74,11 +78,13 @@ fn world_end(&mut self) {
     let mut xyzw = vec![0f32; (b.area() * 4) as usize];
     let rd = HipRenderDesc { integrator: if ro.integrator_name == "directlighting" { 1 } else { 0 },
                              max_depth: ro.integrator_params.find_one_int("maxdepth", 5) as u32,
-                             spp_x, spp_y, seed: 0, rank: 0, world_size: 1, flags: 0, pad: 0 };
-    let mut stats = HipStats::default();
-    let rc = unsafe { pbrt_hip_render(scene, &rd, xyzw.as_mut_ptr(), &mut stats) };
-    unsafe { pbrt_hip_scene_destroy(scene) };
-    if rc != 0 { error!("pbrt_hip_render: {}", hip_last_error()); return; }
+                             spp_x, spp_y, seed: 0, rank: 0, world_size: 1, flags: 0,
+                             sampler: if ro.sampler_name == "stratified" { 0 } else { 1 },
+                             filter_xwidth: filter.radius.x, filter_ywidth: filter.radius.y };
+    let n_gpus = unsafe { pbrt_hip_device_count() };   // all of them: 8 on an MI355X node
+    let mut stats = vec![HipStats::default(); n_gpus.max(1) as usize];
+    let rc = unsafe { pbrt_hip_render_multi(&desc, &rd, n_gpus, xyzw.as_mut_ptr(), stats.as_mut_ptr()) };
+    if rc != 0 { error!("pbrt_hip_render_multi: {}", hip_last_error()); return; }   // api.rs:291-332 style: log, continue
 
     // xyzw is Film.pixels AFTER merge_film_tile (film.rs:313-326): {xyz, filter_weight_sum}
     film.set_pixels_xyzw(&xyzw);     // new: Pixel.xyz / filter_weight_sum from the buffer (film.rs:47-55)

@@ -604,3 +604,33 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     if st is not None:
         for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
             assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_torchrun_uses_rccl(gpu):
+    """bench.py as the driver launches it for N > 1 -- torch.distributed.run, one rank per GPU, RCCL ("nccl") process
+    group with device_id, barrier, all_reduce of the times, gather of the slabs -- on min(2, device_count) ranks.  On a
+    single-GPU box the one-rank group still runs every one of those calls, so the first multi-GPU run of the driver is
+    not the first time they execute."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = min(2, gpu.device_count())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("PBRT_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--workload", "c2", "--spp", "2", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == n and out["value"] > 0 and out["film_check"]["weight_ok"] and out["film_check"]["finite"]
+    assert out["roofline"]["bound"] == "valu" and out["roofline"]["hbm"]["achieved_gbps"] > 0
+    if gpu.device_count() >= 2:  # and all GPUs from ONE process through the library's own ncclGather
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--steps", "1", "--warmup", "1",
+                            "--workload", "c2", "--spp", "2", "2", "--no-cpu-baseline"], capture_output=True, text=True, cwd=root, timeout=800)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out2["film_check"]["weight_ok"] and abs(out2["film_check"]["mean_Y"] - out["film_check"]["mean_Y"]) < 1e-12

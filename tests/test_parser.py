@@ -110,7 +110,8 @@ def _expect_check_sphere(ls, res):
     assert 1.0 < r < 1.25 and 0.45 < g < 0.62 and 0.1 < b < 0.25  # 3000 K normalised blackbody x 1.5: warm white
     want_c2w = pbrt_amd.look_at((3, 4, 1.5), (.5, .5, 0), (0, 0, 1))[1]  # camera_to_world = CTM^-1 (api.rs:813-820)
     assert np.array_equal(sd.cam_to_world, want_c2w)
-    assert len(ls.warnings) == 1 and "checkerboard" in ls.warnings[0]
+    assert len(ls.warnings) == 2 and "halton" in ls.warnings[0] and "checkerboard" in ls.warnings[1]
+    assert ls.sampler == 1  # Sampler "halton": the (0,2)-sequence sampler
 
 
 def test_c0_scene_loads():
@@ -173,3 +174,16 @@ def test_film_scale_and_filter_radius_leave_the_library():
     assert ls.film_scale == 1.0 and ls.filter_width == (0.5, 0.5)
     film = np.ones((2, 2, 4), np.float32)
     assert np.array_equal(pbrt_amd.film_to_rgb(film, scale=2.5), pbrt_amd.film_to_rgb(film) * np.float32(2.5))
+
+
+def test_sampler_names():
+    """Sampler "halton" (the reference's default name, api.rs:235) and the other low-discrepancy names select the
+    (0,2)-sequence sampler; "stratified" / "random" / unknown names the stratified one."""
+    for name, want in (("halton", 1), ("sobol", 1), ("02sequence", 1), ("lowdiscrepancy", 1), ("stratified", 0), ("random", 0), ("bogus", 0)):
+        ls = loader.load_string(f'Sampler "{name}" "integer pixelsamples" 32')
+        assert ls.sampler == want, name
+        if name != "stratified":
+            assert ls.spp[0] * ls.spp[1] == 32
+    assert loader.load_string("WorldBegin\nWorldEnd\n").sampler == 1  # no Sampler directive: the default name is "halton"
+    ls = loader.load_string('Sampler "stratified" "integer xsamples" 3 "integer ysamples" 5')
+    assert ls.sampler == 0 and ls.spp == (3, 5)

@@ -71,6 +71,10 @@ def main():
             hist = {}
             for o in ops:
                 hist[o] = hist.get(o, 0) + 1
+            if "--raw" in sys.argv:
+                import json
+                print(json.dumps(hist))
+                return
             valu = {o: c for o, c in hist.items() if o.startswith("v_")}
             tot = {"fast": 0, "slow": 0, "trans": 0}
             for o, c in valu.items():

@@ -1,18 +1,29 @@
 #!/bin/bash
-# usage (on the GPU box): tools/measure_round.sh <round-tag>
-# The measurement set behind profiles/<tag>_*: GPU parity tests, the default bench under rocprofv3
-# --kernel-trace --stats, the two HBM-traffic PMC passes (each in its own run), and the other workloads' benches.
+# usage (on the GPU box): tools/measure_round.sh <round-tag> [workloads...]   default workloads: c3 big
+# The measurement set behind profiles/<tag>_*:
+#   1. the -m gpu parity suite;
+#   2. per workload: bench.py under rocprofv3 --kernel-trace --stats (no CPU leg under the profiler: ADVICE r01), the
+#      two HBM-traffic PMC passes on the same command (FETCH_SIZE / WRITE_SIZE, each in its own run), and the SQ / TCC /
+#      instruction-class PMC passes on the low-spp probe (tools/pmc_passes.sh);
+#   3. bench.py itself, unprofiled, for every workload (with the CPU baseline leg where it has one).
+# tools/summarize_profile.py then condenses gpurun_out/ into profiles/ (run it here, on the CPU box).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=$1
+TAG=$1; shift
+WLS=${@:-c3 big}
 O=$R/gpurun_out
 cd $R
-timeout 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/${TAG}_pytest_gpu.log
-cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_trace -- python3 $R/bench.py --steps 2 --warmup 1 > $O/bench_c3_${TAG}.json 2> $O/bench_c3_${TAG}.err
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_${TAG}_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-counters > $O/prof_${TAG}_fetch.json 2> $O/prof_${TAG}_fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_${TAG}_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-counters > $O/prof_${TAG}_write.json 2> $O/prof_${TAG}_write.err
-cd $R
-for w in c2 c1 c4; do
-  timeout 900 python3 bench.py --workload $w --steps 2 --warmup 1 > $O/bench_${w}_${TAG}.json 2> $O/bench_${w}_${TAG}.err
+export PBRT_HIP_DEBUG_KNOBS=1
+timeout 1800 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/${TAG}_pytest_gpu.log
+python3 -c "from oracle import binding as ob; ob.build(native=True)"   # (the CPU leg's oracle is built before any profiler runs)
+for w in $WLS; do
+  cd /tmp && export TMPDIR=/tmp
+  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_${w}_trace -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_${TAG}_${w}_trace.json 2> $O/prof_${TAG}_${w}_trace.err
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_${TAG}_${w}_fetch -- python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-counters > $O/prof_${TAG}_${w}_fetch.json 2> $O/prof_${TAG}_${w}_fetch.err
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_${TAG}_${w}_write -- python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-counters > $O/prof_${TAG}_${w}_write.json 2> $O/prof_${TAG}_${w}_write.err
+  cd $R
+  if [ $w = big ]; then bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 2 2 > $O/pmc_${TAG}_${w}.log 2>&1; else bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 4 4 > $O/pmc_${TAG}_${w}.log 2>&1; fi
+done
+for w in c3 c2 c1 c4 big; do
+  timeout 1200 python3 bench.py --workload $w --steps 2 --warmup 1 > $O/bench_${w}_${TAG}.json 2> $O/bench_${w}_${TAG}.err
 done
 tail -n 2 $O/${TAG}_pytest_gpu.log; cat $O/bench_c3_${TAG}.json

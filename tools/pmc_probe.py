@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tiny driver for rocprofv3 --pmc passes: builds a BASELINE scene and renders it once at a low
-sample count (no torch, no baseline leg).  usage: pmc_probe.py [c2|c3] [spp_x spp_y]"""
+sample count (no torch, no baseline leg).  usage: pmc_probe.py [c2|c3|big] [spp_x spp_y]"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ from pbrt_amd import scenes  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 spp = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2, 2)
-n, res = (1_000_000, 2048) if wl == "c3" else (100_000, 1024)
+n, res = {"c3": (1_000_000, 2048), "c2": (100_000, 1024), "big": (12_000_000, 2048)}[wl]
 sd = scenes.random_mesh_scene(n, res, res)
 with pbrt_amd.Scene(sd, builder=os.environ.get("PROBE_BUILDER")) as sc:
     print("accelerator:", sc.build_info(), sc.info())
@@ -23,3 +23,4 @@ with pbrt_amd.Scene(sd, builder=os.environ.get("PROBE_BUILDER")) as sc:
         rays = ex["camera_rays"] + ex["bounce_rays"] + ex["shadow_rays"]
         print("exact: nodes/ray %.1f tris/ray %.2f | production walk: fetches/ray %.1f tris/ray %.2f" % (
             ex["nodes_visited"] / rays, ex["tris_tested"] / rays, wk["nodes_visited"] / rays, wk["tris_tested"] / rays))
+        print("RAYS %d SAMPLES %d KERNEL_MS %.4f" % (rays, ex["samples"], st["kernel_ms"]))

@@ -1,68 +1,84 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 output directories (gpurun_out/prof_*) into the small files kept under
-profiles/: the kernel-stats CSV of the --kernel-trace --stats run and a JSON with the PMC
-counters of the dominant kernel.
+"""Condenses what tools/measure_round.sh left under gpurun_out/ into the small files kept under profiles/.
 
-  python tools/summarize_profile.py <round-tag> <workload> <trace_dir> [<fetch_dir> <write_dir>]
+  python tools/summarize_profile.py <round-tag> <workload> [<workload> ...]
 
-A frame (one bench step) with >= 64 spp is TWO launches of render_kernel (capi.cpp render_device), so the
-figures are per FRAME: total time / counter sum of the kernel's launches divided by the number of frames
-(FRAMES_TRACE = 3 for --steps 2 --warmup 1, FRAMES_PMC = 1 for --steps 1 --warmup 0).
+Per workload: <tag>_<wl>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py), <tag>_<wl>_pmc_counters.txt
+(the PMC passes of the low-spp probe), <tag>_<wl>_summary.json = pmc_<wl>.json (kernel time per frame, FETCH_SIZE /
+WRITE_SIZE per frame from the two dedicated passes, and the VALU-issue model of tools/valu_model.py: what bench.py's
+`roofline` reads), and <tag>_<wl>_bench.json for every bench line found.
 """
 import csv
 import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "render_kernel<false, false"
+FRAMES_TRACE, FRAMES_PMC = 3, 1  # --steps 2 --warmup 1 / --steps 1 --warmup 0
 
 
 def one(pattern):
     f = glob.glob(pattern, recursive=True)
-    if not f:
-        raise SystemExit(f"nothing matches {pattern}")
-    return f[0]
+    return f[0] if f else None
 
 
 def main():
-    tag, workload, trace = sys.argv[1:4]
-    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    os.makedirs(out_dir, exist_ok=True)
-    rows = list(csv.DictReader(open(one(os.path.join(trace, "**", "*kernel_stats.csv")))))
-    with open(os.path.join(out_dir, f"{tag}_{workload}_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-        w.writeheader()
-        for r in rows:
-            r["Name"] = r["Name"][:160]
-            w.writerow(r)
-    k = [r for r in rows if KERNEL in r["Name"]][0]
-    frames_trace = int(os.environ.get("FRAMES_TRACE", "3"))
-    frames_pmc = int(os.environ.get("FRAMES_PMC", "1"))
-    calls = int(k["Calls"])
-    summary = {"workload": workload, "kernel": k["Name"], "calls": calls, "frames": frames_trace,
-               "launches_per_frame": calls / frames_trace, "avg_ms": float(k["TotalDurationNs"]) / 1e6 / frames_trace,
-               "avg_ms_per_launch": float(k["AverageNs"]) / 1e6, "min_ms": float(k["MinNs"]) / 1e6, "max_ms": float(k["MaxNs"]) / 1e6,
-               "share_of_gpu_time_pct": float(k["Percentage"]),
-               "source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1; avg_ms = per frame"}
-    if len(sys.argv) >= 6:
-        for name, d in (("FETCH_SIZE", sys.argv[4]), ("WRITE_SIZE", sys.argv[5])):
-            cr = list(csv.DictReader(open(one(os.path.join(d, "**", "*counter_collection.csv")))))
+    tag = sys.argv[1]
+    G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+    os.makedirs(P, exist_ok=True)
+    for wl in sys.argv[2:]:
+        summary = {"workload": wl, "round": tag}
+        stats = one(os.path.join(G, f"prof_{tag}_{wl}_trace", "**", "*kernel_stats.csv"))
+        if stats:
+            rows = list(csv.DictReader(open(stats)))
+            with open(os.path.join(P, f"{tag}_{wl}_kernel_stats.csv"), "w", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                w.writeheader()
+                for r in rows:
+                    r["Name"] = r["Name"][:160]
+                    w.writerow(r)
+            k = [r for r in rows if KERNEL in r["Name"]][0]
+            calls = int(k["Calls"])
+            summary.update({"kernel": k["Name"], "calls": calls, "frames": FRAMES_TRACE, "launches_per_frame": calls / FRAMES_TRACE,
+                            "avg_ms": float(k["TotalDurationNs"]) / 1e6 / FRAMES_TRACE, "min_ms": float(k["MinNs"]) / 1e6, "max_ms": float(k["MaxNs"]) / 1e6,
+                            "share_of_gpu_time_pct": float(k["Percentage"]),
+                            "source": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps 2 --warmup 1 --no-cpu-baseline; avg_ms = per frame"})
+        for name, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            f = one(os.path.join(G, f"prof_{tag}_{wl}_{sub}", "**", "*counter_collection.csv"))
+            if not f:
+                continue
+            cr = list(csv.DictReader(open(f)))
             vals = [float(r["Counter_Value"]) for r in cr if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
-            summary[name + "_KB_per_launch"] = sum(vals) / frames_pmc  # per frame (all launches of the frame)
+            summary[name + "_KB_per_launch"] = sum(vals) / FRAMES_PMC
             kr = [r for r in cr if KERNEL in r["Kernel_Name"]][0]
             summary.update({"vgpr": int(kr["VGPR_Count"]), "sgpr": int(kr["SGPR_Count"]), "lds_bytes": int(kr["LDS_Block_Size"]),
                             "grid": int(kr["Grid_Size"]), "workgroup": int(kr["Workgroup_Size"])})
-        # MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B in KB; it reads exactly half of the
-        # bytes of a WIDE COALESCED 16 B/lane stream; other access shapes (ours: divergent 16-B loads of 32-B
-        # nodes) are uncalibrated, so both the raw and the doubled figure are kept.
-        summary["traffic_bytes_raw"] = (summary["FETCH_SIZE_KB_per_launch"] + summary["WRITE_SIZE_KB_per_launch"]) * 1024
-        summary["traffic_bytes_fetch_doubled"] = (2 * summary["FETCH_SIZE_KB_per_launch"] + summary["WRITE_SIZE_KB_per_launch"]) * 1024
-        summary["pmc_source"] = ("separate passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace "
-                                 "-- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-counters")
-    with open(os.path.join(out_dir, f"{tag}_{workload}_summary.json"), "w") as f:
-        json.dump(summary, f, indent=1)
-    print(json.dumps(summary, indent=1))
+        if "FETCH_SIZE_KB_per_launch" in summary and "WRITE_SIZE_KB_per_launch" in summary:
+            # MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B in KB, L2-miss requests including Infinity-Cache hits; it reads
+            # exactly half of the bytes of a WIDE COALESCED 16 B/lane stream; other access shapes (ours: divergent 16-B loads) are
+            # uncalibrated, so both the raw and the doubled figure are kept.
+            summary["traffic_bytes_raw"] = (summary["FETCH_SIZE_KB_per_launch"] + summary["WRITE_SIZE_KB_per_launch"]) * 1024
+            summary["traffic_bytes_fetch_doubled"] = (2 * summary["FETCH_SIZE_KB_per_launch"] + summary["WRITE_SIZE_KB_per_launch"]) * 1024
+            summary["pmc_source"] = ("separate passes: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace -- python3 bench.py "
+                                     f"--workload {wl} --steps 1 --warmup 0 --no-cpu-baseline --no-counters")
+        pmc = os.path.join(G, f"pmc_{tag}_{wl}", "summary.txt")
+        if os.path.exists(pmc):
+            shutil.copy(pmc, os.path.join(P, f"{tag}_{wl}_pmc_counters.txt"))
+            model = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_model.py"), pmc], capture_output=True, text=True, check=True).stdout)
+            summary.update(model)
+            summary["valu_source"] = f"tools/pmc_passes.sh on tools/pmc_probe.py {wl} (low-spp frame) -> profiles/{tag}_{wl}_pmc_counters.txt -> tools/valu_model.py"
+        with open(os.path.join(P, f"{tag}_{wl}_summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        shutil.copy(os.path.join(P, f"{tag}_{wl}_summary.json"), os.path.join(P, f"pmc_{wl}.json"))
+        print(wl, {k: summary.get(k) for k in ("avg_ms", "traffic_bytes_raw", "valu_busy_frac_at_profile_clock", "lane_utilisation", "valu_issue_cycles_per_ray")})
+    for f in glob.glob(os.path.join(G, f"bench_*_{tag}.json")):
+        wl = os.path.basename(f).split("_")[1]
+        if os.path.getsize(f):
+            shutil.copy(f, os.path.join(P, f"{tag}_{wl}_bench.json"))
 
 
 if __name__ == "__main__":

@@ -228,7 +228,7 @@ struct Sweep<N_OPS> {
   static void go(const int *, int, double *) {}
 };
 
-int main() {
+int main(int argc, char **argv) {
   hipDeviceProp_t p;
   (void)hipGetDeviceProperties(&p, 0);
   n_cu = p.multiProcessorCount;
@@ -236,6 +236,12 @@ int main() {
   (void)hipMalloc(&d_recs, (size_t)n_cu * 8 * 4 * sizeof(WaveRec));
   (void)hipMalloc(&sink, 64);
   (void)hipMalloc(&d_start, 64);
+  if (argc > 1 && !strcmp(argv[1], "pmc")) {
+    // a short run for rocprofv3 --pmc: one kernel per issue class at 4 waves per SIMD, so that SQ_ACTIVE_INST_VALU /
+    // SQ_INSTS_VALU can be read per kernel (does the counter see the half-rate instructions as twice as long?)
+    PMC_RUNS
+    return 0;
+  }
   const int Ws[] = {1, 2, 4, 8};
   std::vector<double> table((size_t)N_OPS * 4, 0.0);
   Sweep<0>::go(Ws, 4, table.data());
@@ -250,4 +256,13 @@ for W in (1, 2, 4):
         for name in ("v_fma_f32", "v_min_f32", "v_cvt_f32_ubyte0", "node-step mix: 2 cvt_ubyte, pk_fma, max3, 2 min, cmp, cndmask"):
             out.append(f"  run<{idx[name]}>({W}, {lanes});\n")
 out.append("  return 0;\n}\n")
-open("/root/repo/tools/ubench/valu_issue.hip", "w").write("".join(out))
+src = "".join(out)
+pmc = "".join(f"run<{idx[n]}>(4, 64);\n    " for n in (
+    "v_fma_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_fmac_f32", "v_min_f32", "v_max_f32", "v_max3_f32", "v_min3_f32", "v_cvt_f32_ubyte0",
+    "v_cvt_f32_u32", "v_cmp_le_f32", "v_cmp_eq_u32", "v_cndmask_b32_e64", "v_pk_fma_f32", "v_pk_mul_f32", "v_and_b32", "v_or_b32", "v_add_u32",
+    "v_lshlrev_b32", "v_lshrrev_b32", "v_mov_b32", "v_mul_lo_u32", "v_mad_u32_u24", "v_lshl_add_u32", "v_and_or_b32", "v_bfe_u32", "v_rcp_f32",
+    "v_sqrt_f32", "v_mad_u64_u32", "v_fma_f64x", "v_readfirstlane_b32",
+    "node-step mix: 2 cvt_ubyte, pk_fma, max3, 2 min, cmp, cndmask"))
+src = src.replace("PMC_RUNS", pmc)
+import os
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "valu_issue.hip"), "w").write(src)

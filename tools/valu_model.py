@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""The VALU-issue roof of render_kernel from a PMC summary (tools/pmc_passes.sh -> summary.txt).
+
+gfx950 issues vector instructions in two classes (tools/ubench/valu_issue.hip, profiles/r02_valu_issue_ubench.txt; cycles per
+wave64 instruction per SIMD with >= 2 waves resident): FAST 2.33 (fma / mul / add / sub f32, add / sub / and / or / xor /
+right shifts, mov), SLOW 4.2 (min / max / min3 / max3, every cvt, every cmp, cndmask, packed f32, left shift, 3-operand
+integer forms, mul_lo), transcendental 8.1, 64-bit integer mad 5.1.  The SQ's instruction-class counters tell the classes
+apart only partly (calibrated on the ubench, profiles/r02_pmc_class_calibration.txt): ADD_F32 and MUL_F32 are FAST; CVT is
+SLOW; FMA_F32 counts v_fma_f32 (FAST) and v_pk_fma_f32 (SLOW) alike; INT32 mixes both; min / max / cmp / cndmask / mov /
+logic are not counted at all.  The unresolved groups are split by the STATIC census of the kernel's node step
+(tools/isa_stats.py --step: the loop that executes ~70 % of the instructions): the share of SLOW opcodes among the
+instructions of each group there.  Result: issue cycles per instruction, per ray, VALU-busy fraction, and the bracket
+[every unresolved instruction FAST, every one SLOW].
+
+usage: tools/valu_model.py <summary.txt> [n_simds=1024]  ->  JSON on stdout
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+FAST, SLOW, TRANS, INT64 = 2.33, 4.2, 8.1, 5.1
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# which opcodes increment which class counter (profiles/r02_pmc_class_calibration.txt)
+COUNTED = {
+    "FMA_F32": {"v_fma_f32", "v_fmac_f32", "v_pk_fma_f32"},
+    "INT32": {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_cmp_eq_u32", "v_cmp_ne_u32", "v_cmp_lt_u32", "v_cmp_gt_u32", "v_cmp_le_u32", "v_cmp_ge_u32",
+              "v_cmp_lt_i32", "v_cmp_gt_i32", "v_cmp_le_i32", "v_cmp_ge_i32", "v_cmp_eq_i32", "v_cmp_ne_i32",
+              "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_u32_u24", "v_lshl_add_u32", "v_add3_u32", "v_bfe_u32", "v_add_co_u32",
+              "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_min_u32", "v_max_u32", "v_add_lshl_u32", "v_mad_i32_i24"},
+    "ADD_F32": {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_pk_add_f32"},
+    "MUL_F32": {"v_mul_f32", "v_pk_mul_f32"},
+    "CVT": None, "TRANS_F32": None, "INT64": None,
+}
+
+
+def static_slow_share():
+    """share of SLOW opcodes among the node step's instructions of the groups the counters cannot resolve"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_stats
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_stats.py"), "--step", "--raw"], capture_output=True, text=True, check=True).stdout
+    hist = json.loads(out.strip().split("\n")[-1])
+    share = {}
+    for grp in ("FMA_F32", "INT32", "OTHER"):
+        n = {"fast": 0, "slow": 0, "trans": 0}
+        for op, c in hist.items():
+            base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+            if not op.startswith("v_"):
+                continue
+            if grp == "OTHER":
+                counted = any(v is not None and base in v for v in COUNTED.values()) or base.startswith(("v_cvt", "v_rcp", "v_sqrt", "v_rsq", "v_mad_u64"))
+                if counted:
+                    continue
+            elif base not in COUNTED[grp]:
+                continue
+            n[isa_stats.klass(op)] += c
+        tot = n["fast"] + n["slow"] + n["trans"]
+        share[grp] = (n["slow"] / tot) if tot else 0.5
+    return share
+
+
+def main():
+    c = {}
+    for line in open(sys.argv[1]):
+        k, v = line.split()
+        c[k] = float(v)
+    n_simd = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    total = c["SQ_INSTS_VALU"]
+    grp = {k: c.get("SQ_INSTS_VALU_" + k, 0.0) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32", "INT64")}
+    other = total - sum(grp.values())
+    share = static_slow_share()
+    known = grp["ADD_F32"] * FAST + grp["MUL_F32"] * FAST + grp["CVT"] * SLOW + grp["TRANS_F32"] * TRANS + grp["INT64"] * INT64
+
+    def cycles(s_fma, s_int, s_other):
+        mix = lambda n, s: n * (s * SLOW + (1 - s) * FAST)
+        return known + mix(grp["FMA_F32"], s_fma) + mix(grp["INT32"], s_int) + mix(other, s_other)
+
+    best = cycles(share["FMA_F32"], share["INT32"], share["OTHER"])
+    lo, hi = cycles(0, 0, 0), cycles(1, 1, 1)
+    kernel_cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+    simd_cycles = kernel_cycles * n_simd
+    rays = c.get("PROBE_RAYS", 0.0)
+    out = {
+        "valu_instructions": total, "class_counters": grp, "uncounted_instructions": other, "static_slow_share_in_node_step": share,
+        "valu_issue_cycles": best, "mean_issue_cycles_per_instruction": best / total,
+        "kernel_cycles": kernel_cycles, "clock_ghz_in_profile": kernel_cycles / c["PROBE_KERNEL_NS"] if c.get("PROBE_KERNEL_NS") else None,
+        "valu_busy_frac_at_profile_clock": best / simd_cycles, "valu_busy_bracket": [lo / simd_cycles, hi / simd_cycles],
+        "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") else None,
+        "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if c.get("TCC_HIT_sum") else None,
+        "wave_wait_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+        "salu_per_valu": c.get("SQ_INSTS_SALU", 0.0) / total,
+        "probe_rays": rays, "probe_samples": c.get("PROBE_SAMPLES"),
+        "valu_instructions_per_ray": total / rays if rays else None, "valu_issue_cycles_per_ray": best / rays if rays else None,
+        "fetch_bytes_per_ray": c.get("FETCH_SIZE", 0.0) * 1024 / rays if rays else None,
+        "write_bytes_per_ray": c.get("WRITE_SIZE", 0.0) * 1024 / rays if rays else None,
+        "probe_counter_gbps": (c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024 / c["PROBE_KERNEL_NS"] if c.get("PROBE_KERNEL_NS") else None,
+        "costs": {"fast": FAST, "slow": SLOW, "trans": TRANS, "int64": INT64, "source": "profiles/r02_valu_issue_ubench.txt"},
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
