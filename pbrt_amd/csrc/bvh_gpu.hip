@@ -1,14 +1,21 @@
-// BVH construction on the device: Morton codes -> radix sort -> binary radix tree
-// (Karras 2012) -> bottom-up box fit -> greedy collapse into the quantised 4-wide nodes the production walk
-// reads.  The reference has no accelerator at all (core/api.rs:237 is a name), so there is
-// nothing to conform to but the RESULT: by the tie rule of DESIGN.md 3.4 a ray's hit does not depend on the shape
-// of the tree, so a scene built here renders the same film, bit for bit, as one built by the host's SAH builder
-// (tests/test_gpu_parity.py::test_gpu_built_scene_*).  What differs is speed: an LBVH is built in milliseconds
-// and walks slower than the SAH tree.  The canonical counters (oracle order) exist only for the host-built tree.
+// BVH construction on the device: Morton codes -> radix sort -> binary tree -> greedy
+// collapse into the quantised 4-wide nodes the production walk reads.  Two ways to the binary tree:
+//   * PLOC (default): parallel locally-ordered clustering (Meister & Bittner, "Parallel Locally-Ordered Clustering for
+//     Bounding Volume Hierarchy Construction", IEEE TVCG 2018): the Morton-sorted triangles are clusters; every round
+//     each cluster finds, among its kPlocRadius neighbours on either side, the one whose union box with it has the
+//     smallest surface area; mutual nearest neighbours merge into a node; the list is compacted; ~20-30 rounds to one
+//     root.  Agglomerative by surface area, so the tree has SAH quality close to the host's binned top-down builder;
+//   * LBVH (PBRT_HIP_GPU_BUILDER=lbvh behind the debug switch): the binary radix tree of Karras 2012 + a bottom-up box
+//     fit -- faster to build, and a tree that walks ~9 % slower on C3.
+// The reference has no accelerator at all (core/api.rs:237 is a name), so there is nothing to conform to but the RESULT:
+// by the tie rule of DESIGN.md 3.4 a ray's hit does not depend on the shape of the tree, so a scene built here renders
+// the same film, bit for bit, as one built by the host's SAH builder (tests/test_gpu_parity.py::test_gpu_built_scene_*).
+// The canonical counters (oracle order) exist only for the host-built tree.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
@@ -181,6 +188,298 @@ __global__ void fit_kernel(const float *P, const uint32_t *idx, const uint32_t *
   }
 }
 
+// ---- PLOC ----
+constexpr int kPlocRadius = 16;
+
+__device__ __forceinline__ uint32_t node_of(uint32_t ref, int n) { return (ref & kLeafRef) ? (uint32_t)(n - 1) + (ref & ~kLeafRef) : ref; }
+
+// leaf boxes: node id (n - 1) + k for sorted position k; cluster list = the leaves in Morton order
+__global__ void ploc_init_kernel(const float *P, const uint32_t *idx, const uint32_t *order, int n, unsigned long long *bx, uint32_t *clusters) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  float lo[3], hi[3];
+  tri_box(P, idx, order[k], lo, hi);
+  box_store(bx, (uint32_t)(n - 1 + k), lo, hi);
+  clusters[k] = kLeafRef | (uint32_t)k;
+}
+
+// nearest neighbour of every cluster within kPlocRadius list positions, by the surface area of the union box (ties: the
+// lower position).  The boxes of a block's clusters and of the halo on either side are staged in LDS.
+__global__ void __launch_bounds__(256) ploc_nn_kernel(const uint32_t *clusters, int m, int n, const unsigned long long *bx, uint32_t *nn) {
+  __shared__ float sb[256 + 2 * kPlocRadius][6];
+  const int base = (int)(blockIdx.x * 256) - kPlocRadius;
+  for (int t = (int)threadIdx.x; t < 256 + 2 * kPlocRadius; t += 256) {
+    const int g = base + t;
+    if (g >= 0 && g < m) {
+      float lo[3], hi[3];
+      box_load<false>(bx, node_of(clusters[g], n), lo, hi);
+      for (int a = 0; a < 3; a++) { sb[t][a] = lo[a]; sb[t][3 + a] = hi[a]; }
+    }
+  }
+  __syncthreads();
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= m) return;
+  const float *me = sb[threadIdx.x + kPlocRadius];
+  float best = __builtin_huge_valf();
+  int bj = -1;
+  for (int d = -kPlocRadius; d <= kPlocRadius; d++) {
+    const int j = i + d;
+    if (d == 0 || j < 0 || j >= m) continue;
+    const float *o = sb[(int)threadIdx.x + kPlocRadius + d];
+    const float dx = fmaxf(me[3], o[3]) - fminf(me[0], o[0]), dy = fmaxf(me[4], o[4]) - fminf(me[1], o[1]), dz = fmaxf(me[5], o[5]) - fminf(me[2], o[2]);
+    const float area = (dx * dy + dx * dz) + dy * dz;
+    if (area < best) { best = area; bj = j; }
+  }
+  nn[i] = (uint32_t)bj;  // (m >= 2 here, so every cluster has a neighbour)
+}
+
+// flags: low word 1 = the cluster (or the node it merges into) stays in the list, high word 1 = it starts a merge
+__global__ void ploc_flag_kernel(const uint32_t *nn, int m, unsigned long long *flags) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= m) return;
+  const uint32_t j = nn[i];
+  const bool mutual = nn[j] == (uint32_t)i;
+  flags[i] = (mutual && (uint32_t)i > j) ? 0ull : (1ull | ((mutual ? 1ull : 0ull) << 32));
+}
+
+// scan = exclusive prefix sums of flags (low word: new list position, high word: number of merges before this one).
+// A merge creates internal node first_node + rank with the two clusters as children and their union box.
+__global__ void ploc_merge_kernel(const uint32_t *clusters, const uint32_t *nn, const unsigned long long *flags, const unsigned long long *scan, int m,
+                                  int n, uint32_t first_node, uint32_t *child, unsigned long long *bx, uint32_t *out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= m) return;
+  const unsigned long long f = flags[i];
+  if (!(f & 1ull)) return;
+  const uint32_t pos = (uint32_t)scan[i];
+  if (!(f >> 32)) { out[pos] = clusters[i]; return; }
+  const uint32_t id = first_node + (uint32_t)(scan[i] >> 32), a = clusters[i], b = clusters[nn[i]];
+  float alo[3], ahi[3], blo[3], bhi[3];
+  box_load<false>(bx, node_of(a, n), alo, ahi);
+  box_load<false>(bx, node_of(b, n), blo, bhi);
+  for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], blo[k]); ahi[k] = fmaxf(ahi[k], bhi[k]); }
+  box_store(bx, id, alo, ahi);
+  child[2 * (size_t)id] = a;
+  child[2 * (size_t)id + 1] = b;
+  out[pos] = id;
+}
+
+// ---- top-down binned SAH, level-synchronous (the host builder's split rule, DESIGN.md 3.3, on the device) ----
+// The triangles (in Morton order to start with) form SEGMENTS of the position array; every level every segment of two
+// or more triangles is split: bounds of the triangle-box centres -> widest axis -> 16 buckets with counts and boxes ->
+// the plane of least n_l * A_l + n_r * A_r (planes with an empty side excluded) -> a stable partition (one global prefix
+// sum of the "goes left" flags).  No plane (all centres in one bucket), or a level past kSahMedianLevel: the segment is
+// halved as it stands.  Leaves hold one triangle.  Node ids: the root is 0, the segments of the next level get
+// consecutive ids in segment order, so the numbering is deterministic.  Per-segment sums go through atomics, aggregated in
+// LDS when a whole block lies in one segment (the top levels).
+constexpr int kSahBuckets = 16;
+constexpr uint32_t kSahMedianLevel = 40;  // beyond this level only halving: bounds the depth at ~ 40 + log2(n)
+constexpr uint32_t kBinWords = kSahBuckets * 7;  // per bucket: count, box lo xyz, hi xyz (order-preserving integers)
+
+struct SahSegs {  // one level's segment table (structure of arrays; capacity n / 2 + 1)
+  uint32_t *start, *end, *node;
+};
+struct SahSplit {
+  uint32_t axis, best, nl, mode;  // mode 0: bucket <= best goes left; 1: position < start + nl goes left
+  float c0, scale;                // bucket = min(15, (int)((c - c0) * scale))
+};
+
+__global__ void sah_tri_boxes_kernel(const float *P, const uint32_t *idx, uint32_t n, float *tlo, float *thi) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  float lo[3], hi[3];
+  tri_box(P, idx, t, lo, hi);
+  for (int a = 0; a < 3; a++) { tlo[3 * (size_t)t + a] = lo[a]; thi[3 * (size_t)t + a] = hi[a]; }
+}
+
+// centre bounds of every active segment: cb[s][0..2] = min, [3..5] = max (order-preserving integers, preset to ~0 / 0)
+__global__ void __launch_bounds__(256) sah_bounds_kernel(const uint32_t *ids, const uint32_t *seg_of, int n, const float *tlo, const float *thi, uint32_t *cb) {
+  __shared__ uint32_t red[6];
+  __shared__ uint32_t s_first, s_last;
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (threadIdx.x == 0) { s_first = seg_of[blockIdx.x * 256]; s_last = seg_of[min((int)(blockIdx.x * 256 + 255), n - 1)]; }
+  if (threadIdx.x < 6) red[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+  __syncthreads();
+  const bool uniform = s_first == s_last && s_first != kNone;  // segments are contiguous: the whole block is in one
+  const uint32_t s = i < n ? seg_of[i] : kNone;
+  if (s != kNone) {
+    const uint32_t t = ids[i];
+    for (int a = 0; a < 3; a++) {
+      const uint32_t c = f2ord(0.5f * tlo[3 * (size_t)t + a] + 0.5f * thi[3 * (size_t)t + a]);
+      if (uniform) { atomicMin(&red[a], c); atomicMax(&red[3 + a], c); }
+      else { atomicMin(&cb[6 * (size_t)s + a], c); atomicMax(&cb[6 * (size_t)s + 3 + a], c); }
+    }
+  }
+  if (uniform) {
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&cb[6 * (size_t)s_first + threadIdx.x], red[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&cb[6 * (size_t)s_first + threadIdx.x], red[threadIdx.x]);
+  }
+}
+
+__device__ __forceinline__ uint32_t sah_bucket(float c, float c0, float scale) {
+  const int b = (int)((c - c0) * scale);
+  return (uint32_t)(b < 0 ? 0 : (b >= kSahBuckets ? kSahBuckets - 1 : b));
+}
+
+// widest axis of the centre bounds and the bucket scale of every segment
+__global__ void sah_prepare_kernel(int n_seg, const uint32_t *cb, SahSplit *sp) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= n_seg) return;
+  float ext[3], mn[3];
+  for (int a = 0; a < 3; a++) { mn[a] = ord2f(cb[6 * (size_t)s + a]); ext[a] = ord2f(cb[6 * (size_t)s + 3 + a]) - mn[a]; }
+  const int axis = (ext[0] > ext[1] && ext[0] > ext[2]) ? 0 : (ext[1] > ext[2] ? 1 : 2);
+  SahSplit o;
+  o.axis = (uint32_t)axis;
+  o.c0 = mn[axis];
+  o.scale = ext[axis] > 0.f ? (float)kSahBuckets / ext[axis] : 0.f;
+  o.best = 0; o.nl = 0; o.mode = 1;
+  sp[s] = o;
+}
+
+// bucket counts and boxes of every segment (bins preset: count 0, lo ~0, hi 0)
+__global__ void __launch_bounds__(256) sah_bins_kernel(const uint32_t *ids, const uint32_t *seg_of, int n, const float *tlo, const float *thi, const SahSplit *sp,
+                                                       uint32_t *bins) {
+  __shared__ uint32_t lb[kBinWords];
+  __shared__ uint32_t s_first, s_last;
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (threadIdx.x == 0) { s_first = seg_of[blockIdx.x * 256]; s_last = seg_of[min((int)(blockIdx.x * 256 + 255), n - 1)]; }
+  if (threadIdx.x < kBinWords) lb[threadIdx.x] = (threadIdx.x % 7u == 0u || threadIdx.x % 7u > 3u) ? 0u : 0xffffffffu;
+  __syncthreads();
+  const bool uniform = s_first == s_last && s_first != kNone;
+  const uint32_t s = i < n ? seg_of[i] : kNone;
+  if (s != kNone) {
+    const uint32_t t = ids[i];
+    const SahSplit p = sp[s];
+    const float c = 0.5f * tlo[3 * (size_t)t + p.axis] + 0.5f * thi[3 * (size_t)t + p.axis];
+    const uint32_t b = sah_bucket(c, p.c0, p.scale);
+    uint32_t *dst = uniform ? &lb[7u * b] : &bins[(size_t)s * kBinWords + 7u * b];
+    atomicAdd(&dst[0], 1u);
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&dst[1 + a], f2ord(tlo[3 * (size_t)t + a]));
+      atomicMax(&dst[4 + a], f2ord(thi[3 * (size_t)t + a]));
+    }
+  }
+  if (uniform) {
+    __syncthreads();
+    if (threadIdx.x < kBinWords) {
+      uint32_t *dst = &bins[(size_t)s_first * kBinWords + threadIdx.x];
+      const uint32_t k = threadIdx.x % 7u, v = lb[threadIdx.x];
+      if (k == 0u) { if (v) atomicAdd(dst, v); }
+      else if (k <= 3u) atomicMin(dst, v);
+      else atomicMax(dst, v);
+    }
+  }
+}
+
+// the split of every segment: its own box (union of the buckets) goes to bx[node]; active[s] = children of >= 2 triangles
+__global__ void sah_split_kernel(int n_seg, SahSegs segs, const uint32_t *bins, SahSplit *sp, uint32_t level, unsigned long long *bx, uint32_t *active) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= n_seg) return;
+  const uint32_t *b = bins + (size_t)s * kBinWords;
+  const uint32_t n = segs.end[s] - segs.start[s];
+  uint32_t cnt[kSahBuckets];
+  float lo[kSahBuckets][3], hi[kSahBuckets][3];
+  float all_lo[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()}, all_hi[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+  for (int k = 0; k < kSahBuckets; k++) {
+    cnt[k] = b[7 * k];
+    for (int a = 0; a < 3; a++) {
+      lo[k][a] = ord2f(b[7 * k + 1 + a]);
+      hi[k][a] = ord2f(b[7 * k + 4 + a]);
+      if (cnt[k]) { all_lo[a] = fminf(all_lo[a], lo[k][a]); all_hi[a] = fmaxf(all_hi[a], hi[k][a]); }
+    }
+  }
+  box_store(bx, segs.node[s], all_lo, all_hi);
+  // suffix sweep, then prefix sweep over the 15 planes
+  float area_r[kSahBuckets];
+  uint32_t cnt_r[kSahBuckets];
+  {
+    float rl[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()}, rh[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    uint32_t c = 0;
+    for (int k = kSahBuckets - 1; k >= 1; k--) {
+      if (cnt[k]) { for (int a = 0; a < 3; a++) { rl[a] = fminf(rl[a], lo[k][a]); rh[a] = fmaxf(rh[a], hi[k][a]); } c += cnt[k]; }
+      const float dx = rh[0] - rl[0], dy = rh[1] - rl[1], dz = rh[2] - rl[2];
+      cnt_r[k - 1] = c;
+      area_r[k - 1] = c ? (dx * dy + dx * dz) + dy * dz : 0.f;
+    }
+  }
+  SahSplit o = sp[s];
+  float best_cost = __builtin_huge_valf();
+  int best = -1;
+  {
+    float ll[3] = {__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf()}, lh[3] = {-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf()};
+    uint32_t c = 0;
+    for (int k = 0; k < kSahBuckets - 1; k++) {
+      if (cnt[k]) { for (int a = 0; a < 3; a++) { ll[a] = fminf(ll[a], lo[k][a]); lh[a] = fmaxf(lh[a], hi[k][a]); } c += cnt[k]; }
+      if (c == 0 || cnt_r[k] == 0) continue;  // a plane with an empty side splits nothing
+      const float dx = lh[0] - ll[0], dy = lh[1] - ll[1], dz = lh[2] - ll[2];
+      const float cost = (float)c * ((dx * dy + dx * dz) + dy * dz) + (float)cnt_r[k] * area_r[k];
+      if (cost < best_cost) { best_cost = cost; best = k; o.nl = c; }
+    }
+  }
+  if (best < 0 || level >= kSahMedianLevel) { o.mode = 1; o.nl = n / 2; o.best = 0; }
+  else { o.mode = 0; o.best = (uint32_t)best; }
+  sp[s] = o;
+  active[s] = (o.nl >= 2u ? 1u : 0u) + (n - o.nl >= 2u ? 1u : 0u);
+}
+
+__global__ void sah_flags_kernel(const uint32_t *ids, const uint32_t *seg_of, int n, const float *tlo, const float *thi, SahSegs segs, const SahSplit *sp, uint32_t *flags) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const uint32_t s = seg_of[i];
+  uint32_t f = 0;
+  if (s != kNone) {
+    const SahSplit p = sp[s];
+    if (p.mode) f = (uint32_t)i < segs.start[s] + p.nl ? 1u : 0u;
+    else {
+      const uint32_t t = ids[i];
+      f = sah_bucket(0.5f * tlo[3 * (size_t)t + p.axis] + 0.5f * thi[3 * (size_t)t + p.axis], p.c0, p.scale) <= p.best ? 1u : 0u;
+    }
+  }
+  flags[i] = f;
+}
+
+// stable partition of every segment (scan = exclusive prefix sum of flags over the whole array) and the segment each
+// position belongs to on the next level (kNone: a finished leaf)
+__global__ void sah_scatter_kernel(const uint32_t *ids, const uint32_t *seg_of, int n, SahSegs segs, const SahSplit *sp, const uint32_t *flags, const uint32_t *scan,
+                                   const uint32_t *child_base, uint32_t *ids_out, uint32_t *seg_out) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  const uint32_t s = seg_of[i];
+  if (s == kNone) { ids_out[i] = ids[i]; seg_out[i] = kNone; return; }
+  const uint32_t st = segs.start[s], nl = sp[s].nl, nr = segs.end[s] - st - nl;
+  const uint32_t left_before = scan[i] - scan[st];
+  const bool left = flags[i] != 0u;
+  const uint32_t pos = left ? st + left_before : st + nl + ((uint32_t)i - st - left_before);
+  ids_out[pos] = ids[i];
+  const uint32_t first = child_base[s];  // next level's index of this segment's first active child
+  seg_out[pos] = left ? (nl >= 2u ? first : kNone) : (nr >= 2u ? first + (nl >= 2u ? 1u : 0u) : kNone);
+}
+
+// the node of every segment gets its two children; the active children become the next level's segments
+__global__ void sah_children_kernel(int n_seg, SahSegs segs, const SahSplit *sp, const uint32_t *child_base, uint32_t next_node_base, uint32_t *child, SahSegs next) {
+  const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (s >= n_seg) return;
+  const uint32_t st = segs.start[s], en = segs.end[s], nl = sp[s].nl, nr = en - st - nl, node = segs.node[s];
+  uint32_t j = child_base[s];
+  uint32_t left, right;
+  if (nl >= 2u) { left = next_node_base + j; next.start[j] = st; next.end[j] = st + nl; next.node[j] = left; j++; }
+  else left = kLeafRef | st;
+  if (nr >= 2u) { right = next_node_base + j; next.start[j] = st + nl; next.end[j] = en; next.node[j] = right; }
+  else right = kLeafRef | (st + nl);
+  child[2 * (size_t)node] = left;
+  child[2 * (size_t)node + 1] = right;
+}
+
+__global__ void sah_leaf_boxes_kernel(const uint32_t *ids, int n, const float *tlo, const float *thi, unsigned long long *bx, uint32_t *order) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  const uint32_t t = ids[k];
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; a++) { lo[a] = tlo[3 * (size_t)t + a]; hi[a] = thi[3 * (size_t)t + a]; }
+  box_store(bx, (uint32_t)(n - 1 + k), lo, hi);
+  order[k] = t;
+}
+
 struct CollapseItem {
   uint32_t node, quad, path;  // binary internal node, its quad slot, stack entries held above it
 };
@@ -320,17 +619,116 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   hipLaunchKernelGGL(morton_kernel, grid_t, block, 0, stream, d_P, d_idx, n_tris, bounds.as<uint32_t>(), keys.as<uint32_t>(), vals.as<uint32_t>());
   GB_TRY(hipGetLastError());
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
-  GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
-  hipLaunchKernelGGL(radix_tree_kernel, grid_t, block, 0, stream, keys_out.as<uint32_t>(), n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>());
-  hipLaunchKernelGGL(fit_kernel, grid_t, block, 0, stream, d_P, d_idx, d_order, n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>(),
-                     visits.as<uint32_t>(), bx.as<unsigned long long>());
-  GB_TRY(hipGetLastError());
+  uint32_t root_node = 0u;  // internal node the collapse starts from
+  const char *which = debug_knob("PBRT_HIP_GPU_BUILDER");
+  if (which && std::string(which) == "lbvh") {
+    GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
+    hipLaunchKernelGGL(radix_tree_kernel, grid_t, block, 0, stream, keys_out.as<uint32_t>(), n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>());
+    hipLaunchKernelGGL(fit_kernel, grid_t, block, 0, stream, d_P, d_idx, d_order, n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>(),
+                       visits.as<uint32_t>(), bx.as<unsigned long long>());
+    GB_TRY(hipGetLastError());
+  } else if (!which || std::string(which) != "ploc") {
+    // ---- top-down binned SAH ----
+    const size_t cap = (size_t)n / 2 + 2;  // segments of >= 2 triangles on one level
+    Tmp tlo, thi, ids_b, seg_a, seg_b, cb, bins, split, active, cbase, flags, scan, scan_tmp, segtab;
+    GB_TRY(tlo.alloc(12 * (size_t)n)); GB_TRY(thi.alloc(12 * (size_t)n));
+    GB_TRY(ids_b.alloc(4 * (size_t)n)); GB_TRY(seg_a.alloc(4 * (size_t)n)); GB_TRY(seg_b.alloc(4 * (size_t)n));
+    GB_TRY(cb.alloc(24 * cap)); GB_TRY(bins.alloc(4 * (size_t)kBinWords * cap)); GB_TRY(split.alloc(sizeof(SahSplit) * cap));
+    GB_TRY(active.alloc(4 * cap)); GB_TRY(cbase.alloc(4 * cap)); GB_TRY(flags.alloc(4 * (size_t)n)); GB_TRY(scan.alloc(4 * (size_t)n));
+    GB_TRY(segtab.alloc(4 * 6 * cap));
+    size_t scan_bytes = 0;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.as<uint32_t>(), scan.as<uint32_t>(), n, stream));
+    GB_TRY(scan_tmp.alloc(scan_bytes));
+    SahSegs cur_s{segtab.as<uint32_t>(), segtab.as<uint32_t>() + cap, segtab.as<uint32_t>() + 2 * cap};
+    SahSegs nxt_s{segtab.as<uint32_t>() + 3 * cap, segtab.as<uint32_t>() + 4 * cap, segtab.as<uint32_t>() + 5 * cap};
+    hipLaunchKernelGGL(sah_tri_boxes_kernel, grid_t, block, 0, stream, d_P, d_idx, n_tris, tlo.as<float>(), thi.as<float>());
+    // level 0: one segment [0, n) = node 0, triangles in Morton order (d_order holds the sorted ids)
+    uint32_t *ids_in = d_order, *ids_out = ids_b.as<uint32_t>(), *seg_in = seg_a.as<uint32_t>(), *seg_out = seg_b.as<uint32_t>();
+    GB_TRY(hipMemsetAsync(seg_in, 0, 4 * (size_t)n, stream));
+    const uint32_t seg0[3] = {0u, (uint32_t)n, 0u};
+    GB_TRY(hipMemcpyAsync(cur_s.start, &seg0[0], 4, hipMemcpyHostToDevice, stream));
+    GB_TRY(hipMemcpyAsync(cur_s.end, &seg0[1], 4, hipMemcpyHostToDevice, stream));
+    GB_TRY(hipMemcpyAsync(cur_s.node, &seg0[2], 4, hipMemcpyHostToDevice, stream));
+    GB_TRY(hipStreamSynchronize(stream));  // (seg0 is a local)
+    uint32_t n_seg = 1u, next_node = 1u;
+    for (uint32_t level = 0; n_seg > 0u; level++) {
+      if (level > 4096u) return hipErrorUnknown;  // (halving past kSahMedianLevel ends every segment long before)
+      const dim3 gs((n_seg + 127u) / 128u), b128(128);
+      // centre bounds: min words ~0, max words 0 (a strided memset over the second half of every 24-byte record)
+      GB_TRY(hipMemsetAsync(cb.p, 0xff, 24 * (size_t)n_seg, stream));
+      GB_TRY(hipMemset2DAsync((char *)cb.p + 12, 24, 0, 12, n_seg, stream));
+      GB_TRY(hipMemsetAsync(bins.p, 0, 4 * (size_t)kBinWords * n_seg, stream));
+      hipLaunchKernelGGL(sah_bounds_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, tlo.as<float>(), thi.as<float>(), cb.as<uint32_t>());
+      hipLaunchKernelGGL(sah_prepare_kernel, gs, b128, 0, stream, (int)n_seg, cb.as<uint32_t>(), split.as<SahSplit>());
+      // bins: counts 0, box lo words ~0 (hi words 0 already)
+      GB_TRY(hipMemset2DAsync((char *)bins.p + 4, 28, 0xff, 12, (size_t)n_seg * kSahBuckets, stream));
+      hipLaunchKernelGGL(sah_bins_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, tlo.as<float>(), thi.as<float>(), split.as<SahSplit>(), bins.as<uint32_t>());
+      hipLaunchKernelGGL(sah_split_kernel, gs, b128, 0, stream, (int)n_seg, cur_s, bins.as<uint32_t>(), split.as<SahSplit>(), level, bx.as<unsigned long long>(),
+                         active.as<uint32_t>());
+      GB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, active.as<uint32_t>(), cbase.as<uint32_t>(), (int)n_seg, stream));
+      hipLaunchKernelGGL(sah_flags_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, tlo.as<float>(), thi.as<float>(), cur_s, split.as<SahSplit>(), flags.as<uint32_t>());
+      GB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, flags.as<uint32_t>(), scan.as<uint32_t>(), n, stream));
+      hipLaunchKernelGGL(sah_scatter_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, cur_s, split.as<SahSplit>(), flags.as<uint32_t>(), scan.as<uint32_t>(),
+                         cbase.as<uint32_t>(), ids_out, seg_out);
+      hipLaunchKernelGGL(sah_children_kernel, gs, b128, 0, stream, (int)n_seg, cur_s, split.as<SahSplit>(), cbase.as<uint32_t>(), next_node, child.as<uint32_t>(), nxt_s);
+      GB_TRY(hipGetLastError());
+      uint32_t last[2];  // exclusive sum and count of the last segment: the next level's segment count
+      GB_TRY(hipMemcpyAsync(&last[0], cbase.as<uint32_t>() + (n_seg - 1u), 4, hipMemcpyDeviceToHost, stream));
+      GB_TRY(hipMemcpyAsync(&last[1], active.as<uint32_t>() + (n_seg - 1u), 4, hipMemcpyDeviceToHost, stream));
+      GB_TRY(hipStreamSynchronize(stream));
+      n_seg = last[0] + last[1];
+      next_node += n_seg;
+      { uint32_t *t = ids_in; ids_in = ids_out; ids_out = t; }
+      { uint32_t *t = seg_in; seg_in = seg_out; seg_out = t; }
+      { SahSegs t = cur_s; cur_s = nxt_s; nxt_s = t; }
+    }
+    // leaf boxes and the final leaf order (slot k holds triangle ids[k])
+    hipLaunchKernelGGL(sah_leaf_boxes_kernel, grid_t, block, 0, stream, ids_in, n, tlo.as<float>(), thi.as<float>(), bx.as<unsigned long long>(), ids_out);
+    if (ids_out != d_order) GB_TRY(hipMemcpyAsync(d_order, ids_out, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    GB_TRY(hipGetLastError());
+    GB_TRY(hipStreamSynchronize(stream));  // (the scratch above is freed when this block ends)
+    root_node = 0u;
+  } else {
+    // PLOC rounds.  Scratch reuse: keys / keys_out hold the two cluster lists (the Morton keys are no longer needed),
+    // par_i the nearest neighbours; flags / scan are 64-bit per cluster.  The host reads the list length once a round.
+    Tmp flags, scan, scan_tmp, total;
+    GB_TRY(flags.alloc(8 * (size_t)n));
+    GB_TRY(scan.alloc(8 * (size_t)n));
+    GB_TRY(total.alloc(16));
+    size_t scan_bytes = 0;
+    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.as<unsigned long long>(), scan.as<unsigned long long>(), n, stream));
+    GB_TRY(scan_tmp.alloc(scan_bytes));
+    uint32_t *cl_in = keys.as<uint32_t>(), *cl_out = keys_out.as<uint32_t>();
+    hipLaunchKernelGGL(ploc_init_kernel, grid_t, block, 0, stream, d_P, d_idx, d_order, n, bx.as<unsigned long long>(), cl_in);
+    int m = n;
+    uint32_t next_node = 0u;
+    while (m > 1) {
+      const dim3 gm((uint32_t)(m + 255) / 256u);
+      hipLaunchKernelGGL(ploc_nn_kernel, gm, block, 0, stream, cl_in, m, n, bx.as<unsigned long long>(), par_i.as<uint32_t>());
+      hipLaunchKernelGGL(ploc_flag_kernel, gm, block, 0, stream, par_i.as<uint32_t>(), m, flags.as<unsigned long long>());
+      GB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, flags.as<unsigned long long>(), scan.as<unsigned long long>(), m, stream));
+      hipLaunchKernelGGL(ploc_merge_kernel, gm, block, 0, stream, cl_in, par_i.as<uint32_t>(), flags.as<unsigned long long>(), scan.as<unsigned long long>(), m, n,
+                         next_node, child.as<uint32_t>(), bx.as<unsigned long long>(), cl_out);
+      GB_TRY(hipGetLastError());
+      unsigned long long last[2];  // exclusive sum and flag of the last cluster: their sum is the round's total
+      GB_TRY(hipMemcpyAsync(&last[0], scan.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+      GB_TRY(hipMemcpyAsync(&last[1], flags.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost, stream));
+      GB_TRY(hipStreamSynchronize(stream));
+      const unsigned long long tot = last[0] + last[1];
+      const int m_next = (int)(uint32_t)tot;
+      next_node += (uint32_t)(tot >> 32);
+      if (m_next >= m) return hipErrorUnknown;  // (cannot happen: the closest pair of the list is always mutual)
+      m = m_next;
+      uint32_t *t = cl_in; cl_in = cl_out; cl_out = t;
+    }
+    root_node = next_node - 1u;  // the last merge made the root (n - 1 internal nodes: ids 0 .. n - 2)
+  }
 
   // top-down collapse, one launch per level of the quad tree.  The host does not know how many items a level holds
   // (the kernel reads the count the level above left on the device) nor how deep the tree is: it launches kBatch
   // levels blind -- level L holds at most min(4^L, n) items -- and looks at the device once per batch.
   constexpr uint32_t kBatch = 48;
-  const CollapseItem root{0u, 0u, 0u};
+  const CollapseItem root{root_node, 0u, 0u};
   GB_TRY(hipMemcpyAsync(q0.p, &root, sizeof(root), hipMemcpyHostToDevice, stream));
   uint32_t h_counters[2] = {1u, 0u};  // quad 0 is the root's
   GB_TRY(hipMemcpyAsync(counters.p, h_counters, sizeof(h_counters), hipMemcpyHostToDevice, stream));
@@ -358,8 +756,8 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
     if (!first) break;
   }
   GB_TRY(hipMemcpyAsync(h_counters, counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, stream));
-  float root_box[6];  // {lo.x lo.y lo.z hi.x hi.y hi.z} of node 0
-  GB_TRY(hipMemcpyAsync(root_box, bx.p, 24, hipMemcpyDeviceToHost, stream));
+  float root_box[6];  // {lo.x lo.y lo.z hi.x hi.y hi.z} of the root
+  GB_TRY(hipMemcpyAsync(root_box, bx.as<unsigned long long>() + 3 * (size_t)root_node, 24, hipMemcpyDeviceToHost, stream));
   GB_TRY(hipEventRecord(e1, stream));
   GB_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;

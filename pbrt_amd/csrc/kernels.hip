@@ -416,22 +416,11 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       bool hit[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-#ifdef PBRT_SDWA_DECODE
-        // A-B variant: a byte read as the low bits of a float is the denormal byte * 2^-149; times 2^120 it is
-        // byte * 2^-29 exactly (one v_mul_f32 with an SDWA byte select, a full-rate instruction, instead of the
-        // half-rate v_cvt_f32_ubyte), and fma(that, ci * 2^29, -g) rounds the same real number as fma(byte, ci, -g)
-        auto dq = [](uint32_t w, int kk) { return __uint_as_float((w >> (8 * kk)) & 0xffu) * 0x1p120f; };
-        const f32x2 tx = {fmaf(dq(bnx, k), cix * 0x1p29f, -gxx.x), fmaf(dq(bfx, k), cix * 0x1p29f, -gxx.y)};
-        const f32x2 ty = {fmaf(dq(bny, k), ciy * 0x1p29f, -gyy.x), fmaf(dq(bfy, k), ciy * 0x1p29f, -gyy.y)};
-        const f32x2 tz = {fmaf(dq(bnz, k), ciz * 0x1p29f, -gzz.x), fmaf(dq(bfz, k), ciz * 0x1p29f, -gzz.y)};
-        (void)cxx; (void)cyy; (void)czz;
-#else
         const f32x2 qx = {(float)((bnx >> (8 * k)) & 0xffu), (float)((bfx >> (8 * k)) & 0xffu)};
         const f32x2 qy = {(float)((bny >> (8 * k)) & 0xffu), (float)((bfy >> (8 * k)) & 0xffu)};
         const f32x2 qz = {(float)((bnz >> (8 * k)) & 0xffu), (float)((bfz >> (8 * k)) & 0xffu)};
         const f32x2 tx = __builtin_elementwise_fma(qx, cxx, -gxx), ty = __builtin_elementwise_fma(qy, cyy, -gyy);
         const f32x2 tz = __builtin_elementwise_fma(qz, czz, -gzz);
-#endif
         const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kRayTMin));
         const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar));
         hit[k] = tn <= tf * kBoxPad;
