@@ -15,7 +15,7 @@ sd = scenes.random_mesh_scene(n, res, res)
 with pbrt_amd.Scene(sd, builder=os.environ.get("PROBE_BUILDER")) as sc:
     print("accelerator:", sc.build_info(), sc.info())
     world = int(os.environ.get("PROBE_WORLD", "1"))  # PROBE_WORLD=8: rank 0's share of an 8-GPU job (strong scaling)
-    film, st = sc.render(max_depth=8, spp=spp, seed=0, world_size=world)
+    film, st = sc.render(max_depth=8, spp=spp, seed=0, world_size=world, rank=int(os.environ.get("PROBE_RANK", "0")))
     print(wl, spp, "world", world, "kernel_ms", st["kernel_ms"], "Msamples/s", st["samples"] / st["kernel_ms"] / 1e3)
     if os.environ.get("PROBE_COUNTERS"):
         _, ex = sc.render(max_depth=8, spp=spp, seed=0, counters=True)
