@@ -2,7 +2,7 @@
 # rank 0's share of the C3 frame at the full 512 spp for 1, 2, 4, 8 ranks (strong scaling projection: one MI355X renders
 # the share rank 0 of an N-GPU job would render) -- DESIGN.md section 7
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02_shares; mkdir -p $O
+O=$R/gpurun_out/rank_shares; mkdir -p $O
 cd $R
 for w in 1 2 4 8; do
   echo -n "world $w: " >> $O/shares.txt
