@@ -3,6 +3,8 @@ same seeded inputs.  Bar: BIT-EXACT -- every fp32 operation of the path is +,-,*
 comparison, executed in the same order on both sides with FMA contraction off,
 so the film, the hit records and the visit counters must be identical, not merely close.
 (BASELINE.json asks for PSNR >= 50 dB; identical images are PSNR = inf.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,7 +27,8 @@ def test_native_library_is_the_one_loaded(gpu):
     maps = open("/proc/self/maps").read()
     gpu.api.lib()
     maps = open("/proc/self/maps").read()
-    assert "pbrt_amd/lib/libpbrt_hip.so" in maps
+    from pbrt_amd import _lib
+    assert os.path.realpath(_lib.LIB_PATH) in maps and "/pbrt_amd/lib" in _lib.LIB_PATH  # (lib_<variant>/ for A-B builds)
 
 
 @pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere", "ties", "deep"])
@@ -413,8 +416,14 @@ def test_native_cli_renders_c0(gpu, tmp_path):
     from pbrt_amd import loader
     ls = loader.load_string(scene.read_text())
     with gpu.Scene(ls.scene) as sc:
-        film, _ = sc.render(integrator=ls.integrator, max_depth=ls.max_depth, spp=(ls.spp[0] // 2, ls.spp[1] // 2))
-    assert_bit_equal(img, gpu.film_to_rgb(film), "CLI image vs library render")  # PFM is lossless
+        kw = dict(ls.render_kwargs(), spp=(ls.spp[0] // 2, ls.spp[1] // 2))  # --quick; Sampler "halton" -> the (0,2)-sequence sampler
+        film, _ = sc.render(**kw)
+    assert_bit_equal(img, gpu.film_to_rgb(film, scale=ls.film_scale), "CLI image vs library render")  # PFM is lossless
+    # the CLI renders through pbrt_hip_render_multi on every visible GPU; --gpus 1 must give the same image
+    out1 = tmp_path / "o1.pfm"
+    r = subprocess.run([CLI_PATH, "-q", "--quick", "--gpus", "1", "-o", str(out1), str(scene)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert_bit_equal(gpu.read_image(out1), img, "CLI --gpus 1 vs all GPUs")
     assert subprocess.run([CLI_PATH, "-q", str(tmp_path / "missing.pbrt")], capture_output=True).returncode == 1
 
 

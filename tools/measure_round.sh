@@ -13,7 +13,7 @@ WLS=${@:-c3 big}
 O=$R/gpurun_out
 cd $R
 export PBRT_HIP_DEBUG_KNOBS=1
-timeout 1800 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/${TAG}_pytest_gpu.log
+timeout 1800 python3 -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -4 > $O/${TAG}_pytest_gpu.log
 python3 -c "from oracle import binding as ob; ob.build(native=True)"   # (the CPU leg's oracle is built before any profiler runs)
 for w in $WLS; do
   cd /tmp && export TMPDIR=/tmp
