@@ -20,6 +20,11 @@ add("DEP", "v_fma_f32 (one dependent chain)")
 add("MIX", "node-step mix: 2 cvt_ubyte, pk_fma, max3, 2 min, cmp, cndmask")
 add("MAD64", "v_mad_u64_u32")
 add("READLANE", "v_readfirstlane_b32")
+add("MIXF", "v_fma_mix_f32 (f32 operands)", "v_fma_mix_f32 (src0 = low f16)", "v_fma_mix_f32 (src0 = high f16)")
+add("F1", "v_cvt_f32_f16")
+add("F3", "v_pk_fma_f16")
+add("F2", "v_pk_min_f16", "v_pk_max_f16", "v_pk_mul_f16")
+add("SDWA", "v_mul_f32_sdwa (src0 = byte 1)")
 add("DSW", "ds_write_b32", )
 add("DSR", "ds_read_b32", )
 
@@ -35,6 +40,11 @@ def body(kind, mn):
                     '        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db), "v"(dc));)\n'
                     '    a[0] = (float)d0; a[1] = (float)d1; a[2] = (float)d2; a[3] = (float)d3;\n')
         return f'    REP8(asm volatile({rep(mn + " %K, %K, %8, %9")} : {regs8} : "v"(b), "v"(c));)\n'
+    if kind == "MIXF":
+        sel = " op_sel_hi:[1,0,0]" if "low f16" in mn else (" op_sel:[1,0,0] op_sel_hi:[1,0,0]" if "high f16" in mn else "")
+        return f'    REP8(asm volatile({rep("v_fma_mix_f32 %K, %8, %9, %K" + sel)} : {regs8} : "v"(u), "v"(c));)\n'
+    if kind == "SDWA":
+        return f'    REP8(asm volatile({rep("v_mul_f32_sdwa %K, %8, %K dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD")} : {regs8} : "v"(u));)\n'
     if kind == "F2":
         return f'    REP8(asm volatile({rep(mn + " %K, %K, %8")} : {regs8} : "v"(b));)\n'
     if kind == "F2R":
