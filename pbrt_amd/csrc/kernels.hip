@@ -475,6 +475,13 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
          (uint32_t)__popcll(mleaf) * 2u >= (uint32_t)__popcll(__ballot(T.cur != kDone && !parked)))) {
       const uint32_t cnt = parked ? (T.cur >> 24) & 0x7fu : 0u, first = T.cur & 0xffffffu;
       bool stop = false;  // any-hit ray found its hit
+#ifdef PBRT_PHASE_PROBE
+      {  // flushes, and the passes they would take if the (lane, triangle) items were spread over all 64 lanes
+        uint32_t items = 0;
+        for (uint32_t i = 0; i < 8; i++) items += (uint32_t)__popcll(__ballot(cnt > i));
+        PROBE_ADD(6, 1); PROBE_ADD(7, (items + 63u) / 64u);
+      }
+#endif
       for (uint32_t i = 0;; i++) {
         if (__ballot(cnt > i && !stop) == 0ull) break;
         PROBE_ADD(2, 1); PROBE_ADD(3, __popcll(__ballot(cnt > i && !stop)));
@@ -1027,8 +1034,8 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
 
 #ifdef PBRT_PHASE_PROBE
 __global__ void probe_dump() {
-  printf("PROBE step waves %llu lanes %llu | flush waves %llu lanes %llu | service waves %llu lanes %llu\n", g_probe[0], g_probe[1],
-         g_probe[2], g_probe[3], g_probe[4], g_probe[5]);
+  printf("PROBE step waves %llu lanes %llu | flush waves %llu lanes %llu | service waves %llu lanes %llu | flushes %llu dense passes %llu\n",
+         g_probe[0], g_probe[1], g_probe[2], g_probe[3], g_probe[4], g_probe[5], g_probe[6], g_probe[7]);
   for (int i = 0; i < 8; i++) g_probe[i] = 0;
 }
 #endif
