@@ -39,7 +39,9 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     # -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into v_pk_mul / v_pk_add_f32, which issue at half
     # rate on gfx950 (tools/ubench) and need v_mov_b64 copies into aligned register pairs: without it render_kernel has the
     # same instruction count, 13 VGPRs fewer and runs 3 % faster (the packed forms written by hand in the node step stay)
-    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
+    # -amdgpu-sdwa-peephole=0: SDWA forms are half rate too, and the peephole costs render_kernel 10 VGPRs (106 -> 96: five
+    # waves per SIMD without a spill)
+    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sdwa-peephole=0", "-Wall",
               "-Wno-unused-function", f"--offload-arch={ARCH}"] + extra_flags
     def compile_one(src):
         obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")

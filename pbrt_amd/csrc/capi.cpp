@@ -72,9 +72,10 @@ uint32_t tuning(const char *name, uint32_t dflt, long cap = 64) {
 // min_walkers: 36 for deep trees (long walks: C3 +1 % over 32), 20 for shallow ones, where a frame is mostly shading and
 // the shading stage should wait for more lanes (C4 +12 % over 36)
 constexpr uint32_t kMinWalkers = 36, kMinWalkersShallow = 20, kShallowStackNeed = 16, kMinParked = 16;
-// persistent one-wave workgroups of the render kernel per CU: what a CU holds at once (4 SIMDs x 4 waves; the 10 KB LDS
-// stack and the 128-VGPR budget both allow exactly that); the grid is this x the device's CU count (hipDeviceProp_t)
-constexpr uint32_t kRenderWavesPerCu = 16, kRenderWavesPerCuSpheres = 12;
+// persistent one-wave workgroups of the render kernel per CU = what a CU holds at once: render_stack_plan (device_types.h:
+// 20 with up to 32 LDS rows -- 5 waves per SIMD by the kernel's 96 VGPRs --, fewer with more rows); the kernel for scenes
+// with spheres has the register budget of 3 waves per SIMD.  The grid is this x the device's CU count (hipDeviceProp_t)
+constexpr uint32_t kRenderWavesPerCuSpheres = 12;
 constexpr uint32_t kLeafRef = 0x80000000u;
 
 // A vertex that a triangle uses and that is NaN or infinite would send the builders' bucket index out of range:
@@ -690,6 +691,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     D.n_tris = nt;
     D.n_spheres = d->n_spheres;
     D.n_lights = s->n_lights;
+    D.n_lights_f = (float)s->n_lights;
     for (int k = 0; k < 3; k++) D.le_inf[k] = le_inf[k];
     D.has_inf = has_inf ? 1u : 0u;
     for (int k = 0; k < 12; k++) D.c2w[k] = d->cam_to_world[k];
@@ -807,12 +809,20 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     const uint32_t spp = r->spp_x * r->spp_y;
     R.spp_mask = 0;
     while (R.spp_mask + 1u < spp) R.spp_mask = 2u * R.spp_mask + 1u;
+    // reciprocals for the kernel's two divisions by run-time values (kernels.hip pixel_xy, stratified sample): ceil(2^32 / d);
+    // tsup / stx is exact while tsup * stx < 2^32
+    auto recip32 = [](uint32_t d) { return d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1u) / d); };
+    R.stx_recip = recip32(sh.stx);
+    R.spp_x_recip = recip32(r->spp_x);
+    if ((uint64_t)sh.total * (uint64_t)sh.stx >= (1ull << 32))
+      return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for the kernel's tile arithmetic");
     // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once (16 per CU: the
     // LDS stack and the register budget both allow 4 per SIMD), each lane drawing item after item from the rank's list.
     // An item is one CHUNK (an eighth of the samples) of one pixel: DESIGN.md 3.1.
     R.n_items = sh.n_local * 4096u * 8u;
     // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
-    const uint32_t waves_per_cu = s->dev.n_spheres ? kRenderWavesPerCuSpheres : kRenderWavesPerCu;
+    const RenderStackPlan plan = render_stack_plan(s->dev.quad_stack_need, render_force_overflow(), render_prefer_lds());
+    const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, plan.waves_per_cu) : plan.waves_per_cu;
     R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u * 8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
     R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
@@ -827,8 +837,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       R.partials = s->d_partials.p;
     }
     {
-      // the quad walk keeps kQuadLdsStack entries per lane in LDS; deeper entries (rare) spill here
-      const uint32_t extra = s->dev.quad_stack_need + 2u > kQuadLdsStack ? s->dev.quad_stack_need + 2u - kQuadLdsStack : 0;  // sentinel + entries beyond the kQuadLdsStack - 1 kept in LDS
+      // the overflow variant keeps kQuadLdsStackOvf rows per lane in LDS; deeper entries (rare) go here
+      const uint32_t extra = plan.extra_entries;
       const size_t need = (size_t)R.n_workgroups * 64 * extra;
       if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); HIP_TRY(s->d_stack_overflow.alloc(need)); }
       R.stack_overflow = s->d_stack_overflow.p;

@@ -26,11 +26,46 @@ inline const char *debug_knob(const char *name) {
   return std::getenv(name);
 }
 
-#ifndef PBRT_QUAD_LDS_STACK
-#define PBRT_QUAD_LDS_STACK 40
+// LDS stack of the production (quad) walk: one row = 64 lanes x 4 bytes.  A row count r serves trees whose worst-case stack
+// bound is r - 2 (the sentinel and one scratch row).  The render kernel takes its rows as DYNAMIC shared memory, sized per
+// scene (render_stack_plan below): up to 32 rows a CU holds 20 one-wave workgroups (160 KB of LDS; the kernel's 96 VGPRs
+// allow 5 waves per SIMD), 40 rows allow 16.  Trees beyond kQuadLdsStack rows -- or, for the render kernel, beyond what
+// still leaves 18 waves per CU -- run the overflow variant: kQuadLdsStackOvf rows in LDS, deeper entries in HBM.
+// -DPBRT_QUAD_LDS_STACK=12 forces the overflow variant on nearly every scene (tests of that path).
+#ifdef PBRT_QUAD_LDS_STACK
+constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK, kQuadLdsStackOvf = PBRT_QUAD_LDS_STACK;
+#else
+constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 32;
 #endif
-constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK;
-constexpr uint32_t kQuadLdsEntries = kQuadLdsStack - 1u;  // entries kept in LDS (the sentinel first); the last row is scratch  // LDS entries per lane of the quad walk's stack
+constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
+
+struct RenderStackPlan {
+  uint32_t rows;           // LDS rows per wave
+  bool overflow;           // the overflow variant (rows == kQuadLdsStackOvf)
+  uint32_t waves_per_cu;   // one-wave workgroups a CU holds at once with these rows (at most 20: 5 per SIMD by registers)
+  uint32_t extra_entries;  // HBM entries per lane beyond the LDS part (overflow variant)
+};
+inline RenderStackPlan render_stack_plan(uint32_t quad_stack_need, bool force_overflow, bool prefer_lds = false) {
+  RenderStackPlan p;
+  const uint32_t need_rows = quad_stack_need + 2u;
+  auto waves = [](uint32_t rows) { const uint32_t w = kLdsBytesPerCu / (rows * 256u); return w > 20u ? 20u : w; };
+  p.rows = need_rows < 8u ? 8u : need_rows;
+  p.overflow = force_overflow || need_rows > kQuadLdsStack || (waves(p.rows) < 18u && !prefer_lds);
+  if (p.overflow) p.rows = kQuadLdsStackOvf;
+  p.waves_per_cu = waves(p.rows);
+  p.extra_entries = p.overflow && need_rows > p.rows ? need_rows - p.rows : 0u;
+  return p;
+}
+inline bool render_prefer_lds() {  // A-B runs: the whole stack in LDS whenever it fits kQuadLdsStack rows, whatever the occupancy
+  static const bool f = debug_knob("PBRT_HIP_PREFER_LDS_STACK") != nullptr;
+  return f;
+}
+inline bool render_force_overflow() {  // A-B runs
+  static const bool f = debug_knob("PBRT_HIP_FORCE_OVERFLOW_VARIANT") != nullptr;
+  return f;
+}
+// the traversal kernel over ray batches keeps static rows
+constexpr uint32_t kQuadLdsEntries = kQuadLdsStack - 1u;
 
 struct DevScene {
   const uint4 *nodes;
@@ -41,6 +76,7 @@ struct DevScene {
   const float4 *lights;
   const float4 *spheres;
   uint32_t n_nodes, n_tris, n_spheres, n_lights;  // n_nodes: nodes of the binary tree (0 = no triangles)
+  float n_lights_f;                                 // (float)n_lights
   uint32_t root_ref;                                // ref of the root (a leaf ref for tiny scenes)
   float root_lo[3], root_hi[3];                     // its box
   float le_inf[3];
@@ -68,6 +104,7 @@ struct RenderParams {
   float4 *partials;       // [slab position][8]: the partial film sums of the chunks (merge_kernel adds them in order)
   uint32_t sampler;       // PBRT_HIP_SAMPLER_*
   uint32_t spp_mask;      // Sobol sampler: 2^ceil(log2(spp)) - 1
+  uint32_t stx_recip, spp_x_recip;  // ceil(2^32 / super-tiles per row), ceil(2^32 / spp_x): the kernel's divisions by these two
 };
 
 struct RayBatch {

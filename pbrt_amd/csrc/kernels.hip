@@ -175,6 +175,12 @@ __device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) { return (uint32
 __device__ __forceinline__ void lds_store(uint32_t a, uint32_t v) { *(lds_u32 *)(uintptr_t)a = v; }
 __device__ __forceinline__ uint32_t lds_load(uint32_t a) { return *(const lds_u32 *)(uintptr_t)a; }
 constexpr uint32_t kRowBytes = 256u;  // one stack row = 64 lanes x 4 bytes: consecutive entries of a lane are one row apart
+// row of the entry at LDS address `a` of the stack whose lane column starts at `stk`: measured from the ARRAY's base, a
+// link-time constant, so that no per-lane limit has to be kept in a register (the lane's 4-byte column offset is below a row)
+// the lane number where it is needed only on a rare path: opaque to the optimiser, so that nothing derived from it is
+// hoisted out of the kernel's loop into a register that lives for the whole kernel
+__device__ __forceinline__ uint32_t lane_here() { uint32_t l = threadIdx.x & 63u; asm volatile("" : "+v"(l)); return l; }
+__device__ __forceinline__ uint32_t lds_row(uint32_t a, const uint32_t *stk) { return (a - lds_addr(stk - (threadIdx.x & 63u))) / kRowBytes; }
 
 // Per-lane traversal state.  It lives in registers across iterations of the kernels' outer loops,
 // so a lane can be suspended in the middle of a walk while other lanes of the wave are served.
@@ -209,7 +215,7 @@ __device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx,
 // as visited and re-tests `tn <= tfar * pad`, which is equivalent to the oracle's slab test of the
 // popped node with the current tfar (the far-plane part of that test can only have loosened).
 // Otherwise entries are bare refs and a popped node is simply processed (a superset walk).
-template <bool EXACT, bool OVF>
+template <bool EXACT, uint32_t OVFR>  // OVFR: rows of the LDS part when deeper entries go to HBM (overflow variant), else 0
 __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf, unsigned long long &cn) {
   if (EXACT) {
     while (T.sp != 0u) {
@@ -223,21 +229,21 @@ __device__ __forceinline__ uint32_t trav_pop(Trav &T, uint32_t *stk, float *stkt
   }
   // production walk: entry 0 is the sentinel kDone (trav_begin), so a pop needs no emptiness test
   T.sp -= kRowBytes;
-  if (!OVF) return lds_load(T.sp);
-  const uint32_t e = (T.sp - lds_addr(stk)) / kRowBytes;
-  return e < kQuadLdsEntries ? lds_load(T.sp) : ovf[(e - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)];
+  if (OVFR == 0u) return lds_load(T.sp);
+  const uint32_t e = lds_row(T.sp, stk);
+  return e < OVFR - 1u ? lds_load(T.sp) : ovf[(e - (OVFR - 1u)) * 64u + lane_here()];
 }
-// production walk: the LDS part of a lane's stack has kQuadLdsStack rows = kQuadLdsEntries entries (the
+// production walk: the LDS part of a lane's stack has OVFR rows = OVFR - 1 entries (the
 // sentinel first) + one scratch row, which the branch-free pushes below write when they do not push.  Only for
 // trees whose worst-case bound exceeds that (OVF) do the deeper entries go to a per-lane HBM area.
-template <bool OVF>
+template <uint32_t OVFR>
 __device__ __forceinline__ void trav_push(Trav &T, uint32_t *stk, uint32_t *ovf, uint32_t ref) {
-  if (!OVF) {
+  if (OVFR == 0u) {
     lds_store(T.sp, ref);
   } else {
-    const uint32_t e = (T.sp - lds_addr(stk)) / kRowBytes;
-    if (e < kQuadLdsEntries) lds_store(T.sp, ref);
-    else ovf[(e - kQuadLdsEntries) * 64u + (threadIdx.x & 63u)] = ref;
+    const uint32_t e = lds_row(T.sp, stk);
+    if (e < OVFR - 1u) lds_store(T.sp, ref);
+    else ovf[(e - (OVFR - 1u)) * 64u + lane_here()] = ref;
   }
   T.sp += kRowBytes;
 }
@@ -304,7 +310,7 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
 //     lanes keep their state and resume on the next call.
 // `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
 // caller once its walk is over.
-template <bool EXACT, bool COUNT, bool OVF, int STEPS = PBRT_STEPS_PER_CHECK>
+template <bool EXACT, bool COUNT, uint32_t OVFR, int STEPS = PBRT_STEPS_PER_CHECK>
 __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf,
                                          const bool alive, const TravTuning tune, unsigned long long &cn,
                                          unsigned long long &ct) {
@@ -356,7 +362,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         stkt[T.sp * 64u] = hit_far ? (far_first ? tn0 : tn1) : __builtin_nanf("");
         T.sp++;
       }
-      trav_enter(T, hit_near ? ref_near : trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
+      trav_enter(T, hit_near ? ref_near : trav_pop<EXACT, OVFR>(T, stk, stkt, ovf, cn));
     }
 
     // production walk: STEPS node steps between two scheduling checks (a lane that parks or
@@ -440,15 +446,18 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const bool n3 = !n0 && !n1 && !n2;
       const bool any_hit = hit[0] || hit[1] || hit[2] || hit[3];
       const uint32_t nearest = n0 ? W3.x : (n1 ? W3.y : (n2 ? W3.z : W3.w));
-      // OVF (trees whose worst-case stack bound exceeds the LDS part): one wave-uniform test per step -- is any lane
-      // within four entries of the end of its LDS part? -- picks the slow form with predicated pushes that spill
-      // to HBM; stacks rarely get that deep, so nearly every step takes the branch-free form below.
-      if (OVF && __ballot(T.sp + 4u * kRowBytes > lds_addr(stk) + kQuadLdsEntries * kRowBytes) != 0ull) {
-        if (hit[3] && !n3) trav_push<true>(T, stk, ovf, W3.w);
-        if (hit[2] && !n2) trav_push<true>(T, stk, ovf, W3.z);
-        if (hit[1] && !n1) trav_push<true>(T, stk, ovf, W3.y);
-        if (hit[0] && !n0) trav_push<true>(T, stk, ovf, W3.x);
-        trav_enter(T, any_hit ? nearest : trav_pop<false, true>(T, stk, stkt, ovf, cn));
+      // Overflow variant (trees whose worst-case stack bound exceeds the LDS part): one wave-uniform test per step -- is
+      // any lane within four rows of the end of its LDS part? -- picks the slow form with predicated pushes that go
+      // to HBM beyond it; stacks rarely get that deep, so nearly every step takes the branch-free form below.  (One
+      // compare against a constant: the stack array's base is a link-time constant, the lane's column offset is
+      // smaller than a row.  A test per batch of steps instead, with a threshold three times as far from the end,
+      // measured 1.5 % slower.)
+      if (OVFR != 0u && __ballot(T.sp >= lds_addr(stk - (threadIdx.x & 63u)) + (OVFR - 4u) * kRowBytes) != 0ull) {
+        if (hit[3] && !n3) trav_push<OVFR>(T, stk, ovf, W3.w);
+        if (hit[2] && !n2) trav_push<OVFR>(T, stk, ovf, W3.z);
+        if (hit[1] && !n1) trav_push<OVFR>(T, stk, ovf, W3.y);
+        if (hit[0] && !n0) trav_push<OVFR>(T, stk, ovf, W3.x);
+        trav_enter(T, any_hit ? nearest : trav_pop<false, OVFR>(T, stk, stkt, ovf, cn));
       } else {
         // branch-free: each ref is written above the stack top in any case (one LDS row beyond the entries is
         // scratch) and the top advances by the hit mask; entry 0 is the sentinel kDone, so the entry below the top
@@ -517,12 +526,17 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           }
         }
       }
+      // (OVF: is any entry about to be popped one of the rare ones beyond the LDS part?  wave-uniform, as for the pushes)
+      const bool far_pop = OVFR != 0u && !EXACT &&
+                           __ballot(parked && !stop && T.sp >= lds_addr(stk - (threadIdx.x & 63u)) + OVFR * kRowBytes) != 0ull;
       if (parked) {  // leave the leaf: the walk is over (any-hit found) or the next node comes off the stack
         if (stop) {
           T.cur = kDone;
           T.sp = 0u;
+        } else if (OVFR != 0u && far_pop) {
+          trav_enter(T, trav_pop<EXACT, OVFR>(T, stk, stkt, ovf, cn));
         } else {
-          trav_enter(T, trav_pop<EXACT, OVF>(T, stk, stkt, ovf, cn));
+          trav_enter(T, trav_pop<EXACT, 0u>(T, stk, stkt, ovf, cn));
         }
       }
     }
@@ -611,7 +625,7 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FET
 
 // waves per SIMD the register allocator must leave room for (launch_bounds' 2nd argument)
 #ifndef PBRT_RENDER_WAVES_PER_SIMD
-#define PBRT_RENDER_WAVES_PER_SIMD 4
+#define PBRT_RENDER_WAVES_PER_SIMD 5
 #endif
 
 #ifdef PBRT_RAY_LOG
@@ -634,15 +648,34 @@ struct PathState {
 // shadow ray comes back unoccluded) and record 4 (the chunk's partial film sum so far) are read and written only where
 // they are used -- by the lanes whose ray was a shadow ray, and once per finished sample -- and never sit in registers
 // beside the shading arithmetic (r01 loaded all five on every visit: 6 more live VGPRs, 40 % more record traffic).
-constexpr uint32_t kRecLpend = 192u, kRecSum = 256u;
-__device__ __forceinline__ void path_store(float4 *rec, const PathState &P) {
-  rec[0] = make_float4(P.L.x, P.L.y, P.L.z,
-                       __uint_as_float(P.s | (P.bounces << 20) | (P.specular ? 1u << 30 : 0u) | (P.cont ? 1u << 31 : 0u)));
-  rec[64] = make_float4(P.beta.x, P.beta.y, P.beta.z, __uint_as_float((uint32_t)P.rng.state));
-  rec[128] = make_float4(P.wi_next.x, P.wi_next.y, P.wi_next.z, __uint_as_float((uint32_t)(P.rng.state >> 32)));
+// The lane's five records lie 1 KB apart around a wave-uniform base that points at record 2: -2048 ... +2048 bytes, all
+// within the immediate offset of a global load / store.  The address is formed at each access from the uniform base (an
+// SGPR pair) and the lane's 32-bit byte offset, which is made opaque so that base + offset is not hoisted out of the
+// kernel's loop as a 64-bit per-lane pointer: one long-lived VGPR instead of the four the compiler kept (a pointer pair for
+// records 0..3 and a second one for record 4, which was out of immediate range from record 0).
+struct LaneRecords {
+  char *base;    // wave-uniform: record 2 of lane 0
+  uint32_t off;  // lane * 16
+};
+constexpr int32_t kRecL = -2048, kRecBeta = -1024, kRecWi = 0, kRecLpend = 1024, kRecSum = 2048;  // byte offsets
+__device__ __forceinline__ float4 rec_load(const LaneRecords &r, int32_t k) {
+  uint32_t o = r.off;
+  asm volatile("" : "+v"(o));
+  return *reinterpret_cast<const float4 *>(r.base + o + k);
 }
-__device__ __forceinline__ void path_load(const float4 *rec, PathState &P) {
-  const float4 a = rec[0], b = rec[64], c = rec[128];
+__device__ __forceinline__ void rec_store(const LaneRecords &r, int32_t k, float4 v) {
+  uint32_t o = r.off;
+  asm volatile("" : "+v"(o));
+  *reinterpret_cast<float4 *>(r.base + o + k) = v;
+}
+__device__ __forceinline__ void path_store(const LaneRecords &rec, const PathState &P) {
+  rec_store(rec, kRecL, make_float4(P.L.x, P.L.y, P.L.z,
+                                    __uint_as_float(P.s | (P.bounces << 20) | (P.specular ? 1u << 30 : 0u) | (P.cont ? 1u << 31 : 0u))));
+  rec_store(rec, kRecBeta, make_float4(P.beta.x, P.beta.y, P.beta.z, __uint_as_float((uint32_t)P.rng.state)));
+  rec_store(rec, kRecWi, make_float4(P.wi_next.x, P.wi_next.y, P.wi_next.z, __uint_as_float((uint32_t)(P.rng.state >> 32))));
+}
+__device__ __forceinline__ void path_load(const LaneRecords &rec, PathState &P) {
+  const float4 a = rec_load(rec, kRecL), b = rec_load(rec, kRecBeta), c = rec_load(rec, kRecWi);
   P.L = {a.x, a.y, a.z};
   P.beta = {b.x, b.y, b.z};
   P.wi_next = {c.x, c.y, c.z};
@@ -698,11 +731,12 @@ template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PE
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
 __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
-  __shared__ uint32_t lds_stack[EXACT ? STACK : kQuadLdsStack][64];
-  __shared__ float lds_tn[EXACT ? STACK : 1][64];  // entry distances: exact walk only
+  // the walk's stack, rows of 64 lanes x 4 bytes as dynamic shared memory: the launch sizes it per scene (render_stack_plan;
+  // exact walk: STACK rows of refs followed by STACK rows of entry distances)
+  extern __shared__ uint32_t lds_stack[];
   const uint32_t lane = threadIdx.x;
-  uint32_t *stk = &lds_stack[0][lane];
-  float *stkt = &lds_tn[0][lane];
+  uint32_t *stk = lds_stack + lane;
+  float *stkt = reinterpret_cast<float *>(lds_stack + (EXACT ? STACK : 0) * 64) + lane;  // entry distances: exact walk only
   uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u;  // wave-uniform (SGPRs); the lane is added at use
 
   // Work is handed out dynamically (see the fetch step of the service stage) in ITEMS: item number `item` of this rank
@@ -714,10 +748,13 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
   const uint32_t stx = (uint32_t)(W + 63) >> 6;
   const uint64_t seq0 = R.seed * (uint64_t)S.xres * (uint64_t)S.yres;
   uint32_t item = 0;
+  // tsup / stx by R.stx_recip = ceil(2^32 / stx): exact for tsup * stx < 2^32 (checked by the host); the compiler's own
+  // division by a run-time value keeps a float reciprocal in a VGPR for the whole kernel
   auto pixel_xy = [&](uint32_t q, int32_t &xr, int32_t &yr) {
     const uint32_t tsup = R.rank + (q >> 12) * R.world;
-    xr = (int32_t)((tsup % stx) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u));
-    yr = (int32_t)((tsup / stx) * 64u + ((q >> 9) & 7u) * 8u + ((q >> 3) & 7u));
+    const uint32_t ty = stx == 1u ? tsup : __umulhi(tsup, R.stx_recip), tx = tsup - ty * stx;
+    xr = (int32_t)(tx * 64u + ((q >> 6) & 7u) * 8u + (q & 7u));
+    yr = (int32_t)(ty * 64u + ((q >> 9) & 7u) * 8u + ((q >> 3) & 7u));
   };
   auto item_pixel = [](uint32_t it) { return ((it >> 9) << 6) | (it & 63u); };
   // place of pixel q in the rank's slab (super-tiles back to back, row-major inside) and so of its 8 partial sums
@@ -728,11 +765,11 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
   const uint32_t spp = R.spp_x * R.spp_y;
   const uint32_t spp_mask = R.spp_mask;  // Sobol: 2^ceil(log2 spp) - 1
   const uint32_t nL = S.n_lights;
-  const float nLf = (float)nL;
+  const float nLf = S.n_lights_f;  // (float)nL, converted on the host: a kernel argument stays in an SGPR
   const bool direct_only = R.integrator == 1u;
   const TravTuning tune = {R.min_walkers, R.min_parked};
 
-  float4 *rec = R.lane_state + (size_t)blockIdx.x * 320u + lane;
+  const LaneRecords rec = {reinterpret_cast<char *>(R.lane_state + (size_t)blockIdx.x * 320u + 128u), lane * 16u};
   uint32_t state = ST_FETCH;
   uint32_t region = blockIdx.x % R.n_regions;  // the part of the pixel list this wave draws from
   unsigned long long c_cam = 0, c_bounce = 0, c_shadow = 0, c_nodes = 0, c_tris = 0;
@@ -767,10 +804,10 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
         if (state == ST_SHADOW) {
 #ifdef PBRT_DEBUG_PIXEL_X
           if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
-            printf("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(rec[kRecLpend].x), T.any >> 1, T.tmax);
+            printf("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(rec_load(rec, kRecLpend).x), T.any >> 1, T.tmax);
 #endif
           if (T.any != 3u) {  // unoccluded: the light sample counts
-            const float4 lp = rec[kRecLpend];
+            const float4 lp = rec_load(rec, kRecLpend);
             P.L = P.L + mk(lp.x, lp.y, lp.z);
           }
           advance = true;
@@ -832,12 +869,12 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
                 float u1, u2;
                 sample_2d(P, sobol, spp_mask, u1, u2);
                 uint32_t li = (uint32_t)(xi * nLf);
-                if (li > nL - 1u) li = nL - 1u;
+                li = min(li, nL - 1u);
                 V3 Ld;
                 if (sample_light(S, li, po, nf, k, u1, u2, nLf, Ld, sh_d, sh_tmax)) {
                   need_shadow = true;
                   const V3 lpend = P.beta * Ld;
-                  rec[kRecLpend] = make_float4(lpend.x, lpend.y, lpend.z, 0.f);
+                  rec_store(rec, kRecLpend, make_float4(lpend.x, lpend.y, lpend.z, 0.f));
                 }
               }
               if (direct_only) {
@@ -902,7 +939,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
               printf("SAMPLE %u %08x %08x %08x\n", P.s, __float_as_uint(P.L.x), __float_as_uint(P.L.y), __float_as_uint(P.L.z));
 #endif
             // FilmTile::AddSample with the box filter: this pixel, weight 1.  The chunk's partial sum lives in its record.
-            const float4 sm = rec[kRecSum];
+            const float4 sm = rec_load(rec, kRecSum);
             const V3 sum = mk(sm.x, sm.y, sm.z) + P.L;
             P.s++;
             if (sobol) P.rng.state &= 0xffffffffull;  // request counter of the next sample
@@ -912,7 +949,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
               R.partials[slab_pos(item_pixel(item)) * kSampleChunks + ((item >> 6) & 7u)] = make_float4(sum.x, sum.y, sum.z, 0.f);
               state = ST_FETCH;  // this lane takes another item
             } else {
-              rec[kRecSum] = make_float4(sum.x, sum.y, sum.z, 0.f);
+              rec_store(rec, kRecSum, make_float4(sum.x, sum.y, sum.z, 0.f));
               state = ST_NEW;
             }
           }
@@ -935,8 +972,8 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
       for (uint32_t tries = 0; tries < R.n_regions; tries++) {
         // (parts are cut at multiples of 512 items = whole 8x8 blocks)
         const uint32_t nblk = R.n_items >> 9;
-        const uint32_t lo = (uint32_t)(((uint64_t)nblk * region) / R.n_regions) << 9;
-        const uint32_t hi = (uint32_t)(((uint64_t)nblk * (region + 1u)) / R.n_regions) << 9;
+        const uint32_t lo = ((nblk * region) / R.n_regions) << 9;  // (nblk < 2^23, at most 8 regions)
+        const uint32_t hi = ((nblk * (region + 1u)) / R.n_regions) << 9;
         if (lane == 0) base = atomicAdd(R.next_item + 16u * region, (uint32_t)__popcll(mw));
         base = __builtin_amdgcn_readfirstlane(base) + lo;
         lim = hi;
@@ -945,7 +982,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
         base = lim;
       }
       if (state == ST_FETCH) {
-        const uint32_t it = base + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+        const uint32_t it = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));  // set bits below this lane
         if (it >= lim) {
           if (base >= lim) state = ST_DONE;  // every part exhausted (else: this lane draws again in the next round)
         } else {
@@ -957,7 +994,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
               R.partials[slab_pos(q) * kSampleChunks + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
               item = it;
-              rec[kRecSum] = make_float4(0.f, 0.f, 0.f, 0.f);
+              rec_store(rec, kRecSum, make_float4(0.f, 0.f, 0.f, 0.f));
               P.L = {0.f, 0.f, 0.f};
               P.beta = {1.f, 1.f, 1.f};
               P.wi_next = {0.f, 0.f, 0.f};
@@ -982,7 +1019,10 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
           sample_2d(P, sobol, spp_mask, u1, u2);
           float jx = u1, jy = u2;  // Sobol: the (0,2)-net point is the film offset
           if (!sobol) {
-            const uint32_t sx = P.s % R.spp_x, sy = P.s / R.spp_x;
+            // P.s / spp_x by R.spp_x_recip = ceil(2^32 / spp_x): the estimate is the quotient or one more
+            uint32_t sy = R.spp_x == 1u ? P.s : __umulhi(P.s, R.spp_x_recip);
+            if (sy * R.spp_x > P.s) sy--;
+            const uint32_t sx = P.s - sy * R.spp_x;
             jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
             jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
           }
@@ -1016,7 +1056,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
       if (launch) trav_begin<EXACT>(S, T, stk, ro, rd, rtmax, launch_any, c_nodes);
     }
     if (__ballot(state != ST_DONE) == 0ull) break;
-    trav_run<EXACT, COUNT, (!EXACT && STACK != 0), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
+    trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? kQuadLdsStackOvf : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
   }
 
 #ifdef PBRT_PHASE_PROBE
@@ -1092,7 +1132,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
       }
     }
     if (__ballot(have) == 0ull) break;
-    trav_run<COUNT, COUNT, !COUNT>(S, T, stk, stkt, ovf, have, tune, cn, ct);
+    trav_run<COUNT, COUNT, (COUNT ? 0u : kQuadLdsStack)>(S, T, stk, stkt, ovf, have, tune, cn, ct);
   }
 #ifdef PBRT_PHASE_PROBE
   if (threadIdx.x < 8) atomicAdd(&g_probe[threadIdx.x], s_probe[threadIdx.x]);
@@ -1163,22 +1203,23 @@ template <bool SPH, bool COUNT, bool EXACT>
 static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t depth,
                                   hipStream_t st) {
   const dim3 grid(R.n_workgroups), block(64);
-  if constexpr (!EXACT) {  // production walk: fixed LDS part; the overflow variant only for very deep quad trees
+  if constexpr (!EXACT) {  // production walk: LDS rows per scene; the overflow variant for deep quad trees
     // node steps per scheduling check: 3 for deep trees (C3 +1 %, C2 +2 % over 2), 2 for shallow ones whose walks
     // are a few steps long (C4: 3 would cost 5 %)
-    static const bool force_ovf = debug_knob("PBRT_HIP_FORCE_OVERFLOW_VARIANT") != nullptr;  // A-B runs
-    if (S.quad_stack_need + 2u > kQuadLdsStack || force_ovf) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, 0, st, S, R);
-    else if (!COUNT && S.quad_stack_need <= 16u) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0, 2>), grid, block, 0, st, S, R);
-    else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, 0, st, S, R);
+    const RenderStackPlan plan = render_stack_plan(S.quad_stack_need, render_force_overflow(), render_prefer_lds());
+    const uint32_t lds = plan.rows * 256u;
+    if (plan.overflow) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, lds, st, S, R);
+    else if (!COUNT && S.quad_stack_need <= 16u) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0, 2>), grid, block, lds, st, S, R);
+    else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, lds, st, S, R);
     return hipGetLastError();
   } else {
-    // exact walk: the LDS stack is sized to the tree: the walk holds at most depth - 1 entries
+    // exact walk: the LDS stack is sized to the tree: the walk holds at most depth - 1 entries (refs + entry distances)
     const uint32_t need = depth > 0 ? depth - 1 : 0;
-    if (need > 40) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 0, st, S, R);
-    else if (need > 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 40>), grid, block, 0, st, S, R);
-    else if (need > 26) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 0, st, S, R);
-    else if (need > 20) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 26>), grid, block, 0, st, S, R);
-    else hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 20>), grid, block, 0, st, S, R);
+    if (need > 40) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 64>), grid, block, 64 * 512, st, S, R);
+    else if (need > 32) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 40>), grid, block, 40 * 512, st, S, R);
+    else if (need > 26) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 32>), grid, block, 32 * 512, st, S, R);
+    else if (need > 20) hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 26>), grid, block, 26 * 512, st, S, R);
+    else hipLaunchKernelGGL((render_kernel<SPH, COUNT, EXACT, 20>), grid, block, 20 * 512, st, S, R);
     return hipGetLastError();
   }
 }
