@@ -142,8 +142,12 @@ int pbrt_hip_scene_info(const pbrt_hip_scene *scene, uint32_t *n_nodes, uint32_t
                         uint64_t *device_bytes);
 int pbrt_hip_scene_export_bvh(const pbrt_hip_scene *scene, uint32_t *nodes /* 8 words each */, uint32_t *order);
 /* the production walk's own structure: number of 64-byte quantised 4-wide nodes, and the most stack entries a
- * walk can hold (<= 40 live in LDS, deeper ones in an HBM overflow area) */
+ * walk can hold (see pbrt_hip_render_stack_plan for where they live) */
 int pbrt_hip_scene_walk_info(const pbrt_hip_scene *scene, uint32_t *quad_nodes, uint32_t *stack_need);
+/* How the render kernel is launched for a tree with that stack bound (pure function, no device touched): LDS rows of
+ * 64 x 4 bytes per wave, one-wave workgroups a CU holds at once with them (the grid is this x the CU count), and the
+ * entries per lane kept in an HBM overflow area (non-zero = the overflow variant of the kernel). */
+int pbrt_hip_render_stack_plan(uint32_t stack_need, uint32_t *lds_rows, uint32_t *waves_per_cu, uint32_t *overflow_entries);
 /* host-only variant for CPU-side tests of the builder: no device is touched */
 int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
                             uint32_t *nodes /* 8*(2*n_tris) words cap */, uint32_t *order, uint32_t *n_nodes,

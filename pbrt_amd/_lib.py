@@ -58,6 +58,7 @@ SYMBOLS = {
     "pbrt_hip_scene_export_quads": (C.c_int, [_vp, _pu32, _u32, _pu32, _pu32]),
     "pbrt_hip_scene_destroy": (None, [_vp]),
     "pbrt_hip_scene_info": (C.c_int, [_vp, _pu32, _pu32, _pu32, _pu64]),
+    "pbrt_hip_render_stack_plan": (C.c_int, [C.c_uint32, _pu32, _pu32, _pu32]),
     "pbrt_hip_scene_export_bvh": (C.c_int, [_vp, _pu32, _pu32]),
     "pbrt_hip_scene_walk_info": (C.c_int, [_vp, _pu32, _pu32]),
     "pbrt_hip_bvh_build_host": (C.c_int, [_pf, _u32, _pu32, _u32, _pu32, _pu32, _pu32, _pu32]),

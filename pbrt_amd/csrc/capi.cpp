@@ -747,6 +747,14 @@ int pbrt_hip_scene_build_info(const pbrt_hip_scene *s, uint32_t *gpu_built, doub
   return PBRT_HIP_OK;
 }
 
+int pbrt_hip_render_stack_plan(uint32_t stack_need, uint32_t *lds_rows, uint32_t *waves_per_cu, uint32_t *overflow_entries) {
+  const RenderStackPlan p = render_stack_plan(stack_need, render_force_overflow(), render_prefer_lds());
+  if (lds_rows) *lds_rows = p.rows;
+  if (waves_per_cu) *waves_per_cu = p.waves_per_cu;
+  if (overflow_entries) *overflow_entries = p.extra_entries;
+  return PBRT_HIP_OK;
+}
+
 int pbrt_hip_scene_export_quads(const pbrt_hip_scene *s, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *order) {
   if (!s) return fail(PBRT_HIP_ERR_INVALID, "export_quads: null scene");
   const uint32_t n = s->gpu_built ? s->n_quads_gpu : (uint32_t)(s->d_quads.n / 4);

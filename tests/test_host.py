@@ -367,6 +367,29 @@ def test_production_kernels_do_not_spill():
     assert len(prod) >= 4, demangled
     for d, (_, vgpr, spill, scratch) in prod:
         assert spill == 0 and scratch == 0, f"{d}: {vgpr} VGPRs, {spill} spilled, {scratch} B scratch"
+        # the triangle-scene render kernels are launched at 5 waves per SIMD (capi.cpp: 20 one-wave workgroups per CU)
+        if re.search(r"render_kernel<false, false, false,", d):
+            assert vgpr <= 96, f"{d}: {vgpr} VGPRs do not fit 5 waves per SIMD"
+
+
+def test_render_stack_plan():
+    """pbrt_hip_render_stack_plan (device_types.h render_stack_plan): <= 30 entries: 20 waves per CU (5 per SIMD); up to 33:
+    the whole stack in LDS at 18 waves; deeper: the overflow variant with 32 rows at 20 waves.  LDS rows x waves never
+    exceed a CU's 160 KB.  (The kernel-side use is covered by the GPU parity tests, also on a 12-row build.)"""
+    def plan(need):
+        r, w, x = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        assert _lib.lib().pbrt_hip_render_stack_plan(need, C.byref(r), C.byref(w), C.byref(x)) == 0
+        return r.value, w.value, x.value
+    assert plan(5) == (8, 20, 0)
+    assert plan(30) == (32, 20, 0)
+    assert plan(33) == (35, 18, 0)   # BASELINE config C2
+    assert plan(34) == (32, 20, 4)
+    assert plan(38) == (32, 20, 8)   # C3
+    assert plan(60) == (32, 20, 30)
+    for need in range(0, 100):
+        rows, waves, extra = plan(need)
+        assert rows * 256 * waves <= 160 * 1024 and waves >= 16
+        assert rows + extra >= need + 2
 
 
 def test_image_readers_refuse_hostile_headers(tmp_path):
