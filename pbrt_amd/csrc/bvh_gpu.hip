@@ -558,7 +558,7 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t *level_count
   }
   uint32_t ref[4];
   for (int k = 0; k < 4; k++) {
-    if (k >= nk) { ref[k] = kNone; continue; }
+    if (k >= nk) { ref[k] = kEmptyLeafRef; continue; }
     const uint32_t c = kids[k].c;
     if (c & kLeafRef) {
       ref[k] = kLeafRef | (1u << 24) | (c & ~kLeafRef);  // one triangle, leaf slot = sorted position

@@ -168,7 +168,7 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
 // every decoded box contains the true one, so the walk visits a superset of the exact walk's nodes and the
 // RESULT is unchanged (tie rule of DESIGN.md 3.4).  Why: the loop is bound by the bytes it moves
 // from L2 to L1, and this form moves ~2.9 KB per ray instead of ~4.9 KB.
-// Unused child slots: qlo = 255, qhi = 0 (inverted, never hit), ref 0xffffffff.
+// Unused child slots: qlo = 255, qhi = 0 (inverted), ref kEmptyLeafRef (a leaf without triangles: device_types.h).
 struct QuadNodes {
   std::vector<uint4> q;     // 4 per node
   uint32_t stack_need = 0;  // most entries the walk can hold: max over root-to-leaf paths of sum(children - 1)
@@ -420,7 +420,7 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
     }
     uint32_t ref[4];
     for (int k = 0; k < 4; k++) {
-      if (k >= nk) { ref[k] = 0xffffffffu; continue; }
+      if (k >= nk) { ref[k] = kEmptyLeafRef; continue; }
       const QuadChild &c = kids[k];
       if (c.node == 0xffffffffu && c.leaf_node == 0xffffffffu) {
         ref[k] = c.ref;

@@ -39,6 +39,11 @@ constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 32;
 #endif
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 
+// An unused child slot of a quad node holds the ref of a leaf with no triangles (and an inverted box: lower planes 255,
+// upper planes 0).  The box rejects it except for degenerate rays / flat nodes, and then the walk parks at an empty leaf and
+// pops: harmless, so the node step needs no "is this slot used" test (it had two compares per step for it until r02c).
+constexpr uint32_t kEmptyLeafRef = 0x80000000u;
+
 struct RenderStackPlan {
   uint32_t rows;           // LDS rows per wave
   bool overflow;           // the overflow variant (rows == kQuadLdsStackOvf)

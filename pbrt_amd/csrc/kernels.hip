@@ -432,10 +432,8 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         hit[k] = tn <= tf * kBoxPad;
         key[k] = tn;
       }
-      // an unused child slot (ref kDone) must never be taken: its inverted box does not exclude it on an axis where
-      // the node is flat or the ray is parallel to the slab
-      hit[2] = hit[2] && W3.z != kDone;  // (slots 0 and 1 are always used: every node has >= 2 children)
-      hit[3] = hit[3] && W3.w != kDone;
+      // (an unused child slot holds kEmptyLeafRef behind an inverted box: if a degenerate ray gets through that box the
+      // lane parks at a leaf without triangles and pops -- no test for it here)
 #pragma unroll
       for (int k = 0; k < 4; k++) key[k] = hit[k] ? key[k] : kInf;
       // The nearest child hit is entered, the other hit ones are stacked in slot order.  Order affects only

@@ -266,7 +266,7 @@ def _check_quads(quads, need, P, idx, order):
         qlo = [quads[q, 4 + a] for a in range(3)]
         qhi = [quads[q, 7], quads[q, 8], quads[q, 9]]
         refs = quads[q, 12:16]
-        kids = [k for k in range(4) if refs[k] != 0xFFFFFFFF]
+        kids = [k for k in range(4) if refs[k] != 0x80000000]  # kEmptyLeafRef: unused slot
         held += len(kids) - 1
         worst = max(worst, held)
         lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)

@@ -33,14 +33,14 @@ for builder in ("host", "gpu"):
         hi = origin + ((qhi >> (8 * k)) & 0xFF) * cell
         d = np.maximum(hi - lo, 0)
         a = d[:, 0] * d[:, 1] + d[:, 0] * d[:, 2] + d[:, 1] * d[:, 2]
-        used = refs[:, k] != 0xFFFFFFFF
+        used = refs[:, k] != 0x80000000
         leaf = used & ((refs[:, k] & 0x80000000) != 0)
         area_int += a[used & ~leaf].sum()
         area_leaf += a[leaf].sum()
         kids += used.sum()
     d0 = (f[0, 0:3] * 0)  # root box = union of the root's children
-    lo0 = np.min([origin[0] + ((qlo[0] >> (8 * k)) & 0xFF) * cell[0] for k in range(4) if refs[0, k] != 0xFFFFFFFF], axis=0)
-    hi0 = np.max([origin[0] + ((qhi[0] >> (8 * k)) & 0xFF) * cell[0] for k in range(4) if refs[0, k] != 0xFFFFFFFF], axis=0)
+    lo0 = np.min([origin[0] + ((qlo[0] >> (8 * k)) & 0xFF) * cell[0] for k in range(4) if refs[0, k] != 0x80000000], axis=0)
+    hi0 = np.max([origin[0] + ((qhi[0] >> (8 * k)) & 0xFF) * cell[0] for k in range(4) if refs[0, k] != 0x80000000], axis=0)
     dr = hi0 - lo0
     root = dr[0] * dr[1] + dr[0] * dr[2] + dr[1] * dr[2]
     rays = st["camera_rays"] + st["bounce_rays"] + st["shadow_rays"]

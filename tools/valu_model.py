@@ -7,9 +7,10 @@ right shifts, mov), SLOW 4.2 (min / max / min3 / max3, every cvt, every cmp, cnd
 integer forms, mul_lo), transcendental 8.1, 64-bit integer mad 5.1.  The SQ's instruction-class counters tell the classes
 apart only partly (calibrated on the ubench, profiles/r02_pmc_class_calibration.txt): ADD_F32 and MUL_F32 are FAST; CVT is
 SLOW; FMA_F32 counts v_fma_f32 (FAST) and v_pk_fma_f32 (SLOW) alike; INT32 mixes both; min / max / cmp / cndmask / mov /
-logic are not counted at all.  The unresolved groups are split by the STATIC census of the kernel's node step
-(tools/isa_stats.py --step: the loop that executes ~70 % of the instructions): the share of SLOW opcodes among the
-instructions of each group there.  Result: issue cycles per instruction, per ray, VALU-busy fraction, and the bracket
+logic are not counted at all.  The unresolved groups are split by a STATIC census of the kernel in two parts
+(tools/isa_stats.py): one node step, whose dynamic count follows from the CVT counter (24 v_cvt_f32_ubyte per step), and
+the rest of the kernel (leaf pass, service stage: far more v_mov and logic, which are FAST); per part, the share of SLOW
+opcodes among the instructions of each group.  Result: issue cycles per instruction, per ray, VALU-busy fraction, and the bracket
 [every unresolved instruction FAST, every one SLOW].
 
 usage: tools/valu_model.py <summary.txt> [n_simds=1024]  ->  JSON on stdout
@@ -35,29 +36,47 @@ COUNTED = {
 }
 
 
-def static_slow_share():
-    """share of SLOW opcodes among the node step's instructions of the groups the counters cannot resolve"""
+def _group_of(op):
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    for g in ("FMA_F32", "INT32", "ADD_F32", "MUL_F32"):
+        if base in COUNTED[g]:
+            return g
+    if base.startswith("v_cvt"):
+        return "CVT"
+    if base.startswith(("v_rcp", "v_sqrt", "v_rsq", "v_exp", "v_log", "v_sin", "v_cos")):
+        return "TRANS_F32"
+    if base.startswith("v_mad_u64") or base.startswith("v_lshl_add_u64") or base.startswith("v_lshlrev_b64"):
+        return "INT64"
+    return "OTHER"
+
+
+def static_census():
+    """Static census of the production kernel in two parts: one unrolled node step, and the rest of the kernel (leaf pass,
+    service stage, scheduling).  Per part and per counter group: instructions and the share of SLOW opcodes among them."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_stats
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_stats.py"), "--step", "--raw"], capture_output=True, text=True, check=True).stdout
-    hist = json.loads(out.strip().split("\n")[-1])
-    share = {}
-    for grp in ("FMA_F32", "INT32", "OTHER"):
-        n = {"fast": 0, "slow": 0, "trans": 0}
-        for op, c in hist.items():
-            base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
-            if not op.startswith("v_"):
-                continue
-            if grp == "OTHER":
-                counted = any(v is not None and base in v for v in COUNTED.values()) or base.startswith(("v_cvt", "v_rcp", "v_sqrt", "v_rsq", "v_mad_u64"))
-                if counted:
-                    continue
-            elif base not in COUNTED[grp]:
-                continue
-            n[isa_stats.klass(op)] += c
-        tot = n["fast"] + n["slow"] + n["trans"]
-        share[grp] = (n["slow"] / tot) if tot else 0.5
-    return share
+
+    def hist(*flags):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_stats.py"), "--raw", *flags], capture_output=True, text=True, check=True).stdout
+        return {o: c for o, c in json.loads(out.strip().split("\n")[-1]).items() if o.startswith("v_")}
+    step, kernel = hist("--step"), hist()
+    n_cvt_step = sum(c for o, c in step.items() if o.startswith("v_cvt_f32_ubyte"))
+    n_cvt_kernel = sum(c for o, c in kernel.items() if o.startswith("v_cvt_f32_ubyte"))
+    unroll = max(1, round(n_cvt_kernel / max(1, n_cvt_step)))
+    rest = {o: max(0, c - unroll * step.get(o, 0)) for o, c in kernel.items()}
+
+    def part(h):
+        res = {}
+        for g in ("FMA_F32", "INT32", "OTHER", "CVT"):
+            n = {"fast": 0, "slow": 0, "trans": 0}
+            for op, c in h.items():
+                if _group_of(op) == g:
+                    n[isa_stats.klass(op)] += c
+            tot = n["fast"] + n["slow"] + n["trans"]
+            res[g] = {"n": tot, "slow_share": (n["slow"] / tot) if tot else 0.5}
+        res["valu"] = sum(h.values())
+        return res
+    return {"step": part(step), "rest": part(rest), "unroll": unroll}
 
 
 def main():
@@ -69,20 +88,31 @@ def main():
     total = c["SQ_INSTS_VALU"]
     grp = {k: c.get("SQ_INSTS_VALU_" + k, 0.0) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32", "INT64")}
     other = total - sum(grp.values())
-    share = static_slow_share()
+    census = static_census()
     known = grp["ADD_F32"] * FAST + grp["MUL_F32"] * FAST + grp["CVT"] * SLOW + grp["TRANS_F32"] * TRANS + grp["INT64"] * INT64
+    # how many node steps ran: every step converts its 24 plane bytes (v_cvt_f32_ubyte), nearly all the CVT count of the kernel
+    step_passes = grp["CVT"] / max(1, census["step"]["CVT"]["n"])
+    dyn = {"FMA_F32": grp["FMA_F32"], "INT32": grp["INT32"], "OTHER": other}
 
-    def cycles(s_fma, s_int, s_other):
-        mix = lambda n, s: n * (s * SLOW + (1 - s) * FAST)
-        return known + mix(grp["FMA_F32"], s_fma) + mix(grp["INT32"], s_int) + mix(other, s_other)
+    def cycles(pick):
+        tot = known
+        for g, n_dyn in dyn.items():
+            n_step = min(n_dyn, step_passes * census["step"][g]["n"])  # the part of the group executed inside node steps
+            for n, where in ((n_step, "step"), (n_dyn - n_step, "rest")):
+                sh = pick(census[where][g]["slow_share"])
+                tot += n * (sh * SLOW + (1 - sh) * FAST)
+        return tot
 
-    best = cycles(share["FMA_F32"], share["INT32"], share["OTHER"])
-    lo, hi = cycles(0, 0, 0), cycles(1, 1, 1)
+    best = cycles(lambda sh: sh)
+    lo, hi = cycles(lambda sh: 0.0), cycles(lambda sh: 1.0)
+    share = {"step": {g: census["step"][g]["slow_share"] for g in dyn}, "rest": {g: census["rest"][g]["slow_share"] for g in dyn},
+             "node_step_passes": step_passes, "valu_per_step": census["step"]["valu"],
+             "share_of_instructions_in_node_steps": step_passes * census["step"]["valu"] / total}
     kernel_cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
     simd_cycles = kernel_cycles * n_simd
     rays = c.get("PROBE_RAYS", 0.0)
     out = {
-        "valu_instructions": total, "class_counters": grp, "uncounted_instructions": other, "static_slow_share_in_node_step": share,
+        "valu_instructions": total, "class_counters": grp, "uncounted_instructions": other, "static_census": share,
         "valu_issue_cycles": best, "mean_issue_cycles_per_instruction": best / total,
         "kernel_cycles": kernel_cycles, "clock_ghz_in_profile": kernel_cycles / c["PROBE_KERNEL_NS"] if c.get("PROBE_KERNEL_NS") else None,
         "valu_busy_frac_at_profile_clock": best / simd_cycles, "valu_busy_bracket": [lo / simd_cycles, hi / simd_cycles],
