@@ -563,14 +563,15 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t *level_count
     if (c & kLeafRef) {
       ref[k] = kLeafRef | (1u << 24) | (c & ~kLeafRef);  // one triangle, leaf slot = sorted position
     } else {
-      ref[k] = atomicAdd(&counters[0], 1u);
-      next[atomicAdd(&level_count[1], 1u)] = CollapseItem{c, ref[k], path};
+      const uint32_t quad = atomicAdd(&counters[0], 1u);
+      ref[k] = quad * 64u;  // byte offset in the node array (capi.cpp make_quad_nodes)
+      next[atomicAdd(&level_count[1], 1u)] = CollapseItem{c, quad, path};
     }
   }
   uint4 *q = quads + 4 * (size_t)it.quad;
-  q[0] = make_uint4(__float_as_uint(me_lo[0]), __float_as_uint(me_lo[1]), __float_as_uint(me_lo[2]), ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16));
+  q[0] = make_uint4(__float_as_uint(me_lo[0]), __float_as_uint(me_lo[1]), __float_as_uint(me_lo[2]), ebyte[0] << 23);
   q[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
-  q[2] = make_uint4(qhi[1], qhi[2], (ebyte[0] << 7) | (ebyte[1] << 23), ebyte[2] << 7);
+  q[2] = make_uint4(qhi[1], qhi[2], ebyte[1] << 23, ebyte[2] << 23);
   q[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
 }
 

@@ -160,10 +160,11 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
 // interior node collapsed with its interior children (2..4 children); the children's boxes are
 // stored as 8-bit coordinates on the node's own grid (origin = the node's lower corner, one
 // power-of-two cell size per axis), rounded outwards, so a node with four children is 64 bytes:
-//   {origin.x origin.y origin.z  ex | ey<<8 | ez<<16}      ex.. = biased exponent byte of the cell size
+//   {origin.x origin.y origin.z  cell.x}                    cell sizes as f32 (powers of two)
 //   {qlo.x[4]  qlo.y[4]  qlo.z[4]  qhi.x[4]}               one byte per child
-//   {qhi.y[4]  qhi.z[4]  0  0}
-//   {ref[4]}
+//   {qhi.y[4]  qhi.z[4]  cell.y  cell.z}
+//   {ref[4]}                                                interior child: its byte offset in this array (node x 64);
+//                                                           leaf child: 1<<31 | count<<24 | first leaf slot
 // plane = origin + q * cell (a real number): the builder checks in exact (double) arithmetic that
 // every decoded box contains the true one, so the walk visits a superset of the exact walk's nodes and the
 // RESULT is unchanged (tie rule of DESIGN.md 3.4).  Why: the loop is bound by the bytes it moves
@@ -425,18 +426,19 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
       if (c.node == 0xffffffffu && c.leaf_node == 0xffffffffu) {
         ref[k] = c.ref;
       } else {
-        ref[k] = (uint32_t)(out->q.size() / 4);
+        const uint32_t quad = (uint32_t)(out->q.size() / 4);
+        ref[k] = quad * 64u;  // an interior child's ref is its byte offset in the node array: no shift in the walk
         out->q.resize(out->q.size() + 4, make_uint4(0, 0, 0, 0));
         // below child k the walk holds the entries of this path minus the ones already popped: bound by path
-        if (c.node != 0xffffffffu) todo.push_back({c.node, ref[k], path, false});
-        else todo.push_back({c.leaf_node, ref[k], path, true});
+        if (c.node != 0xffffffffu) todo.push_back({c.node, quad, path, false});
+        else todo.push_back({c.leaf_node, quad, path, true});
       }
     }
     uint4 *q = &out->q[4 * (size_t)it.quad];
-    q[0] = make_uint4(as_u(me.lo[0]), as_u(me.lo[1]), as_u(me.lo[2]), ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16));
+    // the three cell sizes as f32 bit patterns (powers of two: exponent byte << 23), ready to be multiplied by 1 / d
+    q[0] = make_uint4(as_u(me.lo[0]), as_u(me.lo[1]), as_u(me.lo[2]), ebyte[0] << 23);
     q[1] = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
-    // the three cell sizes once more as bf16 (a power of two is exact in it): the kernel decodes each with one shift / mask
-    q[2] = make_uint4(qhi[1], qhi[2], (ebyte[0] << 7) | (ebyte[1] << 23), ebyte[2] << 7);
+    q[2] = make_uint4(qhi[1], qhi[2], ebyte[1] << 23, ebyte[2] << 23);
     q[3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
   }
 }

@@ -372,7 +372,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     { const unsigned long long ma = __ballot(T.cur != kDone && !trav_parked(T)); if (ma) { PROBE_ADD(0, 1); PROBE_ADD(1, __popcll(ma)); } }
     if (T.cur != kDone && !trav_parked(T)) {
       // ---- one step of the production walk: the four children of quantised quad node T.cur (64 bytes) ----
-      const uint32_t off = T.cur * 64u;
+      const uint32_t off = T.cur;  // the ref of an interior quad node IS its byte offset (node number x 64)
       const uint4 W0 = *reinterpret_cast<const uint4 *>(quads + off);
       const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
       const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
@@ -407,10 +407,13 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // conservative.
       const float gx = (o.x - __uint_as_float(W0.x)) * inv.x, gy = (o.y - __uint_as_float(W0.y)) * inv.y;
       const float gz = (o.z - __uint_as_float(W0.z)) * inv.z;
-      const float mx = fabsf(gx) * 0x1.8p-22f, my = fabsf(gy) * 0x1.8p-22f, mz = fabsf(gz) * 0x1.8p-22f;
-      const f32x2 gxx = {gx + mx, gx - mx}, gyy = {gy + my, gy - my}, gzz = {gz + mz, gz - mz};  // {near, far}: subtracted below
-      const float cix = __uint_as_float(W2.z << 16) * inv.x, ciy = __uint_as_float(W2.z & 0xffff0000u) * inv.y;
-      const float ciz = __uint_as_float(W2.w << 16) * inv.z;
+      // g +- 3 eps |g| as one fma each (|x| and -x are operand modifiers): rounded once instead of twice, at least
+      // g +- 5/2 eps |g|, still beyond the 2 eps |g| the margin has to cover
+      constexpr float kMargin = 0x1.8p-22f;
+      const f32x2 gxx = {__builtin_fmaf(fabsf(gx), kMargin, gx), __builtin_fmaf(-fabsf(gx), kMargin, gx)};  // {near, far}: subtracted below
+      const f32x2 gyy = {__builtin_fmaf(fabsf(gy), kMargin, gy), __builtin_fmaf(-fabsf(gy), kMargin, gy)};
+      const f32x2 gzz = {__builtin_fmaf(fabsf(gz), kMargin, gz), __builtin_fmaf(-fabsf(gz), kMargin, gz)};
+      const float cix = __uint_as_float(W0.w) * inv.x, ciy = __uint_as_float(W2.z) * inv.y, ciz = __uint_as_float(W2.w) * inv.z;
       // near / far planes by the sign of the inverse direction: one select per axis serves all four
       // children (a dword holds the four children's bytes of one plane)
       const uint32_t bnx = negx ? W1.w : W1.x, bfx = negx ? W1.x : W1.w;
@@ -435,7 +438,9 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // (an unused child slot holds kEmptyLeafRef behind an inverted box: if a degenerate ray gets through that box the
       // lane parks at a leaf without triangles and pops -- no test for it here)
 #pragma unroll
-      for (int k = 0; k < 4; k++) key[k] = hit[k] ? key[k] : kInf;
+      // (a missed child's key is a NaN with all bits set -- an inline constant of the select, where +inf would need a
+      // register; fminf ignores it, and when every child is missed nothing below uses kmin)
+      for (int k = 0; k < 4; k++) key[k] = hit[k] ? key[k] : __uint_as_float(0xffffffffu);
       // The nearest child hit is entered, the other hit ones are stacked in slot order.  Order affects only
       // speed (tie rule of 3.4) -- but a lot: visiting the hit children in slot order alone costs C3 49 node steps per
       // ray instead of 41 (measured, r02), and sorting the stacked ones cost more than it saved (r01).
@@ -465,8 +470,8 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         lds_store(T.sp, W3.z); T.sp += (hit[2] && !n2) ? kRowBytes : 0u;
         lds_store(T.sp, W3.y); T.sp += (hit[1] && !n1) ? kRowBytes : 0u;
         lds_store(T.sp, W3.x); T.sp += (hit[0] && !n0) ? kRowBytes : 0u;
-        const uint32_t top = lds_load(T.sp - kRowBytes);
-        T.sp -= any_hit ? 0u : kRowBytes;
+        const uint32_t below = T.sp - kRowBytes, top = lds_load(below);
+        T.sp = any_hit ? T.sp : below;  // (one select: the address below the top is there already)
         trav_enter(T, any_hit ? nearest : top);
       }
     }

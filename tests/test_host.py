@@ -261,8 +261,8 @@ def _check_quads(quads, need, P, idx, order):
     def visit(q, held):
         nonlocal worst
         origin = f[q, 0:3].astype(np.float64)
-        eb = int(quads[q, 3])
-        cell = np.array([2.0 ** (((eb >> (8 * a)) & 0xFF) - 127) for a in range(3)])
+        cell = np.array([f[q, 3], f[q, 10], f[q, 11]], np.float64)  # powers of two, as f32
+        assert all(c > 0 and np.frexp(c)[0] == 0.5 for c in cell)
         qlo = [quads[q, 4 + a] for a in range(3)]
         qhi = [quads[q, 7], quads[q, 8], quads[q, 9]]
         refs = quads[q, 12:16]
@@ -283,7 +283,8 @@ def _check_quads(quads, need, P, idx, order):
                 seen[first:first + cnt] += 1
                 tlo, thi = tri_lo[first:first + cnt].min(0), tri_hi[first:first + cnt].max(0)
             else:
-                tlo, thi = visit(r, held)
+                assert r % 64 == 0  # an interior child's ref is its byte offset
+                tlo, thi = visit(r // 64, held)
             assert (blo <= tlo).all() and (bhi >= thi).all(), (q, k, blo, tlo, bhi, thi)
             lo_all, hi_all = np.minimum(lo_all, tlo), np.maximum(hi_all, thi)
         return lo_all, hi_all

@@ -21,8 +21,7 @@ for builder in ("host", "gpu"):
         film, st = sc.render(max_depth=8, spp=(2, 2), seed=0, counters="walk")
     f = quads.view(np.float32)
     origin = f[:, 0:3].astype(np.float64)
-    eb = quads[:, 3]
-    cell = np.stack([2.0 ** (((eb >> (8 * a)) & 0xFF).astype(np.float64) - 127) for a in range(3)], axis=1)
+    cell = np.stack([f[:, 3], f[:, 10], f[:, 11]], axis=1).astype(np.float64)  # powers of two, as f32
     qlo = quads[:, 4:7]
     qhi = np.stack([quads[:, 7], quads[:, 8], quads[:, 9]], axis=1)
     refs = quads[:, 12:16]
