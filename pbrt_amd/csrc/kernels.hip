@@ -508,25 +508,27 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const V3 e1 = xyz(b) - p0, e2 = xyz(c) - p0;
           const V3 pv = cross(d, e2);
           const float det = dot(e1, pv);
-          if (!(fabsf(det) < 1e-8f)) {
-            const float idet = 1.0f / det;
-            const V3 tv = o - p0;
-            const float u = dot(tv, pv) * idet;
-            const V3 qv = cross(tv, e1);
-            const float v = dot(d, qv) * idet;
-            const float th = dot(e2, qv) * idet;
-            if ((u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax)) {
-              if (T.any) {
-                T.any = 3u;  // occluded: the walk ends at the first valid hit
-                stop = true;
-              } else {
-                const uint32_t id = __float_as_uint(a.w);
-                if (th < T.h.t || (th == T.h.t && id < T.h.prim)) {
-                  T.h.t = th; T.h.prim = id; T.h.slot = slot; T.h.b1 = u; T.h.b2 = v;
-                }
-              }
-            }
-          }
+          // Branch-free from here: every lane of the pass computes u, v and t (a degenerate triangle's 1 / det is inf or
+          // NaN and fails the tests below like any miss) and the hit record is updated by selects.  The nested early-outs
+          // this replaces skipped work only when ALL lanes of the pass failed the same test, and the compiler paid for
+          // them with copies of the six hit-record registers at every level (about 50 v_mov per pass).
+          const float idet = 1.0f / det;
+          const V3 tv = o - p0;
+          const float u = dot(tv, pv) * idet;
+          const V3 qv = cross(tv, e1);
+          const float v = dot(d, qv) * idet;
+          const float th = dot(e2, qv) * idet;
+          const bool valid = !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax);
+          const uint32_t id = __float_as_uint(a.w);
+          const bool occl = valid && T.any != 0u;  // any-hit ray: the walk ends at the first valid hit
+          const bool closer = valid && T.any == 0u && (th < T.h.t || (th == T.h.t && id < T.h.prim));
+          T.any = occl ? 3u : T.any;
+          stop = stop || occl;
+          T.h.t = closer ? th : T.h.t;
+          T.h.prim = closer ? id : T.h.prim;
+          T.h.slot = closer ? slot : T.h.slot;
+          T.h.b1 = closer ? u : T.h.b1;
+          T.h.b2 = closer ? v : T.h.b2;
         }
       }
       // (OVF: is any entry about to be popped one of the rare ones beyond the LDS part?  wave-uniform, as for the pushes)
