@@ -253,11 +253,17 @@ __device__ __forceinline__ bool trav_parked(const Trav &T) { return T.cur != kDo
 __device__ __forceinline__ uint32_t trav_leaf_cnt(const Trav &T) { return trav_parked(T) ? (T.cur >> 24) & 0x7fu : 0u; }
 
 #ifdef PBRT_PHASE_PROBE
-__shared__ unsigned long long s_probe[8];
-__device__ unsigned long long g_probe[8];
+__shared__ unsigned long long s_probe[24];
+__device__ unsigned long long g_probe[24];
 #define PROBE_ADD(i_, v_) do { const unsigned long long pv_ = (v_); if (threadIdx.x == 0) s_probe[i_] += pv_; } while (0)
+// wave time (s_memtime cycles, stalls included) since the previous marker goes to section k_ (render_kernel's outer loop);
+// the time of the last marker is kept in LDS and the first ACTIVE lane does the bookkeeping, so a marker inside a branch
+// that lane 0 did not take still counts
+#define PROBE_SEC(k_) do { const unsigned long long pt_ = __builtin_amdgcn_s_memtime(); \
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) { s_probe[8 + (k_)] += pt_ - s_probe[23]; s_probe[23] = pt_; } } while (0)
 #else
 #define PROBE_ADD(i_, v_) do { } while (0)
+#define PROBE_SEC(k_) do { } while (0)
 #endif
 template <bool EXACT>
 __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t *stk, V3 o, V3 d, float tmax, bool any,
@@ -788,7 +794,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
 
 #ifdef PBRT_PHASE_PROBE
-  if (lane < 8) s_probe[lane] = 0;
+  if (lane < 24) s_probe[lane] = lane == 23 ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
   for (;;) {
     // ---- service stage: lanes whose walk is over consume the result and launch the next ray ----
@@ -803,6 +809,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
       path_load(rec, P);
       pixel_xy(item_pixel(item), xr, yr);
       P.rng.inc = (((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) * kSampleChunks + ((item >> 6) & 7u)) << 1) | 1u;
+      PROBE_SEC(1);
       if (state != ST_NEW) {
         if (SPH) trav_spheres(S, T);
         bool advance = false;  // take the prepared bounce (or end the sample)
@@ -859,6 +866,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
               P.L = P.L + P.beta * mk(S.le_inf[0], S.le_inf[1], S.le_inf[2]);
             }
           }
+          PROBE_SEC(2);
           P.cont = false;
           bool need_shadow = false;
           if (hit && P.bounces < R.max_depth) {
@@ -882,6 +890,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
                   rec_store(rec, kRecLpend, make_float4(lpend.x, lpend.y, lpend.z, 0.f));
                 }
               }
+              PROBE_SEC(3);
               if (direct_only) {
                 alive = false;
               } else {
@@ -921,6 +930,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
           }
           if (!need_shadow) advance = true;
         }
+        PROBE_SEC(4);
         if (advance) {
           bool go = P.cont;
           if (go) {
@@ -962,6 +972,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
         }
       }
     }
+    PROBE_SEC(5);
     // ---- fetch: lanes without an item draw the next ones of this rank's item list (wave-uniform; one atomic per
     // wave and round).  An item stays with its lane for all its samples, so its RNG stream, sample order and partial
     // sum are those of DESIGN.md 3.1 whichever lane happens to take it; what the dynamic hand-out removes is the
@@ -1016,6 +1027,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
         }
       }
     }
+    PROBE_SEC(6);
     if (serve && state != ST_DONE) {
       if (state == ST_NEW) {
         if (true) {
@@ -1048,6 +1060,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
           if (COUNT) c_cam++;
         }
       }
+      PROBE_SEC(7);
       path_store(rec, P);
 #ifdef PBRT_RAY_LOG  // experiment: every ray the frame traces, in the order it is launched (tools/raylog_probe.py)
       if (launch && g_raylog) {
@@ -1060,12 +1073,14 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
 #endif
       if (launch) trav_begin<EXACT>(S, T, stk, ro, rd, rtmax, launch_any, c_nodes);
     }
+    PROBE_SEC(8);
     if (__ballot(state != ST_DONE) == 0ull) break;
     trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? kQuadLdsStackOvf : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
+    PROBE_SEC(0);
   }
 
 #ifdef PBRT_PHASE_PROBE
-  if (lane < 8) atomicAdd(&g_probe[lane], s_probe[lane]);
+  if (lane < 23) atomicAdd(&g_probe[lane], s_probe[lane]);
 #endif
   if (COUNT) {
     unsigned long long v[5] = {c_cam, c_bounce, c_shadow, c_nodes, c_tris};
@@ -1081,7 +1096,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
 __global__ void probe_dump() {
   printf("PROBE step waves %llu lanes %llu | flush waves %llu lanes %llu | service waves %llu lanes %llu | flushes %llu dense passes %llu\n",
          g_probe[0], g_probe[1], g_probe[2], g_probe[3], g_probe[4], g_probe[5], g_probe[6], g_probe[7]);
-  for (int i = 0; i < 8; i++) g_probe[i] = 0;
+  printf("PROBE wave cycles: traversal %llu | service: records+pixel %llu, shadow return / hit fetch / emission %llu, light sample %llu, bsdf + rr %llu, advance + film %llu, item fetch %llu, camera ray %llu, store + ray start %llu\n",
+         g_probe[8], g_probe[9], g_probe[10], g_probe[11], g_probe[12], g_probe[13], g_probe[14], g_probe[15], g_probe[16]);
+  for (int i = 0; i < 24; i++) g_probe[i] = 0;
 }
 #endif
 #ifndef PBRT_INTERSECT_WAVES_PER_SIMD
