@@ -466,7 +466,7 @@ int pbrt_hip_device_count(void) {
 }
 
 const char *pbrt_hip_last_error(void) { return pbrt_hip::last_error_message(); }
-const char *pbrt_hip_version(void) { return "pbrt_hip 0.1 (gfx950)"; }
+const char *pbrt_hip_version(void) { return "pbrt_hip 0.2 (gfx950)"; }
 
 int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, uint32_t *nodes,
                             uint32_t *order, uint32_t *n_nodes, uint32_t *depth) {
