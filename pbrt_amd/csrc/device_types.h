@@ -28,16 +28,22 @@ inline const char *debug_knob(const char *name) {
 
 // LDS stack of the production (quad) walk: one row = 64 lanes x 4 bytes.  A row count r serves trees whose worst-case stack
 // bound is r - 2 (the sentinel and one scratch row).  The render kernel takes its rows as DYNAMIC shared memory, sized per
-// scene (render_stack_plan below): up to 32 rows a CU holds 20 one-wave workgroups (160 KB of LDS; the kernel's 96 VGPRs
-// allow 5 waves per SIMD), 40 rows allow 16.  Trees beyond kQuadLdsStack rows -- or, for the render kernel, beyond what
-// still leaves 18 waves per CU -- run the overflow variant: kQuadLdsStackOvf rows in LDS, deeper entries in HBM.
-// -DPBRT_QUAD_LDS_STACK=12 forces the overflow variant on nearly every scene (tests of that path).
+// scene (render_stack_plan below).  A CU has 160 KB of LDS, handed out in granules of 1280 bytes (measured: 31 and 32 rows run
+// like 35, 30 rows 3 % faster): up to 30 rows (6 granules) a CU holds 20 one-wave workgroups -- 5 per SIMD, which is also
+// what the kernel's 96 VGPRs allow --, 31..35 rows (7 granules) 18, 36..40 rows 16.  Trees that need more than 30 rows run
+// the overflow variant: kQuadLdsStackOvf rows in LDS at 20 waves, deeper entries in HBM (kQuadLdsStack = the rows of the
+// ray-batch kernel, and the most the render kernel takes with PBRT_HIP_PREFER_LDS_STACK).  -DPBRT_QUAD_LDS_STACK=12 forces the overflow variant on nearly every scene (tests of that path).
 #ifdef PBRT_QUAD_LDS_STACK
 constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK, kQuadLdsStackOvf = PBRT_QUAD_LDS_STACK;
 #else
-constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 32;
+constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 30;
 #endif
+constexpr uint32_t kLdsGranule = 1280u;
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
+#ifndef PBRT_RENDER_MAX_WAVES_PER_CU  // 4 SIMDs x the waves per SIMD the render kernel's register budget allows (kernels.hip)
+#define PBRT_RENDER_MAX_WAVES_PER_CU 20
+#endif
+constexpr uint32_t kRenderMaxWavesPerCu = PBRT_RENDER_MAX_WAVES_PER_CU;
 
 // An unused child slot of a quad node holds the ref of a leaf with no triangles (and an inverted box: lower planes 255,
 // upper planes 0).  The box rejects it except for degenerate rays / flat nodes, and then the walk parks at an empty leaf and
@@ -53,9 +59,13 @@ struct RenderStackPlan {
 inline RenderStackPlan render_stack_plan(uint32_t quad_stack_need, bool force_overflow, bool prefer_lds = false) {
   RenderStackPlan p;
   const uint32_t need_rows = quad_stack_need + 2u;
-  auto waves = [](uint32_t rows) { const uint32_t w = kLdsBytesPerCu / (rows * 256u); return w > 20u ? 20u : w; };
+  auto waves = [](uint32_t rows) {
+    const uint32_t bytes = (rows * 256u + kLdsGranule - 1u) / kLdsGranule * kLdsGranule, w = kLdsBytesPerCu / bytes;
+    return w > kRenderMaxWavesPerCu ? kRenderMaxWavesPerCu : w;
+  };
   p.rows = need_rows < 8u ? 8u : need_rows;
-  p.overflow = force_overflow || need_rows > kQuadLdsStack || (waves(p.rows) < 18u && !prefer_lds);
+  // (20 waves with the overflow variant beat 18 or 16 waves with the whole stack in LDS: C2 +1 %, C3 +4 %)
+  p.overflow = force_overflow || need_rows > kQuadLdsStack || (waves(p.rows) < kRenderMaxWavesPerCu && !prefer_lds);
   if (p.overflow) p.rows = kQuadLdsStackOvf;
   p.waves_per_cu = waves(p.rows);
   p.extra_entries = p.overflow && need_rows > p.rows ? need_rows - p.rows : 0u;

@@ -374,22 +374,24 @@ def test_production_kernels_do_not_spill():
 
 
 def test_render_stack_plan():
-    """pbrt_hip_render_stack_plan (device_types.h render_stack_plan): <= 30 entries: 20 waves per CU (5 per SIMD); up to 33:
-    the whole stack in LDS at 18 waves; deeper: the overflow variant with 32 rows at 20 waves.  LDS rows x waves never
-    exceed a CU's 160 KB.  (The kernel-side use is covered by the GPU parity tests, also on a 12-row build.)"""
+    """pbrt_hip_render_stack_plan (device_types.h render_stack_plan): LDS comes in granules of 1280 bytes, so <= 28 entries
+    (30 rows) run at 20 waves per CU (5 per SIMD) with the whole stack in LDS, deeper trees run the overflow variant with 30 rows,
+    also at 20 waves.  Granules x waves never exceed a CU's 160 KB.  (The kernel-side use is covered by
+    the GPU parity tests, also on a 12-row build.)"""
     def plan(need):
         r, w, x = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         assert _lib.lib().pbrt_hip_render_stack_plan(need, C.byref(r), C.byref(w), C.byref(x)) == 0
         return r.value, w.value, x.value
     assert plan(5) == (8, 20, 0)
-    assert plan(30) == (32, 20, 0)
-    assert plan(33) == (35, 18, 0)   # BASELINE config C2
-    assert plan(34) == (32, 20, 4)
-    assert plan(38) == (32, 20, 8)   # C3
-    assert plan(60) == (32, 20, 30)
+    assert plan(28) == (30, 20, 0)
+    assert plan(29) == (30, 20, 1)
+    assert plan(33) == (30, 20, 5)   # BASELINE config C2
+    assert plan(34) == (30, 20, 6)
+    assert plan(38) == (30, 20, 10)  # C3
+    assert plan(60) == (30, 20, 32)
     for need in range(0, 100):
         rows, waves, extra = plan(need)
-        assert rows * 256 * waves <= 160 * 1024 and waves >= 16
+        assert -(-rows * 256 // 1280) * 1280 * waves <= 160 * 1024 and waves == 20
         assert rows + extra >= need + 2
 
 
