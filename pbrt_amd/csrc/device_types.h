@@ -34,10 +34,14 @@ inline const char *debug_knob(const char *name) {
 // the overflow variant: kQuadLdsStackOvf rows in LDS at 20 waves, deeper entries in HBM (kQuadLdsStack = the rows of the
 // ray-batch kernel, and the most the render kernel takes with PBRT_HIP_PREFER_LDS_STACK).  -DPBRT_QUAD_LDS_STACK=12 forces the overflow variant on nearly every scene (tests of that path).
 #ifdef PBRT_QUAD_LDS_STACK
-constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK, kQuadLdsStackOvf = PBRT_QUAD_LDS_STACK;
+constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK, kQuadLdsStackOvf = PBRT_QUAD_LDS_STACK, kQuadLdsStackOvfDeep = PBRT_QUAD_LDS_STACK;
 #else
-constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 30;
+constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 30, kQuadLdsStackOvfDeep = 35;
 #endif
+// Very deep trees (stack bound >= 42: the 12 M-triangle `big` workload has 44) reach the end of a 30-row LDS part often
+// enough for the slow form of the step to cost more than two waves per CU buy: they get 35 rows at 18 waves (`big`: 870 ms
+// against 925 at 30 rows and 878 at 40; C3, bound 38: 162 / 169 / 178 ms at 30 / 35 / 40 rows).
+constexpr uint32_t kOvfDeepNeed = 42;
 constexpr uint32_t kLdsGranule = 1280u;
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 #ifndef PBRT_RENDER_MAX_WAVES_PER_CU  // 4 SIMDs x the waves per SIMD the render kernel's register budget allows (kernels.hip)
@@ -52,7 +56,7 @@ constexpr uint32_t kEmptyLeafRef = 0x80000000u;
 
 struct RenderStackPlan {
   uint32_t rows;           // LDS rows per wave
-  bool overflow;           // the overflow variant (rows == kQuadLdsStackOvf)
+  bool overflow;           // the overflow variant (rows == kQuadLdsStackOvf or kQuadLdsStackOvfDeep)
   uint32_t waves_per_cu;   // one-wave workgroups a CU holds at once with these rows (at most 20: 5 per SIMD by registers)
   uint32_t extra_entries;  // HBM entries per lane beyond the LDS part (overflow variant)
 };
@@ -65,8 +69,8 @@ inline RenderStackPlan render_stack_plan(uint32_t quad_stack_need, bool force_ov
   };
   p.rows = need_rows < 8u ? 8u : need_rows;
   // (20 waves with the overflow variant beat 18 or 16 waves with the whole stack in LDS: C2 +1 %, C3 +4 %)
-  p.overflow = force_overflow || need_rows > kQuadLdsStack || (waves(p.rows) < kRenderMaxWavesPerCu && !prefer_lds);
-  if (p.overflow) p.rows = kQuadLdsStackOvf;
+  p.overflow = force_overflow || need_rows > kQuadLdsStack || (waves(p.rows) < waves(kQuadLdsStackOvf) && !prefer_lds);
+  if (p.overflow) p.rows = quad_stack_need >= kOvfDeepNeed ? kQuadLdsStackOvfDeep : kQuadLdsStackOvf;
   p.waves_per_cu = waves(p.rows);
   p.extra_entries = p.overflow && need_rows > p.rows ? need_rows - p.rows : 0u;
   return p;

@@ -736,8 +736,8 @@ __device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const
 // order so that the counters are the oracle's; COUNT without EXACT counts the production walk itself
 // (64-byte fetches and triangle tests).
 // One workgroup = one wavefront = one 8x8 pixel tile; 64 workgroups per 64x64 super-tile.
-// STACK: LDS entries of the exact walk; for the production walk it only says whether the HBM overflow
-// area is compiled in (STACK != 0).
+// STACK: LDS entries of the exact walk; for the production walk the LDS rows of the overflow variant (deeper entries
+// in the HBM overflow area), or 0 = the whole stack in LDS.
 template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK>
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     }
     PROBE_SEC(8);
     if (__ballot(state != ST_DONE) == 0ull) break;
-    trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? kQuadLdsStackOvf : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
+    trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? (uint32_t)STACK : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
     PROBE_SEC(0);
   }
 
@@ -1230,7 +1230,10 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
     // are a few steps long (C4: 3 would cost 5 %)
     const RenderStackPlan plan = render_stack_plan(S.quad_stack_need, render_force_overflow(), render_prefer_lds());
     const uint32_t lds = plan.rows * 256u;
-    if (plan.overflow) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 1>), grid, block, lds, st, S, R);
+    // (production walk: STACK = the LDS rows of the overflow variant, 0 = whole stack in LDS)
+    if (plan.overflow && plan.rows == kQuadLdsStackOvfDeep && kQuadLdsStackOvfDeep != kQuadLdsStackOvf)
+      hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, (int)kQuadLdsStackOvfDeep>), grid, block, lds, st, S, R);
+    else if (plan.overflow) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, (int)kQuadLdsStackOvf>), grid, block, lds, st, S, R);
     else if (!COUNT && S.quad_stack_need <= 16u) hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0, 2>), grid, block, lds, st, S, R);
     else hipLaunchKernelGGL((render_kernel<SPH, COUNT, false, 0>), grid, block, lds, st, S, R);
     return hipGetLastError();
