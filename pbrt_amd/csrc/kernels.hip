@@ -443,13 +443,13 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       }
       // (an unused child slot holds kEmptyLeafRef behind an inverted box: if a degenerate ray gets through that box the
       // lane parks at a leaf without triangles and pops -- no test for it here)
+      // The nearest child hit is entered, the other hit ones are stacked in slot order.  Order affects only
+      // speed (tie rule of 3.4) -- but a lot: visiting the hit children in slot order alone costs C3 49 node steps per
+      // ray instead of 41 (measured, r02), and sorting the stacked ones cost more than it saved (r01).
 #pragma unroll
       // (a missed child's key is a NaN with all bits set -- an inline constant of the select, where +inf would need a
       // register; fminf ignores it, and when every child is missed nothing below uses kmin)
       for (int k = 0; k < 4; k++) key[k] = hit[k] ? key[k] : __uint_as_float(0xffffffffu);
-      // The nearest child hit is entered, the other hit ones are stacked in slot order.  Order affects only
-      // speed (tie rule of 3.4) -- but a lot: visiting the hit children in slot order alone costs C3 49 node steps per
-      // ray instead of 41 (measured, r02), and sorting the stacked ones cost more than it saved (r01).
       const float kmin = fminf(fminf(key[0], key[1]), fminf(key[2], key[3]));
       const bool n0 = key[0] == kmin, n1 = !n0 && key[1] == kmin, n2 = !n0 && !n1 && key[2] == kmin;
       const bool n3 = !n0 && !n1 && !n2;

@@ -23,7 +23,7 @@ FRAMES_TRACE, FRAMES_PMC = 3, 1  # --steps 2 --warmup 1 / --steps 1 --warmup 0
 
 def one(pattern):
     f = glob.glob(pattern, recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None  # (a re-run of one workload leaves the older files beside the new ones)
 
 
 def main():
@@ -76,7 +76,7 @@ def main():
         shutil.copy(os.path.join(P, f"{tag}_{wl}_summary.json"), os.path.join(P, f"pmc_{wl}.json"))
         print(wl, {k: summary.get(k) for k in ("avg_ms", "traffic_bytes_raw", "valu_busy_frac_at_profile_clock", "lane_utilisation", "valu_issue_cycles_per_ray")})
     for f in glob.glob(os.path.join(G, f"bench_*_{tag}.json")):
-        wl = os.path.basename(f).split("_")[1]
+        wl = os.path.basename(f)[len("bench_"):-len(f"_{tag}.json")]  # "c3", "c3_gpubuilder", ...
         if os.path.getsize(f):
             shutil.copy(f, os.path.join(P, f"{tag}_{wl}_bench.json"))
 
