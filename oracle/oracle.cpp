@@ -17,12 +17,12 @@ static bool g_debug_li = false;  // ORC_DEBUG_LI=1: orc_pixel_samples traces eve
 
 // -------- Samplers --------
 // A pixel's spp samples are cut into kSampleChunks CHUNKS: chunk c holds the samples s with
-// floor(c * spp / 8) <= s < floor((c + 1) * spp / 8) and is a unit of its own -- its own PCG32 stream
-// Rng::new((seed * W * H + y * W + x) * 8 + c) (rng.rs:46-59 fixes only set_sequence) and its own partial film sum;
-// the pixel's contrib_sum is the sum of the eight partial sums in chunk order.  (Round 1 ran all samples of a
-// pixel on one stream; the chunks exist so that the GPU can hand out work in pieces of spp / 8 samples: the frame no
+// floor(c * spp / 16) <= s < floor((c + 1) * spp / 16) and is a unit of its own -- its own PCG32 stream
+// Rng::new((seed * W * H + y * W + x) * 16 + c) (rng.rs:46-59 fixes only set_sequence) and its own partial film sum;
+// the pixel's contrib_sum is the sum of the sixteen partial sums in chunk order.  (Round 1 ran all samples of a
+// pixel on one stream; the chunks exist so that the GPU can hand out work in pieces of spp / 16 samples: the frame no
 // longer waits for the sequential samples of its most expensive pixels.)
-constexpr uint32_t kSampleChunks = 8;
+constexpr uint32_t kSampleChunks = 16;
 static inline uint32_t chunk_begin(uint32_t c, uint32_t spp) { return (uint32_t)(((uint64_t)c * spp) / kSampleChunks); }
 
 // lowbias32 (integer hash; every operation is defined on uint32): the scrambles of the Sobol sampler come from it

@@ -106,7 +106,7 @@ def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
 
 
 def test_item_handout_is_scheduling_only(gpu, oracle, monkeypatch):
-    """A pixel's samples run in eight chunks (work items with their own RNG stream and partial film sum)
+    """A pixel's samples run in sixteen chunks (work items with their own RNG stream and partial film sum)
     that any lane of any wave may take in any order.  The film must not depend on who takes what: ragged image, three
     ranks, a grid of 5 one-wave workgroups (every lane renders hundreds of items) and one of a single hand-out region,
     all bit-equal to the oracle, with the oracle's canonical counters."""
@@ -131,9 +131,9 @@ def test_item_handout_is_scheduling_only(gpu, oracle, monkeypatch):
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
 
 
-@pytest.mark.parametrize("spp", [(1, 1), (3, 1), (7, 1), (3, 3), (5, 5), (13, 5)])
+@pytest.mark.parametrize("spp", [(1, 1), (3, 1), (7, 1), (3, 3), (5, 5), (17, 1), (13, 5)])
 def test_sample_chunks(gpu, oracle, spp):
-    """Chunk boundaries floor(c * spp / 8): fewer samples than chunks (empty chunks), spp not a multiple of 8."""
+    """Chunk boundaries floor(c * spp / 16): fewer samples than chunks (empty chunks), spp not a multiple of 16."""
     sd = SMALL_SCENES["cornell"]()
     ref, _ = oracle.OracleScene(sd).render(max_depth=5, spp=spp, seed=21)
     with gpu.Scene(sd) as sc:

@@ -159,8 +159,8 @@ def test_tie_rule_on_duplicated_geometry(oracle):
 
 
 def test_film_is_the_chunk_ordered_sum_of_the_samples(oracle):
-    """a pixel's contrib_sum is ((part_0 + part_1) + ... + part_7) with part_c the in-order sum of
-    the samples floor(c spp / 8) <= s < floor((c + 1) spp / 8) -- recomputed here from the per-sample radiances."""
+    """a pixel's contrib_sum is ((part_0 + part_1) + ... + part_15) with part_c the in-order sum of
+    the samples floor(c spp / 16) <= s < floor((c + 1) spp / 16) -- recomputed here from the per-sample radiances."""
     from pbrt_amd import film_to_rgb  # noqa: F401  (host arithmetic only)
     sd = SMALL_SCENES["cornell"]()
     sc = oracle.OracleScene(sd)
@@ -170,9 +170,9 @@ def test_film_is_the_chunk_ordered_sum_of_the_samples(oracle):
         for (x, y) in ((10, 12), (40, 33)):
             s = sc.pixel_samples(x, y, max_depth=5, spp=spp, seed=3, sampler=sampler)
             total = np.zeros(3, np.float32)
-            for c in range(8):
+            for c in range(16):
                 part = np.zeros(3, np.float32)
-                for k in range((c * n) // 8, ((c + 1) * n) // 8):
+                for k in range((c * n) // 16, ((c + 1) * n) // 16):
                     part = part + s[k]
                 total = total + part
             want = np.zeros(4, np.float32)
