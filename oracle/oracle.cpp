@@ -16,14 +16,18 @@ static bool g_debug_li = false;  // ORC_DEBUG_LI=1: orc_pixel_samples traces eve
 
 
 // -------- Samplers --------
-// A pixel's spp samples are cut into kSampleChunks CHUNKS: chunk c holds the samples s with
-// floor(c * spp / 16) <= s < floor((c + 1) * spp / 16) and is a unit of its own -- its own PCG32 stream
-// Rng::new((seed * W * H + y * W + x) * 16 + c) (rng.rs:46-59 fixes only set_sequence) and its own partial film sum;
-// the pixel's contrib_sum is the sum of the sixteen partial sums in chunk order.  (Round 1 ran all samples of a
-// pixel on one stream; the chunks exist so that the GPU can hand out work in pieces of spp / 16 samples: the frame no
-// longer waits for the sequential samples of its most expensive pixels.)
-constexpr uint32_t kSampleChunks = 16;
-static inline uint32_t chunk_begin(uint32_t c, uint32_t spp) { return (uint32_t)(((uint64_t)c * spp) / kSampleChunks); }
+// A pixel's spp samples are cut into K CHUNKS, K = sample_chunks(spp) = the largest power of two <= 16 that leaves a chunk
+// at least 32 samples (1 below 64 spp): chunk c holds the samples s with floor(c * spp / K) <= s < floor((c + 1) * spp / K)
+// and is a unit of its own -- its own PCG32 stream Rng::new((seed * W * H + y * W + x) * K + c) (rng.rs:46-59 fixes only
+// set_sequence) and its own partial film sum; the pixel's contrib_sum is the sum of the K partial sums in chunk order.
+// (Round 1 ran all samples of a pixel on one stream; the chunks exist so that the GPU can hand out work in pieces of about
+// 32 samples: the frame no longer waits for the sequential samples of its most expensive pixels.)
+static inline uint32_t sample_chunks(uint32_t spp) {
+  uint32_t k = 1;
+  while (2 * k <= 16 && 2 * k * 32 <= spp) k *= 2;
+  return k;
+}
+static inline uint32_t chunk_begin(uint32_t c, uint32_t spp) { return (uint32_t)(((uint64_t)c * spp) / sample_chunks(spp)); }
 
 // lowbias32 (integer hash; every operation is defined on uint32): the scrambles of the Sobol sampler come from it
 static inline uint32_t mix32(uint32_t v) {
@@ -52,7 +56,7 @@ class StratifiedSampler : public Sampler {
     inv_ny_ = 1.0f / (float)ny;
   }
   void StartChunk(int x, int y, uint32_t chunk) override {
-    rng_.set_sequence((seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x) * kSampleChunks + chunk);
+    rng_.set_sequence((seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x) * sample_chunks(nx_ * ny_) + chunk);
     px_ = x; py_ = y;
     s_ = chunk_begin(chunk, nx_ * ny_);
     s_end_ = chunk_begin(chunk + 1, nx_ * ny_);
@@ -401,7 +405,7 @@ static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_
   Sampler &sampler = r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat;
   Vec3 sum = {0, 0, 0};
   uint32_t i = 0;
-  for (uint32_t c = 0; c < kSampleChunks; c++) {
+  for (uint32_t c = 0, n_chunks = sample_chunks(r.spp_x * r.spp_y); c < n_chunks; c++) {
     Vec3 part = {0, 0, 0};
     for (sampler.StartChunk(x, y, c); !sampler.ChunkDone(); sampler.StartNextSample()) {
       float fx, fy;

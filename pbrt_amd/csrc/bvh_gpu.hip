@@ -556,6 +556,11 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t *level_count
     }
     ebyte[a] = (uint32_t)((e > 127 ? 127 : e) + 127);
   }
+  // the interior children of a node are allocated side by side, as in the host's breadth-first array (one atomic for the
+  // node: siblings share 128-byte lines, and a walk that has taken one child usually comes back for the next)
+  uint32_t n_int = 0;
+  for (int k = 0; k < nk; k++) n_int += (kids[k].c & kLeafRef) ? 0u : 1u;
+  uint32_t quad = n_int ? atomicAdd(&counters[0], n_int) : 0u, slot = n_int ? atomicAdd(&level_count[1], n_int) : 0u;
   uint32_t ref[4];
   for (int k = 0; k < 4; k++) {
     if (k >= nk) { ref[k] = kEmptyLeafRef; continue; }
@@ -563,9 +568,8 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t *level_count
     if (c & kLeafRef) {
       ref[k] = kLeafRef | (1u << 24) | (c & ~kLeafRef);  // one triangle, leaf slot = sorted position
     } else {
-      const uint32_t quad = atomicAdd(&counters[0], 1u);
       ref[k] = quad * 64u;  // byte offset in the node array (capi.cpp make_quad_nodes)
-      next[atomicAdd(&level_count[1], 1u)] = CollapseItem{c, quad, path};
+      next[slot++] = CollapseItem{c, quad++, path};
     }
   }
   uint4 *q = quads + 4 * (size_t)it.quad;

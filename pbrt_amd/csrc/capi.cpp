@@ -828,13 +828,15 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for the kernel's tile arithmetic");
     // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once (16 per CU: the
     // LDS stack and the register budget both allow 4 per SIMD), each lane drawing item after item from the rank's list.
-    // An item is one CHUNK (a sixteenth of the samples) of one pixel: DESIGN.md 3.1.
-    if ((uint64_t)sh.n_local * 4096u * kSampleChunks >= (1ull << 32)) return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for 32-bit item numbers");
-    R.n_items = sh.n_local * 4096u * kSampleChunks;
+    // An item is one CHUNK (a K-th of the samples, K <= 16 with at least 32 samples per chunk) of one pixel: DESIGN.md 3.1.
+    R.chunk_shift = sample_chunk_shift(spp);
+    const uint32_t n_chunks = 1u << R.chunk_shift;  // K: DESIGN.md 3.1
+    if ((uint64_t)sh.n_local * 4096u * n_chunks >= (1ull << 32)) return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for 32-bit item numbers");
+    R.n_items = sh.n_local * 4096u * n_chunks;
     // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
     const RenderStackPlan plan = render_stack_plan(s->dev.quad_stack_need, render_force_overflow(), render_prefer_lds());
     const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, plan.waves_per_cu) : plan.waves_per_cu;
-    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u * kSampleChunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
+    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
     R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
     {
@@ -843,7 +845,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       R.lane_state = s->d_lane_state.p;
     }
     {
-      const size_t need = (size_t)sh.n_local * 4096u * kSampleChunks;  // one float4 per item
+      const size_t need = (size_t)sh.n_local * 4096u * n_chunks;  // one float4 per item
       if (s->d_partials.n < need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
       R.partials = s->d_partials.p;
     }
@@ -862,7 +864,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       return fail(PBRT_HIP_ERR_INVALID, "render: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 80 * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
-    // one launch renders every item of the rank; the merge adds each pixel's sixteen partial sums in chunk order
+    // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order
     HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
     HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
     HIP_TRY(hipEventRecord(s->ev1, st));

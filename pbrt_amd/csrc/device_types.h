@@ -54,10 +54,15 @@ constexpr uint32_t kRenderMaxWavesPerCu = PBRT_RENDER_MAX_WAVES_PER_CU;
 // pops: harmless, so the node step needs no "is this slot used" test (it had two compares per step for it until r02c).
 constexpr uint32_t kEmptyLeafRef = 0x80000000u;
 
-// A pixel's samples are cut into kSampleChunks chunks, each a work item with its own RNG stream and partial film sum
-// (oracle/oracle.cpp has the same constant).  Item number: pixel-in-block (6 bits) | chunk << 6 | 8x8 block << 10.
-constexpr uint32_t kChunkShift = 4u, kSampleChunks = 1u << kChunkShift;
-constexpr uint32_t kItemsPerBlockShift = 6u + kChunkShift;  // 64 pixels x kSampleChunks items per 8x8 block
+// A pixel's spp samples are cut into K = sample_chunks(spp) chunks, each a work item with its own RNG stream and partial
+// film sum (oracle/oracle.cpp has the same rule): the largest power of two <= 16 that leaves a chunk at least
+// 32 samples (1 below 64 spp).  Item number: pixel-in-block (6 bits) | chunk << 6 | 8x8 block << (6 + log2 K).
+constexpr uint32_t kMaxSampleChunks = 16u, kMinSamplesPerChunk = 32u;
+inline uint32_t sample_chunk_shift(uint32_t spp) {  // log2 K
+  uint32_t kb = 0;
+  while ((2u << kb) <= kMaxSampleChunks && (2u << kb) * kMinSamplesPerChunk <= spp) kb++;
+  return kb;
+}
 
 struct RenderStackPlan {
   uint32_t rows;           // LDS rows per wave
@@ -123,9 +128,10 @@ struct RenderParams {
   uint32_t stack_overflow_entries;
   uint32_t *next_item;    // hand-out counters of the render kernel's item list, one per region, 16 words apart (zeroed before the launch)
   uint32_t n_regions;     // contiguous parts of the list, one per XCD (kernels.hip fetch step)
-  uint32_t n_items;       // n_local_super * 4096 pixels * kSampleChunks (kernels.hip: item = block, chunk, pixel in block)
+  uint32_t n_items;       // n_local_super * 4096 pixels * K chunks (kernels.hip: item = block, chunk, pixel in block)
+  uint32_t chunk_shift;   // log2 K, K = sample_chunks(spp)
   uint32_t n_workgroups;  // one-wave workgroups launched: what the device holds at once, not one per tile
-  float4 *partials;       // [slab position][kSampleChunks]: the partial film sums of the chunks (merge_kernel adds them in order)
+  float4 *partials;       // [slab position][K]: the partial film sums of the chunks (merge_kernel adds them in order)
   uint32_t sampler;       // PBRT_HIP_SAMPLER_*
   uint32_t spp_mask;      // Sobol sampler: 2^ceil(log2(spp)) - 1
   uint32_t stx_recip, spp_x_recip;  // ceil(2^32 / super-tiles per row), ceil(2^32 / spp_x): the kernel's divisions by these two
@@ -150,7 +156,7 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);
-// adds the kSampleChunks partial sums of every pixel of a rank's slab in chunk order and converts to XYZ (Film::merge_film_tile)
+// adds the K partial sums of every pixel of a rank's slab in chunk order and converts to XYZ (Film::merge_film_tile)
 hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
                         uint32_t n_local_super, uint32_t spp, hipStream_t stream);
 // bvh_gpu.hip: the accelerator built on the device.  d_order (n_tris) and d_quads (>= n_tris nodes of 4 uint4) are outputs.

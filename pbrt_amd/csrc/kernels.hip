@@ -699,8 +699,8 @@ __device__ __forceinline__ void path_load(const LaneRecords &rec, PathState &P) 
 }
 
 // ---- samplers (DESIGN.md 3.1 stratified, 3.10 padded (0,2)-sequence) ----
-// (kSampleChunks = 16 chunks per pixel: device_types.h)
-__device__ __forceinline__ uint32_t chunk_begin(uint32_t c, uint32_t spp) { return (c * spp) >> kChunkShift; }  // spp <= 2^20
+// (K = 2^kb chunks per pixel, kb = RenderParams::chunk_shift: device_types.h sample_chunk_shift)
+__device__ __forceinline__ uint32_t chunk_begin(uint32_t c, uint32_t spp, uint32_t kb) { return (c * spp) >> kb; }  // spp <= 2^20, c <= 16
 __device__ __forceinline__ uint32_t mix32(uint32_t v) {  // lowbias32
   v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
   return v;
@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
   uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u;  // wave-uniform (SGPRs); the lane is added at use
 
   // Work is handed out dynamically (see the fetch step of the service stage) in ITEMS: item number `item` of this rank
-  // is chunk ((item >> 6) & 15) of pixel (item & 63) of 8x8 block (item >> 10) -- the 1024 items of a block are its 64
+  // is chunk ((item >> 6) & (K - 1)) of pixel (item & 63) of 8x8 block (item >> (6 + log2 K)) -- the 64 K items of a block are its 64
   // pixels at chunk 0, then at chunk 1, ... so a wave that draws 64 consecutive items holds one 8x8 block at one
   // chunk.  Pixel number q = block * 64 + pixel is pixel (q & 63) of 8x8 block ((q >> 6) & 63) of local super-tile
   // (q >> 12), both row-major.
@@ -767,7 +767,8 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     xr = (int32_t)(tx * 64u + ((q >> 6) & 7u) * 8u + (q & 7u));
     yr = (int32_t)(ty * 64u + ((q >> 9) & 7u) * 8u + ((q >> 3) & 7u));
   };
-  auto item_pixel = [](uint32_t it) { return ((it >> kItemsPerBlockShift) << 6) | (it & 63u); };
+  const uint32_t kb = R.chunk_shift, chunk_mask = (1u << kb) - 1u;  // K = 2^kb chunks per pixel
+  auto item_pixel = [&](uint32_t it) { return ((it >> (6u + kb)) << 6) | (it & 63u); };
   // place of pixel q in the rank's slab (super-tiles back to back, row-major inside) and so of its 8 partial sums
   auto slab_pos = [](uint32_t q) {
     return (size_t)(q >> 12) * 4096u + (((q >> 9) & 7u) * 8u + ((q >> 3) & 7u)) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u);
@@ -808,7 +809,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     if (serve && state != ST_FETCH) {
       path_load(rec, P);
       pixel_xy(item_pixel(item), xr, yr);
-      P.rng.inc = (((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) * kSampleChunks + ((item >> 6) & (kSampleChunks - 1u))) << 1) | 1u;
+      P.rng.inc = ((((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) << kb) + ((item >> 6) & chunk_mask)) << 1) | 1u;
       PROBE_SEC(1);
       if (state != ST_NEW) {
         if (SPH) trav_spheres(S, T);
@@ -958,10 +959,10 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
             const V3 sum = mk(sm.x, sm.y, sm.z) + P.L;
             P.s++;
             if (sobol) P.rng.state &= 0xffffffffull;  // request counter of the next sample
-            if (P.s == chunk_begin(((item >> 6) & (kSampleChunks - 1u)) + 1u, spp)) {
-              // the chunk is complete: its partial sum goes to the item's slot; merge_kernel adds a pixel's sixteen in
+            if (P.s == chunk_begin(((item >> 6) & chunk_mask) + 1u, spp, kb)) {
+              // the chunk is complete: its partial sum goes to the item's slot; merge_kernel adds a pixel's K in
               // chunk order (Film::merge_film_tile, core/film.rs:313-326)
-              R.partials[slab_pos(item_pixel(item)) * kSampleChunks + ((item >> 6) & (kSampleChunks - 1u))] = make_float4(sum.x, sum.y, sum.z, 0.f);
+              R.partials[(slab_pos(item_pixel(item)) << kb) + ((item >> 6) & chunk_mask)] = make_float4(sum.x, sum.y, sum.z, 0.f);
               state = ST_FETCH;  // this lane takes another item
             } else {
               rec_store(rec, kRecSum, make_float4(sum.x, sum.y, sum.z, 0.f));
@@ -976,7 +977,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     // ---- fetch: lanes without an item draw the next ones of this rank's item list (wave-uniform; one atomic per
     // wave and round).  An item stays with its lane for all its samples, so its RNG stream, sample order and partial
     // sum are those of DESIGN.md 3.1 whichever lane happens to take it; what the dynamic hand-out removes is the
-    // idling of lanes whose pixels have short paths (sky) beside long ones, and -- items being a sixteenth of a pixel --
+    // idling of lanes whose pixels have short paths (sky) beside long ones, and -- items being a K-th of a pixel --
     // the wait for the sequential samples of the frame's most expensive pixels at its end. ----
     for (;;) {
       const unsigned long long mw = __ballot(state == ST_FETCH);
@@ -986,10 +987,10 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
       // one part of the image -- and helps the next part when its own is exhausted.
       uint32_t base = 0, lim = R.n_items;
       for (uint32_t tries = 0; tries < R.n_regions; tries++) {
-        // (parts are cut at multiples of 1024 items = whole 8x8 blocks)
-        const uint32_t nblk = R.n_items >> kItemsPerBlockShift;
-        const uint32_t lo = ((nblk * region) / R.n_regions) << kItemsPerBlockShift;  // (nblk < 2^22, at most 8 regions)
-        const uint32_t hi = ((nblk * (region + 1u)) / R.n_regions) << kItemsPerBlockShift;
+        // (parts are cut at multiples of 64 K items = whole 8x8 blocks)
+        const uint32_t nblk = R.n_items >> (6u + kb);
+        const uint32_t lo = ((nblk * region) / R.n_regions) << (6u + kb);  // (nblk < 2^26 / 8, at most 8 regions)
+        const uint32_t hi = ((nblk * (region + 1u)) / R.n_regions) << (6u + kb);
         if (lane == 0) base = atomicAdd(R.next_item + 16u * region, (uint32_t)__popcll(mw));
         base = __builtin_amdgcn_readfirstlane(base) + lo;
         lim = hi;
@@ -1002,12 +1003,12 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
         if (it >= lim) {
           if (base >= lim) state = ST_DONE;  // every part exhausted (else: this lane draws again in the next round)
         } else {
-          const uint32_t q = item_pixel(it), chunk = (it >> 6) & (kSampleChunks - 1u);
+          const uint32_t q = item_pixel(it), chunk = (it >> 6) & chunk_mask;
           pixel_xy(q, xr, yr);
           if (xr < W && yr < H) {  // (pixels of a ragged super-tile outside the image are skipped)
-            if (chunk_begin(chunk, spp) == chunk_begin(chunk + 1u, spp)) {
+            if (chunk_begin(chunk, spp, kb) == chunk_begin(chunk + 1u, spp, kb)) {
               // an empty chunk (fewer than 8 samples per pixel): its partial sum is zero; the lane draws again
-              R.partials[slab_pos(q) * kSampleChunks + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
+              R.partials[(slab_pos(q) << kb) + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
               item = it;
               rec_store(rec, kRecSum, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1016,8 +1017,8 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
               P.wi_next = {0.f, 0.f, 0.f};
               const uint64_t pixel_seq = seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr);
               if (sobol) P.rng.state = mix32((uint32_t)pixel_seq ^ mix32((uint32_t)(pixel_seq >> 32) + 0x9e3779b9u));
-              else pcg_seq(P.rng, pixel_seq * kSampleChunks + chunk);
-              P.s = chunk_begin(chunk, spp);
+              else pcg_seq(P.rng, (pixel_seq << kb) + chunk);
+              P.s = chunk_begin(chunk, spp, kb);
               P.bounces = 0;
               P.specular = false;
               P.cont = false;
@@ -1193,10 +1194,10 @@ __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int
   if (x < w && y < h) film[(size_t)y * w + x] = slab[i];
 }
 
-// Film::merge_film_tile (core/film.rs:313-326) for one pixel of a rank's slab: contrib_sum = the sixteen partial sums of
+// Film::merge_film_tile (core/film.rs:313-326) for one pixel of a rank's slab: contrib_sum = the K = 2^kb partial sums of
 // its chunks added in chunk order, xyz = rgb_to_xyz(contrib_sum) (spectrum.rs:139-145), weight = spp.
 __global__ void merge_kernel(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
-                             uint32_t n_local_super, float weight) {
+                             uint32_t n_local_super, float weight, uint32_t kb) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_local_super * 4096u) return;
   const uint32_t j = i >> 12, pys = (i >> 6) & 63u, pxs = i & 63u;
@@ -1206,9 +1207,8 @@ __global__ void merge_kernel(const float4 *partials, float4 *slab, int32_t w, in
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
   if (x < w && y < h) {  // (pixels of a ragged super-tile outside the image were never rendered)
     V3 sum = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (uint32_t c = 0; c < kSampleChunks; c++) {
-      const float4 p = partials[(size_t)i * kSampleChunks + c];
+    for (uint32_t c = 0; c < (1u << kb); c++) {
+      const float4 p = partials[((size_t)i << kb) + c];
       sum = sum + mk(p.x, p.y, p.z);
     }
     o.x = 0.412453f * sum.x + 0.357580f * sum.y + 0.180423f * sum.z;
@@ -1328,7 +1328,7 @@ hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t
   if (n_local_super == 0) return hipSuccess;
   const uint32_t n = n_local_super * 4096u;
   hipLaunchKernelGGL(merge_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partials, slab, w, h, rank, world, n_local_super,
-                     (float)spp);
+                     (float)spp, sample_chunk_shift(spp));
   return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 reference has no renderer to generate them from, SURVEY.md section 8c "parity unpinned").
 Run from the repo root:  python tests/golden/make_golden.py
 Key format: scene-integrator-maxdepth-sppx-sppy-seed-sampler (sampler: 0 stratified, 1 sobol).
-Regenerated in round 2 (r02f): a pixel's samples run in sixteen chunks with their own RNG streams."""
+Regenerated in round 2 (r02f): a pixel's samples run in K = sample_chunks(spp) chunks with their own RNG streams."""
 import os
 import sys
 

@@ -106,7 +106,7 @@ def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
 
 
 def test_item_handout_is_scheduling_only(gpu, oracle, monkeypatch):
-    """A pixel's samples run in sixteen chunks (work items with their own RNG stream and partial film sum)
+    """A pixel's samples run in K <= 16 chunks (work items with their own RNG stream and partial film sum)
     that any lane of any wave may take in any order.  The film must not depend on who takes what: ragged image, three
     ranks, a grid of 5 one-wave workgroups (every lane renders hundreds of items) and one of a single hand-out region,
     all bit-equal to the oracle, with the oracle's canonical counters."""
@@ -131,10 +131,11 @@ def test_item_handout_is_scheduling_only(gpu, oracle, monkeypatch):
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
 
 
-@pytest.mark.parametrize("spp", [(1, 1), (3, 1), (7, 1), (3, 3), (5, 5), (17, 1), (13, 5)])
+@pytest.mark.parametrize("spp", [(1, 1), (7, 1), (5, 5), (9, 7), (8, 8), (13, 5), (16, 8), (17, 15), (16, 16), (32, 16), (25, 21)])
 def test_sample_chunks(gpu, oracle, spp):
-    """Chunk boundaries floor(c * spp / 16): fewer samples than chunks (empty chunks), spp not a multiple of 16."""
-    sd = SMALL_SCENES["cornell"]()
+    """K = sample_chunks(spp) chunks per pixel -- 1 below 64 spp, then 2, 4, 8, 16 (at least 32 samples per chunk) -- with
+    boundaries floor(c * spp / K): every K, with and without a remainder."""
+    sd = scenes.cornell_scene(40, 24) if spp[0] * spp[1] > 64 else SMALL_SCENES["cornell"]()
     ref, _ = oracle.OracleScene(sd).render(max_depth=5, spp=spp, seed=21)
     with gpu.Scene(sd) as sc:
         film, _ = sc.render(max_depth=5, spp=spp, seed=21)

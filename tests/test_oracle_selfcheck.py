@@ -158,21 +158,32 @@ def test_tie_rule_on_duplicated_geometry(oracle):
     assert not dup_hit.any()  # a duplicate never wins against its original
 
 
+def sample_chunks(spp):
+    """the largest power of two <= 16 that leaves a chunk at least 32 samples."""
+    k = 1
+    while 2 * k <= 16 and 2 * k * 32 <= spp:
+        k *= 2
+    return k
+
+
 def test_film_is_the_chunk_ordered_sum_of_the_samples(oracle):
-    """a pixel's contrib_sum is ((part_0 + part_1) + ... + part_15) with part_c the in-order sum of
-    the samples floor(c spp / 16) <= s < floor((c + 1) spp / 16) -- recomputed here from the per-sample radiances."""
+    """a pixel's contrib_sum is ((part_0 + part_1) + ... + part_{K-1}) with part_c the in-order sum of
+    the samples floor(c spp / K) <= s < floor((c + 1) spp / K), K = sample_chunks(spp) -- recomputed here from the per-sample
+    radiances, for K = 1, 2, 4 and (with a remainder) 2."""
     from pbrt_amd import film_to_rgb  # noqa: F401  (host arithmetic only)
+    assert [sample_chunks(n) for n in (1, 63, 64, 127, 128, 255, 256, 511, 512, 4096, 1 << 20)] == [1, 1, 2, 2, 4, 4, 8, 8, 16, 16, 16]
     sd = SMALL_SCENES["cornell"]()
     sc = oracle.OracleScene(sd)
-    for spp, sampler in (((5, 3), "stratified"), ((4, 4), "sobol"), ((3, 1), "stratified")):
+    for spp, sampler in (((5, 3), "stratified"), ((8, 8), "sobol"), ((16, 8), "stratified"), ((11, 7), "stratified")):
         film, _ = sc.render(max_depth=5, spp=spp, seed=3, sampler=sampler)
         n = spp[0] * spp[1]
+        K = sample_chunks(n)
         for (x, y) in ((10, 12), (40, 33)):
             s = sc.pixel_samples(x, y, max_depth=5, spp=spp, seed=3, sampler=sampler)
             total = np.zeros(3, np.float32)
-            for c in range(16):
+            for c in range(K):
                 part = np.zeros(3, np.float32)
-                for k in range((c * n) // 16, ((c + 1) * n) // 16):
+                for k in range((c * n) // K, ((c + 1) * n) // K):
                     part = part + s[k]
                 total = total + part
             want = np.zeros(4, np.float32)
