@@ -4,7 +4,7 @@
 #   1. the -m gpu parity suite;
 #   2. per workload: bench.py under rocprofv3 --kernel-trace --stats (no CPU leg under the profiler: ADVICE r01), the
 #      two HBM-traffic PMC passes on the same command (FETCH_SIZE / WRITE_SIZE, each in its own run), and the SQ / TCC /
-#      instruction-class PMC passes on a 64-spp frame (tools/pmc_passes.sh);
+#      instruction-class PMC passes on the workload's own frame (tools/pmc_passes.sh);
 #   3. bench.py itself, unprofiled, for every workload (with the CPU baseline leg where it has one).
 # tools/summarize_profile.py then condenses gpurun_out/ into profiles/ (run it here, on the CPU box).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -21,7 +21,8 @@ for w in $WLS; do
   timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_${TAG}_${w}_fetch -- python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-counters > $O/prof_${TAG}_${w}_fetch.json 2> $O/prof_${TAG}_${w}_fetch.err
   timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_${TAG}_${w}_write -- python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-counters > $O/prof_${TAG}_${w}_write.json 2> $O/prof_${TAG}_${w}_write.err
   cd $R
-  bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 8 8 > $O/pmc_${TAG}_${w}.log 2>&1   # 64-spp frames: a 4-spp probe of `big` is too short to be representative (r02a)
+  # PMC on the workload's own frame (C3: 512 spp, big: 64): the chunk count and so the hand-out granularity follow the sample count
+  if [ $w = c3 ]; then bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 32 16 > $O/pmc_${TAG}_${w}.log 2>&1; else bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 8 8 > $O/pmc_${TAG}_${w}.log 2>&1; fi
 done
 for w in c3 c2 c1 c4 big; do
   timeout 1200 python3 bench.py --workload $w --steps 2 --warmup 1 > $O/bench_${w}_${TAG}.json 2> $O/bench_${w}_${TAG}.err
