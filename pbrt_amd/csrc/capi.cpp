@@ -443,15 +443,19 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
   }
 }
 
-// The tree the walk gets: the greedy collapse.  PBRT_HIP_COLLAPSE=dp|plain selects the others (PBRT_HIP_GREEDY_COLLAPSE=0
-// = plain).  Measured: dp is 1.5-2 % faster on C2, 1 % slower on C3 (its stack bound of 41 needs the overflow variant)
-// and 2.6 % slower on C4's 19-node tree, and its build takes 50 % longer: greedy stays the default.
+// The tree the walk gets: the quantisation-aware dynamic-programming collapse for trees of 1024 triangles and more, the
+// greedy one below that.  Measured (r02f kernel): dp is 2.5 % faster on C3 (433 k instead of 488 k nodes, 40.2 instead of 41.0
+// fetches per ray), 1.6 % on C2, 3.1 % on the 12 M-triangle workload, but 2 % slower on C4's 19-node tree; its build takes a
+// third longer.  (Until r02e its deeper stack bound -- C3: 41 instead of 38 -- cost it the overflow variant of the walk, which
+// every big tree takes now anyway.)  PBRT_HIP_COLLAPSE=dp|greedy|plain overrides (PBRT_HIP_GREEDY_COLLAPSE=0 = plain).
+constexpr uint32_t kDpCollapseMinTris = 1024;
 void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, QuadNodes *out) {
   const char *c = debug_knob("PBRT_HIP_COLLAPSE");
   const char *g = debug_knob("PBRT_HIP_GREEDY_COLLAPSE");
-  Collapse how = kCollapseGreedy;
+  Collapse how = b.order.size() >= kDpCollapseMinTris ? kCollapseDp : kCollapseGreedy;
   if ((g && g[0] == '0') || (c && std::strcmp(c, "plain") == 0)) how = kCollapsePlain;
   else if (c && std::strcmp(c, "dp") == 0) how = kCollapseDp;
+  else if (c && std::strcmp(c, "greedy") == 0) how = kCollapseGreedy;
   make_quad_nodes_as(b, P, idx, split_leaves, how, out);
 }
 
