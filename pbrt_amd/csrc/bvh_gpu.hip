@@ -456,7 +456,8 @@ __global__ void sah_scatter_kernel(const uint32_t *ids, const uint32_t *seg_of, 
 }
 
 // the node of every segment gets its two children; the active children become the next level's segments
-__global__ void sah_children_kernel(int n_seg, SahSegs segs, const SahSplit *sp, const uint32_t *child_base, uint32_t next_node_base, uint32_t *child, SahSegs next) {
+__global__ void sah_children_kernel(int n_seg, SahSegs segs, const SahSplit *sp, const uint32_t *child_base, uint32_t next_node_base, uint32_t *child, SahSegs next,
+                                    uint32_t *parent_internal, uint32_t *parent_leaf) {
   const int s = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (s >= n_seg) return;
   const uint32_t st = segs.start[s], en = segs.end[s], nl = sp[s].nl, nr = en - st - nl, node = segs.node[s];
@@ -468,6 +469,10 @@ __global__ void sah_children_kernel(int n_seg, SahSegs segs, const SahSplit *sp,
   else right = kLeafRef | (st + nl);
   child[2 * (size_t)node] = left;
   child[2 * (size_t)node + 1] = right;
+  // (parents: the collapse's dynamic programme walks the tree bottom-up)
+  if (left & kLeafRef) parent_leaf[left & ~kLeafRef] = node; else parent_internal[left] = node;
+  if (right & kLeafRef) parent_leaf[right & ~kLeafRef] = node; else parent_internal[right] = node;
+  if (node == 0u) parent_internal[0] = kNone;
 }
 
 __global__ void sah_leaf_boxes_kernel(const uint32_t *ids, int n, const float *tlo, const float *thi, unsigned long long *bx, uint32_t *order) {
@@ -480,6 +485,72 @@ __global__ void sah_leaf_boxes_kernel(const uint32_t *ids, int n, const float *t
   order[k] = t;
 }
 
+// ---- the collapse's dynamic programme (capi.cpp make_quad_nodes_as, after Ylitie, Karras, Laine 2017, section 3.2) ----
+// F(n, k, d) = least expected work inside subtree n when n may occupy up to k child slots of the quad node made of its
+// ancestor at binary distance d; G(n) = the work below n as a quad node of its own.  A child is reached with the probability
+// of its box AS THE ANCESTOR'S 8-BIT GRID HOLDS IT (about one cell wider per axis).  Leaves hold one triangle here.
+constexpr float kDpTriCost = 2.0f;
+struct DpTables {
+  float *F;   // [(4 * node + (k - 1)) * 3 + (d - 1)], internal nodes
+  float *Fl;  // [3 * slot + (d - 1)], leaves
+  float *G;   // internal nodes
+};
+__device__ __forceinline__ float dp_load(const float *p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float dp_f(const DpTables &T, uint32_t c, uint32_t k, uint32_t d) {
+  return (c & kLeafRef) ? dp_load(&T.Fl[3 * (size_t)(c & ~kLeafRef) + (d - 1u)]) : dp_load(&T.F[(4 * (size_t)c + (k - 1u)) * 3 + (d - 1u)]);
+}
+// surface area of box (lo, hi) as the grid of a quad node with box (qlo, qhi) holds it
+__device__ __forceinline__ float area_on_grid(const float lo[3], const float hi[3], const float qlo[3], const float qhi[3]) {
+  float dd[3];
+  for (int a = 0; a < 3; a++) {
+    const float ext = qhi[a] - qlo[a];
+    int e = -126;
+    if (ext > 0.f) { (void)frexpf(ext / 255.0f, &e); if (e < -126) e = -126; }
+    dd[a] = (hi[a] - lo[a]) + ldexpf(1.0f, e);
+  }
+  return (dd[0] * dd[1] + dd[0] * dd[2]) + dd[1] * dd[2];
+}
+__device__ __forceinline__ float dp_dist(const DpTables &T, uint32_t l, uint32_t r, uint32_t k, uint32_t d) {
+  float best = INFINITY;
+  for (uint32_t k1 = 1; k1 < k; k1++) best = fminf(best, dp_f(T, l, k1, d) + dp_f(T, r, k - k1, d));
+  return best;
+}
+// bottom-up: one thread per leaf climbs; the second thread to reach a node computes it (its children are complete)
+__global__ void collapse_dp_kernel(int n, const uint32_t *child, const uint32_t *parent_internal, const uint32_t *parent_leaf, uint32_t *visits,
+                                   const unsigned long long *bx, DpTables T) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  float lo[3], hi[3], qlo[3], qhi[3];
+  box_load<false>(bx, (uint32_t)(n - 1 + k), lo, hi);  // (leaf boxes were written by an earlier launch)
+  uint32_t anc = parent_leaf[k];
+  for (uint32_t d = 1; d <= 3; d++) {
+    box_load<false>(bx, anc, qlo, qhi);
+    T.Fl[3 * (size_t)k + (d - 1u)] = kDpTriCost * area_on_grid(lo, hi, qlo, qhi);
+    if (parent_internal[anc] != kNone) anc = parent_internal[anc];
+  }
+  uint32_t node = parent_leaf[k];
+  while (node != kNone) {
+    __threadfence();
+    if (atomicAdd(&visits[node], 1u) == 0u) return;  // the sibling subtree is not done yet
+    __threadfence();
+    const uint32_t l = child[2 * (size_t)node], r = child[2 * (size_t)node + 1];
+    const float g = dp_dist(T, l, r, 4u, 1u);
+    T.G[node] = g;
+    box_load<false>(bx, node, lo, hi);
+    anc = node;
+    for (uint32_t d = 1; d <= 3; d++) {
+      if (parent_internal[anc] != kNone) anc = parent_internal[anc];
+      box_load<false>(bx, anc, qlo, qhi);
+      const float one = area_on_grid(lo, hi, qlo, qhi) + g;  // one step at the node when reached, plus what lies below
+      T.F[(4 * (size_t)node + 0u) * 3 + (d - 1u)] = one;
+      for (uint32_t kk = 2; kk <= 4; kk++) T.F[(4 * (size_t)node + (kk - 1u)) * 3 + (d - 1u)] = d < 3u ? fminf(one, dp_dist(T, l, r, kk, d + 1u)) : one;
+    }
+    node = parent_internal[node];
+  }
+}
+
 struct CollapseItem {
   uint32_t node, quad, path;  // binary internal node, its quad slot, stack entries held above it
 };
@@ -489,8 +560,9 @@ struct CollapseItem {
 // make_quad_nodes; leaves hold one triangle here, so only interior children open).  Child boxes are quantised to
 // the node's own 8-bit grid exactly as the host builder does it, enclosure checked in double arithmetic.
 // counters: [0] quads allocated, [1] stack need (max); level_count[0] = items of this level, level_count[1] of the next
+template <bool DP>
 __global__ void collapse_kernel(const CollapseItem *items, uint32_t *level_count, int n, const uint32_t *child, const unsigned long long *bx,
-                                uint4 *quads, CollapseItem *next, uint32_t *counters) {
+                                uint4 *quads, CollapseItem *next, uint32_t *counters, DpTables T) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= level_count[0]) return;
   const CollapseItem it = items[w];
@@ -505,9 +577,33 @@ __global__ void collapse_kernel(const CollapseItem *items, uint32_t *level_count
     kids[nk].c = c;
     nk++;
   };
+  if (DP) {
+    // follow the programme's minimising choices: node c with k slots at distance d is opened or presented as one child
+    struct Open { uint32_t c, k, d; } st[8];
+    int ns = 0;
+    auto split = [&](uint32_t c, uint32_t k, uint32_t d) {  // the children of c share k slots at distance d; ties: the most even split
+      const uint32_t l = child[2 * (size_t)c], r = child[2 * (size_t)c + 1];
+      uint32_t bk = 1;
+      float best = INFINITY;
+      for (uint32_t k1 = 1; k1 < k; k1++) {
+        const float v = dp_f(T, l, k1, d) + dp_f(T, r, k - k1, d);
+        const int ev = abs((int)(2 * k1) - (int)k), eb = abs((int)(2 * bk) - (int)k);
+        if (v < best || (v == best && ev < eb)) { best = v; bk = k1; }
+      }
+      st[ns++] = Open{r, k - bk, d};
+      st[ns++] = Open{l, bk, d};
+    };
+    split(it.node, 4u, 1u);
+    while (ns > 0) {
+      const Open o = st[--ns];
+      if (!(o.c & kLeafRef) && o.k >= 2u && o.d < 3u && dp_f(T, o.c, o.k, o.d) < dp_f(T, o.c, 1u, o.d)) split(o.c, o.k, o.d + 1u);
+      else add(o.c);
+    }
+  } else {
   add(child[2 * it.node]);
   add(child[2 * it.node + 1]);
-  for (;;) {
+  }
+  for (; !DP;) {
     int best = -1;
     float best_area = -1.f;
     for (int k = 0; k < nk; k++) {
@@ -625,6 +721,7 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   GB_TRY(hipGetLastError());
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
   uint32_t root_node = 0u;  // internal node the collapse starts from
+  bool sah_tree = false;    // (the SAH path leaves parent pointers: the collapse's dynamic programme needs them)
   const char *which = debug_knob("PBRT_HIP_GPU_BUILDER");
   if (which && std::string(which) == "lbvh") {
     GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
@@ -675,7 +772,8 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
       GB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, flags.as<uint32_t>(), scan.as<uint32_t>(), n, stream));
       hipLaunchKernelGGL(sah_scatter_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, cur_s, split.as<SahSplit>(), flags.as<uint32_t>(), scan.as<uint32_t>(),
                          cbase.as<uint32_t>(), ids_out, seg_out);
-      hipLaunchKernelGGL(sah_children_kernel, gs, b128, 0, stream, (int)n_seg, cur_s, split.as<SahSplit>(), cbase.as<uint32_t>(), next_node, child.as<uint32_t>(), nxt_s);
+      hipLaunchKernelGGL(sah_children_kernel, gs, b128, 0, stream, (int)n_seg, cur_s, split.as<SahSplit>(), cbase.as<uint32_t>(), next_node, child.as<uint32_t>(), nxt_s,
+                         par_i.as<uint32_t>(), par_l.as<uint32_t>());
       GB_TRY(hipGetLastError());
       uint32_t last[2];  // exclusive sum and count of the last segment: the next level's segment count
       GB_TRY(hipMemcpyAsync(&last[0], cbase.as<uint32_t>() + (n_seg - 1u), 4, hipMemcpyDeviceToHost, stream));
@@ -693,6 +791,7 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
     GB_TRY(hipGetLastError());
     GB_TRY(hipStreamSynchronize(stream));  // (the scratch above is freed when this block ends)
     root_node = 0u;
+    sah_tree = true;
   } else {
     // PLOC rounds.  Scratch reuse: keys / keys_out hold the two cluster lists (the Morton keys are no longer needed),
     // par_i the nearest neighbours; flags / scan are 64-bit per cluster.  The host reads the list length once a round.
@@ -732,6 +831,23 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   // top-down collapse, one launch per level of the quad tree.  The host does not know how many items a level holds
   // (the kernel reads the count the level above left on the device) nor how deep the tree is: it launches kBatch
   // levels blind -- level L holds at most min(4^L, n) items -- and looks at the device once per batch.
+  // Which descendants become a quad node's children: for trees of kDpMinTris triangles and more the dynamic programme of
+  // capi.cpp (the host's default there too), else -- and for the LBVH / PLOC trees -- the greedy largest-area rule.
+  constexpr uint32_t kDpMinTris = 1024;
+  const char *cm = debug_knob("PBRT_HIP_COLLAPSE");
+  const bool use_dp = sah_tree && n >= 2 && ((n_tris >= kDpMinTris && !(cm && std::string(cm) == "greedy")) || (cm && std::string(cm) == "dp"));
+  Tmp dpF, dpFl, dpG;
+  DpTables dp{nullptr, nullptr, nullptr};
+  if (use_dp) {
+    GB_TRY(dpF.alloc(48 * (size_t)n));
+    GB_TRY(dpFl.alloc(12 * (size_t)n));
+    GB_TRY(dpG.alloc(4 * (size_t)n));
+    dp = DpTables{dpF.as<float>(), dpFl.as<float>(), dpG.as<float>()};
+    GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
+    hipLaunchKernelGGL(collapse_dp_kernel, grid_t, block, 0, stream, n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>(), visits.as<uint32_t>(),
+                       bx.as<unsigned long long>(), dp);
+    GB_TRY(hipGetLastError());
+  }
   constexpr uint32_t kBatch = 48;
   const CollapseItem root{root_node, 0u, 0u};
   GB_TRY(hipMemcpyAsync(q0.p, &root, sizeof(root), hipMemcpyHostToDevice, stream));
@@ -747,8 +863,12 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
     uint64_t bound = first;
     for (uint32_t l = 0; l < kBatch; l++) {
       const uint32_t cap = (uint32_t)std::min<uint64_t>(bound, (uint64_t)n);
-      hipLaunchKernelGGL(collapse_kernel, dim3((cap + 127u) / 128u), dim3(128), 0, stream, cur, level_counts.as<uint32_t>() + l, n,
-                         child.as<uint32_t>(), bx.as<unsigned long long>(), d_quads, nxt, counters.as<uint32_t>());
+      if (use_dp)
+        hipLaunchKernelGGL(collapse_kernel<true>, dim3((cap + 127u) / 128u), dim3(128), 0, stream, cur, level_counts.as<uint32_t>() + l, n,
+                           child.as<uint32_t>(), bx.as<unsigned long long>(), d_quads, nxt, counters.as<uint32_t>(), dp);
+      else
+        hipLaunchKernelGGL(collapse_kernel<false>, dim3((cap + 127u) / 128u), dim3(128), 0, stream, cur, level_counts.as<uint32_t>() + l, n,
+                           child.as<uint32_t>(), bx.as<unsigned long long>(), d_quads, nxt, counters.as<uint32_t>(), dp);
       CollapseItem *t = cur; cur = nxt; nxt = t;
       bound = std::min<uint64_t>(bound * 4u, (uint64_t)n);
     }
