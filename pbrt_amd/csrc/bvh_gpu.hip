@@ -271,7 +271,10 @@ __global__ void ploc_merge_kernel(const uint32_t *clusters, const uint32_t *nn, 
 // halved as it stands.  Leaves hold one triangle.  Node ids: the root is 0, the segments of the next level get
 // consecutive ids in segment order, so the numbering is deterministic.  Per-segment sums go through atomics, aggregated in
 // LDS when a whole block lies in one segment (the top levels).
-constexpr int kSahBuckets = 16;
+#ifndef PBRT_SAH_BUCKETS
+#define PBRT_SAH_BUCKETS 16
+#endif
+constexpr int kSahBuckets = PBRT_SAH_BUCKETS;
 constexpr uint32_t kSahMedianLevel = 40;  // beyond this level only halving: bounds the depth at ~ 40 + log2(n)
 constexpr uint32_t kBinWords = kSahBuckets * 7;  // per bucket: count, box lo xyz, hi xyz (order-preserving integers)
 
