@@ -379,6 +379,11 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     if (T.cur != kDone && !trav_parked(T)) {
       // ---- one step of the production walk: the four children of quantised quad node T.cur (64 bytes) ----
       const uint32_t off = T.cur;  // the ref of an interior quad node IS its byte offset (node number x 64)
+      // Wave priority (s_setprio; the SIMD's arbiter picks the ready wave of highest priority, the oldest among equals): 3
+      // while a step issues its node fetch, 0 for the arithmetic on the node -- a wave that is about to wait ~700 cycles for
+      // its next node gets its loads out before the other waves' decode and slab tests.  With the same around the leaf
+      // pass's triangle fetch and 1 for the service stage: C3 +3.5 %, C2 +0.7 % (tools/experiments/README.md).
+      __builtin_amdgcn_s_setprio(3);
       const uint4 W0 = *reinterpret_cast<const uint4 *>(quads + off);
       const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
       const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
@@ -391,6 +396,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         if ((X0.x ^ X1.y) == 0x9e3779b9u && X0.z == 0x12345u) T.tmax = 0.f;
       }
 #endif
+      __builtin_amdgcn_s_setprio(0);
       if (COUNT) cn++;  // one 64-byte fetch
       const float tfar = fminf(T.h.t, T.tmax);
 #ifdef PBRT_EXTRA_VALU  // A-B experiment: PBRT_EXTRA_VALU extra independent VALU instructions per node step
@@ -505,9 +511,11 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         PROBE_ADD(2, 1); PROBE_ADD(3, __popcll(__ballot(cnt > i && !stop)));
         if (cnt > i && !stop) {
           const uint32_t slot = first + i;
+          __builtin_amdgcn_s_setprio(3);  // (as for the node fetch)
           const float4 a = *reinterpret_cast<const float4 *>(tris + slot * 48u);
           const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
           const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
+          __builtin_amdgcn_s_setprio(0);
           if (COUNT) ct++;
               // Moeller-Trumbore, operation order of DESIGN.md 3.5
           const V3 p0 = xyz(a);
@@ -1076,7 +1084,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     }
     PROBE_SEC(8);
     if (__ballot(state != ST_DONE) == 0ull) break;
+    __builtin_amdgcn_s_setprio(0);  // traversal arithmetic at priority 0, its fetches at 3 (trav_run)
     trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? (uint32_t)STACK : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
+    __builtin_amdgcn_s_setprio(1);  // the service stage of the next round: its lanes are not tracing while it lasts
     PROBE_SEC(0);
   }
 
