@@ -198,6 +198,27 @@ struct TravTuning {
   uint32_t min_parked;   // test triangles once this many lanes are parked at a leaf
 };
 
+// s_setprio (A-B: -DPBRT_NO_PRIO compiles the priorities out; the levels can be overridden)
+#ifndef PBRT_PRIO_FETCH
+#define PBRT_PRIO_FETCH 3
+#endif
+#ifndef PBRT_PRIO_ARITH
+#define PBRT_PRIO_ARITH 0
+#endif
+#ifndef PBRT_PRIO_SERVICE
+#define PBRT_PRIO_SERVICE 1
+#endif
+__device__ __forceinline__ void wave_prio(int p) {
+#ifndef PBRT_NO_PRIO
+  switch (p) {  // (the builtin wants a constant)
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+#endif
+}
+
 // The slab test of DESIGN.md 3.4 against [kRayTMin, tfar]: near / far plane per axis by the sign of
 // the inverse direction; fmin / fmax ignore a 0 * inf = NaN (conservative); far side padded.
 __device__ __forceinline__ bool box_test(float lx, float ly, float lz, float hx, float hy, float hz, V3 o, V3 inv,
@@ -383,7 +404,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // while a step issues its node fetch, 0 for the arithmetic on the node -- a wave that is about to wait ~700 cycles for
       // its next node gets its loads out before the other waves' decode and slab tests.  With the same around the leaf
       // pass's triangle fetch and 1 for the service stage: C3 +3.5 %, C2 +0.7 % (tools/experiments/README.md).
-      __builtin_amdgcn_s_setprio(3);
+      wave_prio(PBRT_PRIO_FETCH);
       const uint4 W0 = *reinterpret_cast<const uint4 *>(quads + off);
       const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
       const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
@@ -396,7 +417,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         if ((X0.x ^ X1.y) == 0x9e3779b9u && X0.z == 0x12345u) T.tmax = 0.f;
       }
 #endif
-      __builtin_amdgcn_s_setprio(0);
+      wave_prio(PBRT_PRIO_ARITH);
       if (COUNT) cn++;  // one 64-byte fetch
       const float tfar = fminf(T.h.t, T.tmax);
 #ifdef PBRT_EXTRA_VALU  // A-B experiment: PBRT_EXTRA_VALU extra independent VALU instructions per node step
@@ -449,6 +470,9 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       }
       // (an unused child slot holds kEmptyLeafRef behind an inverted box: if a degenerate ray gets through that box the
       // lane parks at a leaf without triangles and pops -- no test for it here)
+#ifdef PBRT_PRIO_SELECT  // (A-B: raised priority from the child selection on)
+      wave_prio(PBRT_PRIO_SELECT);
+#endif
       // The nearest child hit is entered, the other hit ones are stacked in slot order.  Order affects only
       // speed (tie rule of 3.4) -- but a lot: visiting the hit children in slot order alone costs C3 49 node steps per
       // ray instead of 41 (measured, r02), and sorting the stacked ones cost more than it saved (r01).
@@ -511,11 +535,11 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         PROBE_ADD(2, 1); PROBE_ADD(3, __popcll(__ballot(cnt > i && !stop)));
         if (cnt > i && !stop) {
           const uint32_t slot = first + i;
-          __builtin_amdgcn_s_setprio(3);  // (as for the node fetch)
+          wave_prio(PBRT_PRIO_FETCH);  // (as for the node fetch)
           const float4 a = *reinterpret_cast<const float4 *>(tris + slot * 48u);
           const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
           const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
-          __builtin_amdgcn_s_setprio(0);
+          wave_prio(PBRT_PRIO_ARITH);
           if (COUNT) ct++;
               // Moeller-Trumbore, operation order of DESIGN.md 3.5
           const V3 p0 = xyz(a);
@@ -1084,9 +1108,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     }
     PROBE_SEC(8);
     if (__ballot(state != ST_DONE) == 0ull) break;
-    __builtin_amdgcn_s_setprio(0);  // traversal arithmetic at priority 0, its fetches at 3 (trav_run)
+    wave_prio(PBRT_PRIO_ARITH);  // traversal arithmetic at priority 0, its fetches at 3 (trav_run)
     trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? (uint32_t)STACK : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
-    __builtin_amdgcn_s_setprio(1);  // the service stage of the next round: its lanes are not tracing while it lasts
+    wave_prio(PBRT_PRIO_SERVICE);  // the service stage of the next round: its lanes are not tracing while it lasts
     PROBE_SEC(0);
   }
 
