@@ -502,13 +502,16 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         // scratch) and the top advances by the hit mask; entry 0 is the sentinel kDone, so the entry below the top
         // can be read in any case.  T.sp is the LDS ADDRESS of the top: a push is one ds_write + one v_add, no
         // address arithmetic (v_lshl_or_b32 and the other three-operand integer forms issue at half rate on gfx950).
+        // the entry below the top is read BEFORE the pushes (a lane that pops has pushed nothing in this step): the read
+        // does not wait behind four writes, and the next node's address is known that much earlier
+        const uint32_t below = T.sp - kRowBytes, top = lds_load(below);
+        const uint32_t next = any_hit ? nearest : top;
         lds_store(T.sp, W3.w); T.sp += (hit[3] && !n3) ? kRowBytes : 0u;
         lds_store(T.sp, W3.z); T.sp += (hit[2] && !n2) ? kRowBytes : 0u;
         lds_store(T.sp, W3.y); T.sp += (hit[1] && !n1) ? kRowBytes : 0u;
         lds_store(T.sp, W3.x); T.sp += (hit[0] && !n0) ? kRowBytes : 0u;
-        const uint32_t below = T.sp - kRowBytes, top = lds_load(below);
-        T.sp = any_hit ? T.sp : below;  // (one select: the address below the top is there already)
-        trav_enter(T, any_hit ? nearest : top);
+        T.sp = any_hit ? T.sp : below;
+        trav_enter(T, next);
       }
     }
     }
