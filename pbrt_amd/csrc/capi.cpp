@@ -642,7 +642,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     }
     HIP_TRY(s->d_nodes.alloc(pairs.q.size()));
     HIP_TRY(s->d_quads.alloc(s->gpu_built ? 4 * (size_t)nt : quads.q.size()));
-    HIP_TRY(s->d_tris.alloc(3 * (size_t)nt));
+    HIP_TRY(s->d_tris.alloc(kTriStride * (size_t)nt));
     HIP_TRY(s->d_mats.alloc(mats.size()));
     HIP_TRY(s->d_lights.alloc(lights.size()));
     HIP_TRY(s->d_spheres.alloc(spheres.size()));

@@ -539,9 +539,9 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         if (cnt > i && !stop) {
           const uint32_t slot = first + i;
           wave_prio(PBRT_PRIO_FETCH);  // (as for the node fetch)
-          const float4 a = *reinterpret_cast<const float4 *>(tris + slot * 48u);
-          const float4 b = *reinterpret_cast<const float4 *>(tris + slot * 48u + 16u);
-          const float4 c = *reinterpret_cast<const float4 *>(tris + slot * 48u + 32u);
+          const float4 a = *reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride));
+          const float4 b = *reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride) + 16u);
+          const float4 c = *reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride) + 32u);
           wave_prio(PBRT_PRIO_ARITH);
           if (COUNT) ct++;
               // Moeller-Trumbore, operation order of DESIGN.md 3.5
@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
           if (hit) {
             uint32_t mid;
             if (!SPH || h.prim < S.n_tris) {
-              const float4 a = S.tris[3 * h.slot], b = S.tris[3 * h.slot + 1], c = S.tris[3 * h.slot + 2];
+              const float4 a = S.tris[kTriStride * h.slot], b = S.tris[kTriStride * h.slot + 1], c = S.tris[kTriStride * h.slot + 2];
               const V3 p0 = xyz(a), p1 = xyz(b), p2 = xyz(c);
               ng = unit(cross(p1 - p0, p2 - p0));
               const float w = (1.0f - h.b1) - h.b2;
@@ -1215,9 +1215,9 @@ __global__ void pack_tris_kernel(const float *P, const uint32_t *idx, const uint
   if (slot >= n_tris) return;
   const uint32_t t = order[slot];
   const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
-  tris[3 * slot] = make_float4(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2], __uint_as_float(t));
-  tris[3 * slot + 1] = make_float4(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2], __uint_as_float((uint32_t)mat_id[t]));
-  tris[3 * slot + 2] = make_float4(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2], 0.f);
+  tris[kTriStride * slot] = make_float4(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2], __uint_as_float(t));
+  tris[kTriStride * slot + 1] = make_float4(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2], __uint_as_float((uint32_t)mat_id[t]));
+  tris[kTriStride * slot + 2] = make_float4(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2], 0.f);
 }
 
 __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
