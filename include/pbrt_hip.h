@@ -157,6 +157,18 @@ int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *id
  * tests of its invariants.  quads: 16 words per node (cap_nodes nodes of room); split_leaves as the library default. */
 int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
                              uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need);
+/* The same with the binary tree the 4-wide nodes are collapsed from chosen explicitly -- PBRT_HIP_TREE_SAH: the canonical
+ * binned-SAH tree of DESIGN.md 3.3; PBRT_HIP_TREE_SBVH: SAH over triangle references with spatial splits (a triangle may
+ * be reached through several leaves; it still has one record) -- and more outputs, each of which may be NULL: order =
+ * leaf slot -> triangle id (n_tris words; what a leaf child's slot refers to), root_box = lo xyz, hi xyz, n_refs =
+ * references in the tree (n_tris without spatial splits), exact_boxes = the children's boxes before quantisation (24 floats
+ * per node of `quads`: lo xyz, hi xyz of child 0..3; diagnostics). */
+#define PBRT_HIP_TREE_SAH 0u
+#define PBRT_HIP_TREE_SBVH 1u
+#define PBRT_HIP_TREE_DEFAULT 0xffffffffu
+int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
+                                uint32_t tree, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need,
+                                uint32_t *order, float *root_box, uint32_t *n_refs, float *exact_boxes);
 
 /* ---- the hot path ---- */
 /* Render this rank's super-tiles and return the assembled film in HOST memory:

@@ -102,6 +102,7 @@ def lib(native=False):
         l.orc_sobol_dims.restype = C.c_int
         l.orc_sobol_matrix.argtypes = [C.c_int, C.c_void_p]
         l.orc_sobol_points.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        l.orc_quad_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
         _libs[native] = l
     return _libs[native]
 
@@ -204,6 +205,28 @@ def gamma_correct(v):
 
 def to_byte(v):
     return lib().orc_to_byte(v)
+
+
+def quad_walk(quads, root_box, P, idx, order, o, d, tmax, any_hit=False, root_ref=None, n_threads=None, exact_boxes=None):
+    """The production walk of the render kernel restated on the CPU (oracle/quad_walk.cpp) over a 4-wide tree a product
+    builder emitted: dict(t, prim, b1, b2, occluded, steps, tris, max_stack).  root_ref: None = quad 0 (or no tree when
+    there are no quads)."""
+    quads = np.ascontiguousarray(quads, np.uint32).reshape(-1, 16)
+    P = np.ascontiguousarray(P, np.float32).reshape(-1, 3); idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    order = np.ascontiguousarray(order, np.uint32); box = np.ascontiguousarray(root_box, np.float32)
+    o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+    tmax = np.ascontiguousarray(tmax, np.float32).reshape(-1); n = o.shape[0]
+    if root_ref is None:
+        root_ref = 0 if len(quads) else 0xFFFFFFFF
+    out = {"t": np.zeros(n, np.float32), "prim": np.zeros(n, np.uint32), "b1": np.zeros(n, np.float32), "b2": np.zeros(n, np.float32),
+           "occluded": np.zeros(n, np.uint8), "steps": np.zeros(n, np.uint32), "tris": np.zeros(n, np.uint32)}
+    ms = C.c_uint32()
+    lib().orc_quad_walk(_p(quads), len(quads), root_ref, _p(box), _p(P), _p(idx), _p(order), n, _p(o), _p(d), _p(tmax), int(any_hit),
+                        _p(out["t"]), _p(out["prim"]), _p(out["b1"]), _p(out["b2"]), _p(out["occluded"]), _p(out["steps"]),
+                        _p(out["tris"]), C.byref(ms), n_threads or os.cpu_count(),
+                        _p(np.ascontiguousarray(exact_boxes, np.float32)) if exact_boxes is not None else None)
+    out["max_stack"] = ms.value
+    return out
 
 
 class OracleScene:

@@ -130,6 +130,15 @@ void orc_pixel_samples(const orc_scene *s, const orc_render_desc *r, int x, int 
  * pixels of super-tiles owned by other ranks are left untouched. */
 int orc_render(const orc_scene *s, const orc_render_desc *r, float *film_xyzw, orc_stats *st, int n_threads);
 
+/* ---- the production walk of the render kernel (pbrt_amd/csrc/kernels.hip, quantised 4-wide nodes of DESIGN.md section
+ * 4) restated one ray at a time (quad_walk.cpp): checks the trees the product's builders emit without a GPU, and counts
+ * node steps / triangle tests per ray.  quads: 16 words per node; root_ref: 0 = quad 0, a leaf ref for a tree that is one
+ * leaf, 0xffffffff = no tree; order: leaf slot -> triangle id.  Every output may be NULL. ---- */
+void orc_quad_walk(const uint32_t *quads, uint32_t n_quads, uint32_t root_ref, const float root_box[6], const float *P,
+                   const uint32_t *idx, const uint32_t *order, int64_t n, const float *o, const float *d, const float *tmax,
+                   int any_hit, float *t, uint32_t *prim, float *b1, float *b2, uint8_t *occluded, uint32_t *steps,
+                   uint32_t *tris, uint32_t *max_stack, int n_threads, const float *exact_boxes /* diagnostics: NULL */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,6 +195,28 @@ def quad_build_host(P, idx, split_leaves=True):
     return quads[:nq.value].copy(), need.value
 
 
+TREES = {"sah": 0, "sbvh": 1, "default": 0xFFFFFFFF}
+
+
+def quad_build_host_ex(P, idx, tree="default", split_leaves=True):
+    """pbrt_hip_quad_build_host_ex (no device): dict(quads[n, 16] uint32, stack_need, order = leaf slot -> triangle,
+    root_box[6], n_refs) of the production walk's tree collapsed from the binary tree `tree` ("sah" / "sbvh" / "default")."""
+    P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
+    nt = idx.shape[0]
+    cap = 4 * nt + 4
+    quads = np.zeros((cap, 16), np.uint32)
+    order = np.zeros(max(nt, 1), np.uint32)
+    box = np.zeros(6, np.float32)
+    nq, need, nrefs = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    exact = np.zeros((cap, 24), np.float32)
+    check(lib().pbrt_hip_quad_build_host_ex(_fp(P), P.shape[0], _u32p(idx), nt, int(split_leaves), TREES[tree], _u32p(quads), cap,
+                                            C.byref(nq), C.byref(need), _u32p(order), _fp(box), C.byref(nrefs), _fp(exact)),
+          "pbrt_hip_quad_build_host_ex")
+    return {"quads": quads[:nq.value].copy(), "stack_need": need.value, "order": order[:nt].copy(), "root_box": box, "n_refs": nrefs.value,
+            "exact_boxes": exact[:nq.value].copy()}
+
+
 def slab_pixel_index(xres, yres, crop, rank, world_size):
     n = lib().pbrt_hip_slab_floats(xres, yres, (C.c_float * 4)(*crop), rank, world_size)
     if n < 0:

@@ -20,6 +20,7 @@
 #include "capi_internal.hpp"
 #include "device_types.h"
 #include "host_math.hpp"
+#include "sbvh_build.hpp"
 #include "scene_parser.hpp"
 
 using namespace pbrt_hip;
@@ -173,6 +174,7 @@ bool make_pair_nodes(const Bvh &b, PairNodes *out, std::string *why) {
 struct QuadNodes {
   std::vector<uint4> q;     // 4 per node
   uint32_t stack_need = 0;  // most entries the walk can hold: max over root-to-leaf paths of sum(children - 1)
+  std::vector<float> exact;  // diagnostics (tools/walk_sim.py): the children's boxes before quantisation, 24 floats per node
 };
 // A child of a quad node while it is being assembled: a node of the binary tree, or (split_leaves) one
 // triangle of a leaf that was expanded into a quad node of single-triangle children.
@@ -183,7 +185,9 @@ struct QuadChild {
   uint32_t leaf_node;  // binary leaf to expand into its own quad node, or 0xffffffff
 };
 enum Collapse { kCollapsePlain = 0, kCollapseGreedy = 1, kCollapseDp = 2 };
-void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, Collapse how, QuadNodes *out) {
+// `b`: the binary tree over triangle references (the canonical tree through refs_of_bvh, or the spatial-split tree of
+// sbvh_build.cpp); slot_of_ref[r] = slot of reference r's triangle in the leaf-ordered triangle records (null: r itself).
+void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split_leaves, Collapse how, QuadNodes *out) {
   const bool greedy = how != kCollapsePlain;
   if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
   auto as_u = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
@@ -220,13 +224,9 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
     }
     return (dd[0] * dd[1] + dd[0] * dd[2]) + dd[1] * dd[2];
   };
-  auto tri_box = [&](uint32_t slot, float lo[3], float hi[3]) {
-    const uint32_t t = b.order[slot];
-    for (int a = 0; a < 3; a++) {
-      const float v0 = P[3 * idx[3 * t] + a], v1 = P[3 * idx[3 * t + 1] + a], v2 = P[3 * idx[3 * t + 2] + a];
-      lo[a] = std::min(v0, std::min(v1, v2));
-      hi[a] = std::max(v0, std::max(v1, v2));
-    }
+  auto slot_of = [&](uint32_t r) { return slot_of_ref ? slot_of_ref[r] : r; };
+  auto tri_box = [&](uint32_t r, float lo[3], float hi[3]) {  // box of reference r
+    for (int a = 0; a < 3; a++) { lo[a] = b.ref_lo[3 * (size_t)r + a]; hi[a] = b.ref_hi[3 * (size_t)r + a]; }
   };
   auto one_cost = [&](uint32_t n, uint32_t d) {  // n presented as ONE child of its ancestor at distance d
     const BvhNode &nd = b.nodes[n];
@@ -291,22 +291,17 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
       QuadChild k;
       for (int a = 0; a < 3; a++) { k.lo[a] = n.lo[a]; k.hi[a] = n.hi[a]; }
       const uint32_t cnt = n.count_axis & 0xffffu;
-      k.ref = cnt ? (kLeafRef | (cnt << 24) | n.offset) : 0u;
+      k.ref = cnt ? (kLeafRef | (cnt << 24) | slot_of(n.offset)) : 0u;  // (a run of several references: consecutive slots)
       k.node = cnt ? 0xffffffffu : c;
       // a leaf of 2..4 triangles becomes a quad node of single triangles: their boxes are then tested in
       // the node step and each leaf pass tests exactly one triangle per parked lane
       k.leaf_node = (split_leaves && cnt >= 2 && cnt <= 4) ? c : 0xffffffffu;
       kids[nk++] = k;
     };
-    auto tri_child = [&](uint32_t slot) {
-      const uint32_t t = b.order[slot];
+    auto tri_child = [&](uint32_t r) {
       QuadChild k;
-      for (int a = 0; a < 3; a++) {
-        const float v0 = P[3 * idx[3 * t] + a], v1 = P[3 * idx[3 * t + 1] + a], v2 = P[3 * idx[3 * t + 2] + a];
-        k.lo[a] = std::min(v0, std::min(v1, v2));
-        k.hi[a] = std::max(v0, std::max(v1, v2));
-      }
-      k.ref = kLeafRef | (1u << 24) | slot;
+      tri_box(r, k.lo, k.hi);
+      k.ref = kLeafRef | (1u << 24) | slot_of(r);
       k.node = k.leaf_node = 0xffffffffu;
       return k;
     };
@@ -434,6 +429,12 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
         else todo.push_back({c.leaf_node, quad, path, true});
       }
     }
+    out->exact.resize(out->q.size() / 4 * 24, 0.f);
+    for (int k = 0; k < 4; k++)
+      for (int a = 0; a < 3; a++) {
+        out->exact[(size_t)it.quad * 24 + k * 6 + a] = k < nk ? kids[k].lo[a] : std::numeric_limits<float>::infinity();
+        out->exact[(size_t)it.quad * 24 + k * 6 + 3 + a] = k < nk ? kids[k].hi[a] : -std::numeric_limits<float>::infinity();
+      }
     uint4 *q = &out->q[4 * (size_t)it.quad];
     // the three cell sizes as f32 bit patterns (powers of two: exponent byte << 23), ready to be multiplied by 1 / d
     q[0] = make_uint4(as_u(me.lo[0]), as_u(me.lo[1]), as_u(me.lo[2]), ebyte[0] << 23);
@@ -449,14 +450,54 @@ void make_quad_nodes_as(const Bvh &b, const float *P, const uint32_t *idx, bool 
 // third longer.  (Until r02e its deeper stack bound -- C3: 41 instead of 38 -- cost it the overflow variant of the walk, which
 // every big tree takes now anyway.)  PBRT_HIP_COLLAPSE=dp|greedy|plain overrides (PBRT_HIP_GREEDY_COLLAPSE=0 = plain).
 constexpr uint32_t kDpCollapseMinTris = 1024;
-void make_quad_nodes(const Bvh &b, const float *P, const uint32_t *idx, bool split_leaves, QuadNodes *out) {
+void make_quad_nodes(const RefBvh &b, const uint32_t *slot_of_ref, bool split_leaves, QuadNodes *out) {
   const char *c = debug_knob("PBRT_HIP_COLLAPSE");
   const char *g = debug_knob("PBRT_HIP_GREEDY_COLLAPSE");
-  Collapse how = b.order.size() >= kDpCollapseMinTris ? kCollapseDp : kCollapseGreedy;
+  Collapse how = b.ref_tri.size() >= kDpCollapseMinTris ? kCollapseDp : kCollapseGreedy;
   if ((g && g[0] == '0') || (c && std::strcmp(c, "plain") == 0)) how = kCollapsePlain;
   else if (c && std::strcmp(c, "dp") == 0) how = kCollapseDp;
   else if (c && std::strcmp(c, "greedy") == 0) how = kCollapseGreedy;
-  make_quad_nodes_as(b, P, idx, split_leaves, how, out);
+  make_quad_nodes_as(b, slot_of_ref, split_leaves, how, out);
+}
+
+// The production walk's 4-wide tree of a triangle soup.  `tree` picks the binary tree it is collapsed from: kTreeCanonical
+// = the canonical binned-SAH tree `canon` (the oracle's tree), kTreeSbvh = a tree of its own over triangle
+// references with spatial splits (sbvh_build.cpp).  Either way a leaf child's slot refers to the triangle records in
+// `canon`'s leaf order (a triangle reached through several references has ONE record).
+enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeSbvh = 1 };
+SbvhParams sbvh_params() {
+  SbvhParams p;
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_ALPHA")) p.alpha = (float)std::atof(v);
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_BUDGET")) p.budget = (float)std::atof(v);
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_OBJECT_BINS")) p.object_bins = std::max(2, std::atoi(v));
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_SPATIAL_BINS")) p.spatial_bins = std::max(2, std::atoi(v));
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_SWEEP_BELOW")) p.sweep_below = (uint32_t)std::max(2, std::atoi(v));
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_PAD")) p.pad = (float)std::atof(v);
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_WIDEST")) p.widest_axis_only = std::atoi(v);
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_LOW_FIRST")) p.low_side_first = std::atoi(v);
+  if (const char *v = debug_knob("PBRT_HIP_SBVH_BIAS")) p.spatial_bias = (float)std::atof(v);
+  return p;
+}
+ProductionTree production_tree_default() {
+  const char *v = debug_knob("PBRT_HIP_TREE");
+  if (v && std::strcmp(v, "sbvh") == 0) return kTreeSbvh;
+  if (v && std::strcmp(v, "sah") == 0) return kTreeCanonical;
+  return kTreeCanonical;
+}
+void build_production_quads(const Bvh &canon, const float *P, const uint32_t *idx, uint32_t n_tris, ProductionTree tree,
+                            bool split_leaves, QuadNodes *out, uint32_t *n_refs = nullptr) {
+  RefBvh rb;
+  if (tree == kTreeSbvh && n_tris >= 2) {
+    build_sbvh(P, idx, n_tris, sbvh_params(), &rb);
+    std::vector<uint32_t> slot_of_tri(n_tris), slot_of_ref(rb.ref_tri.size());
+    for (uint32_t s = 0; s < n_tris; s++) slot_of_tri[canon.order[s]] = s;
+    for (size_t r = 0; r < rb.ref_tri.size(); r++) slot_of_ref[r] = slot_of_tri[rb.ref_tri[r]];
+    make_quad_nodes(rb, slot_of_ref.data(), true, out);
+  } else {
+    refs_of_bvh(canon, P, idx, &rb);
+    make_quad_nodes(rb, nullptr, split_leaves, out);
+  }
+  if (n_refs) *n_refs = (uint32_t)rb.ref_tri.size();
 }
 
 }  // namespace
@@ -493,20 +534,33 @@ int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *id
 
 int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
                              uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need) {
+  return pbrt_hip_quad_build_host_ex(P, n_verts, idx, n_tris, split_leaves, PBRT_HIP_TREE_DEFAULT, quads, cap_nodes, n_quads, stack_need,
+                                     nullptr, nullptr, nullptr, nullptr);
+}
+
+int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves, uint32_t tree,
+                                uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need, uint32_t *order,
+                                float *root_box, uint32_t *n_refs, float *exact_boxes) {
   try {
     if ((n_tris && (!P || !idx)) || !n_quads || !stack_need) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: null argument");
+    if (tree > PBRT_HIP_TREE_SBVH && tree != PBRT_HIP_TREE_DEFAULT) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: unknown tree");
     for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
       if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: vertex index out of range");
     if (first_non_finite_vertex(P, idx, n_tris) >= 0) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: a vertex is not finite");
     Bvh b;
     build_bvh(P, idx, n_tris, &b);
     QuadNodes q;
-    make_quad_nodes(b, P, idx, split_leaves != 0, &q);
+    const ProductionTree pt = tree == PBRT_HIP_TREE_DEFAULT ? production_tree_default() : (ProductionTree)tree;
+    build_production_quads(b, P, idx, n_tris, pt, split_leaves != 0, &q, n_refs);
     *n_quads = (uint32_t)(q.q.size() / 4);
     *stack_need = q.stack_need;
+    if (order && !b.order.empty()) std::memcpy(order, b.order.data(), b.order.size() * 4);
+    if (root_box && !b.nodes.empty())
+      for (int a = 0; a < 3; a++) { root_box[a] = b.nodes[0].lo[a]; root_box[3 + a] = b.nodes[0].hi[a]; }
     if (quads) {
       if (*n_quads > cap_nodes) return fail(PBRT_HIP_ERR_LIMIT, "quad_build_host: output too small");
       if (!q.q.empty()) std::memcpy(quads, q.q.data(), q.q.size() * 16);
+      if (exact_boxes && !q.exact.empty()) std::memcpy(exact_boxes, q.exact.data(), q.exact.size() * 4);
     }
     return PBRT_HIP_OK;
   } catch (const std::exception &e) {
@@ -637,7 +691,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     if (!s->gpu_built) {
       const auto t0 = std::chrono::steady_clock::now();
       const char *sl = debug_knob("PBRT_HIP_SPLIT_LEAVES");
-      make_quad_nodes(s->bvh, d->P, d->idx, !(sl && sl[0] == '0'), &quads);
+      build_production_quads(s->bvh, d->P, d->idx, d->n_tris, production_tree_default(), !(sl && sl[0] == '0'), &quads);
       s->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     HIP_TRY(s->d_nodes.alloc(pairs.q.size()));
