@@ -99,9 +99,13 @@ typedef struct {
   uint32_t rank, world_size; /* this process renders the 64x64 super-tiles t with t % world_size == rank */
   uint32_t flags;
   uint32_t sampler;          /* PBRT_HIP_SAMPLER_* */
-  float filter_xwidth, filter_ywidth; /* PixelFilter "box" "float xwidth" / "ywidth" (box.rs:57-61).  0 = the default 0.5.
-                                         Only 0.5 is implemented (a sample lands in its own pixel, film.rs:264-273 needs no
-                                         tile overlap); any other radius is refused with PBRT_HIP_ERR_LIMIT */
+  float filter_xwidth, filter_ywidth; /* PixelFilter "box" "float xwidth" / "ywidth" (box.rs:57-61): the filter's radii in
+                                         pixels.  0 = the default 0.5 (a sample lands in its own pixel, film.rs:264-273 needs
+                                         no tile overlap).  Any other radius in (0, 16]: every sample inside the sample bounds
+                                         (film.rs:166-175) adds, weight 1, to all pixels within the radius; the film is then
+                                         accumulated in 64-bit fixed point -- see pbrt_hip_render_acc below */
+  float max_sample_luminance;         /* Film "float maxsampleluminance" (film.rs:75,279; pbrt-v3 FilmTile::AddSample): a
+                                         sample whose luminance exceeds it is scaled down to it.  0 = no bound */
 } pbrt_hip_render_desc;
 
 typedef struct {
@@ -184,6 +188,23 @@ int pbrt_hip_render_wait(pbrt_hip_scene *scene, pbrt_hip_stats *stats);
 /* scatter one rank's slab (device) into a row-major film (device), both float4 per pixel */
 int pbrt_hip_film_assemble_device(const pbrt_hip_scene *scene, const void *d_slab, uint32_t rank, uint32_t world_size,
                                   void *d_film_xyzw, void *stream);
+/* ---- box filter radii other than 0.5 (pbrt_hip_render_desc.filter_xwidth / ywidth) ----
+ * The reference's Film keeps a filter table for any radius (film.rs:113-123), expands a tile by it (film.rs:264-273) and
+ * merges tiles under a mutex (film.rs:313-326); it has no add_sample.  Here such a film is accumulated in 64-bit fixed
+ * point -- four int64 per pixel of the cropped window, {r, g, b} in units of 2^-24 (a component of a sample clamped to
+ * [0, 2^15]) and the sample count -- with integer atomics: integer sums do not depend on the order of arrival, so the
+ * image is reproducible and the accumulators of several ranks ADD to those of one rank exactly (multi-GPU: one sum
+ * reduction instead of the gather).  pbrt_hip_render / pbrt_hip_render_multi accept such a desc like any other (with
+ * world_size > 1, pbrt_hip_render's film then holds the rank's OWN samples only: combine ranks by adding accumulators).
+ *  - pbrt_hip_render_buffer_bytes: bytes pbrt_hip_render_device writes for this desc -- the rank's slab (default filter)
+ *    or the accumulators of the whole cropped window, 32 bytes per pixel (zeroed by the call);
+ *  - pbrt_hip_render_acc: this rank's accumulators in HOST memory (crop_w * crop_h * 4 int64);
+ *  - pbrt_hip_film_from_acc_device / pbrt_hip_film_from_acc: accumulators -> Film pixels {X, Y, Z, weight}
+ *    (= Film::merge_film_tile's arithmetic on the radiance sum, film.rs:313-326), on the device or on the host. */
+int64_t pbrt_hip_render_buffer_bytes(const pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc);
+int pbrt_hip_render_acc(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, int64_t *acc, pbrt_hip_stats *stats);
+int pbrt_hip_film_from_acc_device(const pbrt_hip_scene *scene, const void *d_acc, void *d_film_xyzw, void *stream);
+void pbrt_hip_film_from_acc(const int64_t *acc, int64_t n_pixels, float *film_xyzw);
 /* host-side geometry of the sharding (no device needed) */
 int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world_size);
 /* for every float4 slot of a rank's slab the row-major pixel index inside the cropped film, or -1 */

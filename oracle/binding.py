@@ -40,7 +40,7 @@ class RenderDesc(C.Structure):
     _fields_ = [
         ("integrator", C.c_uint32), ("max_depth", C.c_uint32), ("spp_x", C.c_uint32), ("spp_y", C.c_uint32),
         ("seed", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32), ("flags", C.c_uint32),
-        ("sampler", C.c_uint32),
+        ("sampler", C.c_uint32), ("filter_xwidth", C.c_float), ("filter_ywidth", C.c_float), ("max_sample_luminance", C.c_float),
     ]
 
 
@@ -86,6 +86,9 @@ def lib(native=False):
         l.orc_pixel_samples.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p]
         l.orc_render.restype = C.c_int
         l.orc_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.POINTER(Stats), C.c_int]
+        l.orc_render_acc.restype = C.c_int
+        l.orc_render_acc.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_void_p, C.POINTER(Stats), C.c_int]
+        l.orc_film_from_acc.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         l.orc_quadratic.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         l.orc_gamma_correct.restype = C.c_float
         l.orc_gamma_correct.argtypes = [C.c_float]
@@ -275,10 +278,13 @@ class OracleScene:
         o = np.zeros(3, np.float32); d = np.zeros(3, np.float32)
         self.l.orc_camera_ray(self.h, fx, fy, _p(o), _p(d)); return o, d
 
-    def _rd(self, integrator, max_depth, spp, seed, rank, world_size, sampler=0):
+    def _rd(self, integrator, max_depth, spp, seed, rank, world_size, sampler=0, filter_width=None, max_sample_luminance=0.0):
         r = RenderDesc(); r.integrator = integrator; r.max_depth = max_depth; r.spp_x, r.spp_y = spp
         r.seed = seed; r.rank = rank; r.world_size = world_size
         r.sampler = {"stratified": 0, "sobol": 1}.get(sampler, sampler)
+        if filter_width is not None:
+            r.filter_xwidth, r.filter_ywidth = filter_width
+        r.max_sample_luminance = max_sample_luminance
         return r
 
     def pixel_samples(self, x, y, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler=0):
@@ -287,15 +293,32 @@ class OracleScene:
         self.l.orc_pixel_samples(self.h, C.byref(r), x, y, _p(out)); return out
 
     def render(self, integrator=0, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1, n_threads=None, sampler=0,
-               filter_width=None):
-        """sampler: "stratified" / "sobol" (or 0 / 1).  filter_width is accepted for symmetry with pbrt_amd's render
-        (the oracle, like the product, only has the box filter of radius 0.5)."""
-        if filter_width is not None and tuple(filter_width) not in ((0.5, 0.5), (0.0, 0.0)):
-            raise ValueError("the oracle only implements the box filter of radius 0.5")
-        r = self._rd(integrator, max_depth, spp, seed, rank, world_size, sampler)
+               filter_width=None, max_sample_luminance=0.0):
+        """sampler: "stratified" / "sobol" (or 0 / 1).  filter_width: box filter radii (None / (0.5, 0.5): the default;
+        others: DESIGN.md 3.11 -- with world_size > 1 the film then holds this rank's samples only and ranks combine by
+        adding ACCUMULATORS, render_acc)."""
+        r = self._rd(integrator, max_depth, spp, seed, rank, world_size, sampler, filter_width, max_sample_luminance)
         w, h = self.sd.crop_size()
         film = np.zeros((h, w, 4), np.float32); st = Stats()
         rc = self.l.orc_render(self.h, C.byref(r), _p(film), C.byref(st), n_threads or os.cpu_count())
         if rc != 0:
             raise ValueError("orc_render: bad render description")
         return film, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def render_acc(self, filter_width, integrator=0, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1, n_threads=None, sampler=0,
+                   max_sample_luminance=0.0):
+        """The fixed-point film accumulators (h, w, 4) int64 {r, g, b, samples} of this rank's samples."""
+        r = self._rd(integrator, max_depth, spp, seed, rank, world_size, sampler, filter_width, max_sample_luminance)
+        w, h = self.sd.crop_size()
+        acc = np.zeros((h, w, 4), np.int64); st = Stats()
+        rc = self.l.orc_render_acc(self.h, C.byref(r), _p(acc), C.byref(st), n_threads or os.cpu_count())
+        if rc != 0:
+            raise ValueError("orc_render_acc: bad render description")
+        return acc, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+
+def film_from_acc(acc):
+    a = np.ascontiguousarray(acc, np.int64)
+    film = np.zeros(a.shape[:-1] + (4,), np.float32)
+    lib().orc_film_from_acc(_p(a), a.size // 4, _p(film))
+    return film

@@ -50,13 +50,14 @@ class Sampler {
 // stratified pixel position + independent later dimensions
 class StratifiedSampler : public Sampler {
  public:
-  StratifiedSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s)
-      : nx_(nx), ny_(ny), seed_(seed), w_((uint64_t)s.xres), h_((uint64_t)s.yres) {
+  // pad: pixels the sample bounds reach beyond the image on each side (0 for the default filter)
+  StratifiedSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s, int pad_x = 0, int pad_y = 0)
+      : nx_(nx), ny_(ny), seed_(seed), w_((uint64_t)(s.xres + 2 * pad_x)), h_((uint64_t)(s.yres + 2 * pad_y)), pad_x_(pad_x), pad_y_(pad_y) {
     inv_nx_ = 1.0f / (float)nx;
     inv_ny_ = 1.0f / (float)ny;
   }
   void StartChunk(int x, int y, uint32_t chunk) override {
-    rng_.set_sequence((seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x) * sample_chunks(nx_ * ny_) + chunk);
+    rng_.set_sequence((seed_ * w_ * h_ + (uint64_t)(y + pad_y_) * w_ + (uint64_t)(x + pad_x_)) * sample_chunks(nx_ * ny_) + chunk);
     px_ = x; py_ = y;
     s_ = chunk_begin(chunk, nx_ * ny_);
     s_end_ = chunk_begin(chunk + 1, nx_ * ny_);
@@ -82,6 +83,7 @@ class StratifiedSampler : public Sampler {
  private:
   uint32_t nx_, ny_;
   uint64_t seed_, w_, h_;
+  int pad_x_, pad_y_;
   float inv_nx_, inv_ny_;
   Rng rng_;
   int px_ = 0, py_ = 0;
@@ -133,13 +135,14 @@ static void sobol_matrix(int dim, uint32_t out[kSobolColumns]) {
 // j): any chunk of a pixel's samples can be generated on its own.
 class SobolSampler : public Sampler {
  public:
-  SobolSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s) : spp_(nx * ny), seed_(seed), w_((uint64_t)s.xres), h_((uint64_t)s.yres) {
+  SobolSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s, int pad_x = 0, int pad_y = 0)
+      : spp_(nx * ny), seed_(seed), w_((uint64_t)(s.xres + 2 * pad_x)), h_((uint64_t)(s.yres + 2 * pad_y)), pad_x_(pad_x), pad_y_(pad_y) {
     sobol_matrix(1, c1_);
     log2_ = 0;
     while ((1u << log2_) < spp_) log2_++;
   }
   void StartChunk(int x, int y, uint32_t chunk) override {
-    const uint64_t q = seed_ * w_ * h_ + (uint64_t)y * w_ + (uint64_t)x;
+    const uint64_t q = seed_ * w_ * h_ + (uint64_t)(y + pad_y_) * w_ + (uint64_t)(x + pad_x_);
     key_ = mix32((uint32_t)q ^ mix32((uint32_t)(q >> 32) + 0x9e3779b9u));
     px_ = x; py_ = y;
     s_ = chunk_begin(chunk, spp_);
@@ -173,6 +176,7 @@ class SobolSampler : public Sampler {
  private:
   uint32_t spp_, log2_ = 0;
   uint64_t seed_, w_, h_;
+  int pad_x_, pad_y_;
   uint32_t c1_[kSobolColumns];
   uint32_t key_ = 0, j_ = 0;
   int px_ = 0, py_ = 0;
@@ -398,6 +402,80 @@ static inline Vec3 sanitize(Vec3 L) {
   return L;
 }
 
+// FilmTile::AddSample's clamp (pbrt-v3; the reference stores the bound, film.rs:75,279): a sample brighter than
+// max_sample_luminance is scaled down to it.  0 = no bound.
+static inline Vec3 clamp_luminance(Vec3 L, float max_lum) {
+  const float y = (0.212671f * L.x + 0.715160f * L.y) + 0.072169f * L.z;
+  if (max_lum > 0.f && y > max_lum) {
+    const float sc = max_lum / y;
+    return {L.x * sc, L.y * sc, L.z * sc};
+  }
+  return L;
+}
+
+// ---- box filter radii other than 0.5 ----
+// Sample bounds (film.rs:166-175) reach pad = ceil(radius - 0.5) pixels beyond the cropped window; every sample at film
+// point p adds its radiance, weight 1, to the pixels [ceil(p - 0.5 - radius), floor(p - 0.5 + radius)] inside the window
+// (pbrt-v3 FilmTile::AddSample with the box filter's table of ones).  The sums are kept in 64-bit fixed point, 2^-24
+// units, a component clamped to [0, 2^15] first: integer addition is associative, so the result does not depend on the
+// order in which samples -- of one thread or of several ranks -- arrive, which is what lets the GPU add them with atomics.
+struct WideFilter {
+  float rx, ry;
+  int pad_x, pad_y;
+  int32_t sb[4];  // sample bounds x0 y0 x1 y1
+};
+static inline float filter_radius(float w) { return w == 0.f ? 0.5f : w; }
+static inline bool is_default_filter(const orc_render_desc &r) { return filter_radius(r.filter_xwidth) == 0.5f && filter_radius(r.filter_ywidth) == 0.5f; }
+static WideFilter wide_filter(const Scene &s, const orc_render_desc &r) {
+  WideFilter f;
+  f.rx = filter_radius(r.filter_xwidth);
+  f.ry = filter_radius(r.filter_ywidth);
+  f.sb[0] = (int32_t)std::floor(((float)s.cropped[0] + 0.5f) - f.rx);
+  f.sb[1] = (int32_t)std::floor(((float)s.cropped[1] + 0.5f) - f.ry);
+  f.sb[2] = (int32_t)std::ceil(((float)s.cropped[2] - 0.5f) + f.rx);
+  f.sb[3] = (int32_t)std::ceil(((float)s.cropped[3] - 0.5f) + f.ry);
+  f.pad_x = std::max(0, (int)std::ceil(f.rx - 0.5f));
+  f.pad_y = std::max(0, (int)std::ceil(f.ry - 0.5f));
+  return f;
+}
+constexpr float kFixedOne = 16777216.0f;        // 2^24
+constexpr float kFixedMax = 32768.0f;           // 2^15: largest component a sample can add
+static inline int64_t to_fixed(float v) {
+  const float c = v > 0.f ? (v < kFixedMax ? v : kFixedMax) : 0.f;
+  return (int64_t)(c * kFixedOne);
+}
+static void render_pixel_wide(const Scene &s, const PathIntegrator &integ, const orc_render_desc &r, const WideFilter &f, int x, int y,
+                              int64_t *acc, RayStats &st) {
+  StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
+  SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
+  Sampler &sampler = r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat;
+  const int W = s.cropped[2] - s.cropped[0];
+  for (uint32_t c = 0, n_chunks = sample_chunks(r.spp_x * r.spp_y); c < n_chunks; c++)
+    for (sampler.StartChunk(x, y, c); !sampler.ChunkDone(); sampler.StartNextSample()) {
+      float fx, fy;
+      sampler.GetCameraSample(&fx, &fy);
+      Ray ray = s.camera_ray(fx, fy);
+      const Vec3 L = clamp_luminance(sanitize(integ.Li(ray, sampler, st)), r.max_sample_luminance);
+      const int64_t q[4] = {to_fixed(L.x), to_fixed(L.y), to_fixed(L.z), 1};
+      const float dx = fx - 0.5f, dy = fy - 0.5f;
+      int x0 = (int)std::ceil(dx - f.rx), x1 = (int)std::floor(dx + f.rx) + 1;
+      int y0 = (int)std::ceil(dy - f.ry), y1 = (int)std::floor(dy + f.ry) + 1;
+      x0 = std::max(x0, s.cropped[0]); x1 = std::min(x1, s.cropped[2]);
+      y0 = std::max(y0, s.cropped[1]); y1 = std::min(y1, s.cropped[3]);
+      for (int py = y0; py < y1; py++)
+        for (int px = x0; px < x1; px++) {
+          int64_t *a = acc + 4 * ((size_t)(py - s.cropped[1]) * W + (size_t)(px - s.cropped[0]));
+          for (int k = 0; k < 4; k++) __atomic_fetch_add(&a[k], q[k], __ATOMIC_RELAXED);
+        }
+    }
+}
+static inline void film_from_acc(const int64_t a[4], float out_xyzw[4]) {
+  const float inv = 1.0f / kFixedOne;
+  float rgb[3] = {(float)a[0] * inv, (float)a[1] * inv, (float)a[2] * inv}, xyz[3];
+  rgb_to_xyz(rgb, xyz);
+  out_xyzw[0] = xyz[0]; out_xyzw[1] = xyz[1]; out_xyzw[2] = xyz[2]; out_xyzw[3] = (float)a[3];
+}
+
 static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_render_desc &r, int x, int y,
                          float out_xyzw[4], float *per_sample, RayStats &st) {
   StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s);
@@ -411,7 +489,7 @@ static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_
       float fx, fy;
       sampler.GetCameraSample(&fx, &fy);
       Ray ray = s.camera_ray(fx, fy);
-      Vec3 L = sanitize(integ.Li(ray, sampler, st));
+      Vec3 L = clamp_luminance(sanitize(integ.Li(ray, sampler, st)), r.max_sample_luminance);
       if (per_sample) { per_sample[3 * i] = L.x; per_sample[3 * i + 1] = L.y; per_sample[3 * i + 2] = L.z; }
       part = part + L;  // FilmTile::AddSample with the box filter: weight 1, this pixel only
       i++;
@@ -596,13 +674,19 @@ void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int
   orc::g_debug_li = false;
 }
 
-int orc_render(const orc_scene *sc, const orc_render_desc *r, float *film, orc_stats *out, int n_threads) {
+// the render loop of both film paths: acc == nullptr: the default box filter, pixels straight into `film`; else the
+// fixed-point accumulators of DESIGN.md 3.11 over the sample bounds
+static int render_any(const orc_scene *sc, const orc_render_desc *r, float *film, int64_t *acc, orc_stats *out, int n_threads) {
   const Scene &s = sc->s;
   if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 1) return -1;
+  if (!(filter_radius(r->filter_xwidth) > 0.f) || !(filter_radius(r->filter_ywidth) > 0.f)) return -1;
   PathIntegrator integ(s, r->max_depth, r->integrator == 1);
-  const int x0 = s.cropped[0], y0 = s.cropped[1], x1 = s.cropped[2], y1 = s.cropped[3];
+  const WideFilter wf = wide_filter(s, *r);
+  // the 64x64 super-tiles cover the SAMPLE bounds (= the cropped window for the default filter)
+  const int x0 = acc ? wf.sb[0] : s.cropped[0], y0 = acc ? wf.sb[1] : s.cropped[1];
+  const int x1 = acc ? wf.sb[2] : s.cropped[2], y1 = acc ? wf.sb[3] : s.cropped[3];
   const int W = x1 - x0, H = y1 - y0;
-  if (W <= 0 || H <= 0) return 0;
+  if (W <= 0 || H <= 0 || s.cropped[2] <= s.cropped[0] || s.cropped[3] <= s.cropped[1]) return 0;
   // 16x16 work tiles inside the 64x64 super-tiles this rank owns
   const int stx = (W + 63) / 64;
   const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
@@ -620,7 +704,8 @@ int orc_render(const orc_scene *sc, const orc_render_desc *r, float *film, orc_s
       if ((uint32_t)super % r->world_size != r->rank) continue;
       for (int yy = ty * 16; yy < std::min(ty * 16 + 16, H); yy++)
         for (int xx = tx * 16; xx < std::min(tx * 16 + 16, W); xx++)
-          render_pixel(s, integ, *r, x0 + xx, y0 + yy, film + 4 * ((size_t)yy * W + xx), nullptr, st);
+          if (acc) render_pixel_wide(s, integ, *r, wf, x0 + xx, y0 + yy, acc, st);
+          else render_pixel(s, integ, *r, x0 + xx, y0 + yy, film + 4 * ((size_t)yy * W + xx), nullptr, st);
     }
   };
   std::vector<std::thread> th;
@@ -637,6 +722,23 @@ int orc_render(const orc_scene *sc, const orc_render_desc *r, float *film, orc_s
     out->seconds = std::chrono::duration<double>(t_end - t_start).count();
   }
   return 0;
+}
+
+int orc_render_acc(const orc_scene *sc, const orc_render_desc *r, int64_t *acc, orc_stats *out, int n_threads) {
+  return render_any(sc, r, nullptr, acc, out, n_threads);
+}
+void orc_film_from_acc(const int64_t *acc, int64_t n_px, float *film) {
+  for (int64_t i = 0; i < n_px; i++) film_from_acc(acc + 4 * i, film + 4 * i);
+}
+int orc_render(const orc_scene *sc, const orc_render_desc *r, float *film, orc_stats *out, int n_threads) {
+  if (is_default_filter(*r)) return render_any(sc, r, film, nullptr, out, n_threads);
+  // another radius: this rank's samples into accumulators, then converted (ranks combine by adding ACCUMULATORS)
+  const Scene &s = sc->s;
+  const int64_t n_px = (int64_t)std::max(0, s.cropped[2] - s.cropped[0]) * (int64_t)std::max(0, s.cropped[3] - s.cropped[1]);
+  std::vector<int64_t> acc((size_t)(4 * n_px), 0);
+  const int rc = render_any(sc, r, nullptr, acc.data(), out, n_threads);
+  if (rc == 0) orc_film_from_acc(acc.data(), n_px, film);
+  return rc;
 }
 
 }  // extern "C"

@@ -71,6 +71,8 @@ typedef struct {
   uint32_t rank, world_size; /* which 64x64 super-tiles to render (t % world == rank) */
   uint32_t flags;
   uint32_t sampler;    /* 0 = stratified, 1 = padded (0,2)-sequence "sobol" (3.10) */
+  float filter_xwidth, filter_ywidth; /* box filter radii (box.rs:57-61); 0 = the default 0.5.  Other radii: DESIGN.md 3.11 */
+  float max_sample_luminance;         /* Film "maxsampleluminance" (film.rs:75,279); 0 = infinity */
 } orc_render_desc;
 
 typedef struct {
@@ -129,6 +131,12 @@ void orc_pixel_samples(const orc_scene *s, const orc_render_desc *r, int x, int 
 /* film_xyzw: row-major over the cropped pixel bounds, 4 floats/pixel {X,Y,Z,weight};
  * pixels of super-tiles owned by other ranks are left untouched. */
 int orc_render(const orc_scene *s, const orc_render_desc *r, float *film_xyzw, orc_stats *st, int n_threads);
+/* Box filter radii other than 0.5: the film is accumulated in 64-bit fixed point (2^-24 units), four
+ * int64 per pixel of the cropped window {r, g, b, samples}; integer sums do not depend on the order of addition, so the
+ * accumulators of several ranks ADD to the single-rank ones exactly.  orc_render_acc ADDS this rank's samples into `acc`
+ * (zero it first); orc_film_from_acc converts accumulators into film pixels {X, Y, Z, weight}. */
+int orc_render_acc(const orc_scene *s, const orc_render_desc *r, int64_t *acc, orc_stats *st, int n_threads);
+void orc_film_from_acc(const int64_t *acc, int64_t n_px, float *film_xyzw);
 
 /* ---- the production walk of the render kernel (pbrt_amd/csrc/kernels.hip, quantised 4-wide nodes of DESIGN.md section
  * 4) restated one ray at a time (quad_walk.cpp): checks the trees the product's builders emit without a GPU, and counts

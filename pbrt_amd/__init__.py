@@ -7,6 +7,7 @@ call that computes needs lib/libpbrt_hip.so (built by `__graft_entry__.build()`)
 """
 from .api import (FLAG_COUNTERS, INTEGRATOR_DIRECT, INTEGRATOR_PATH, LIGHT_DISTANT, LIGHT_INFINITE, LIGHT_POINT, MATTE,
                   MIRROR, MultiScene, Scene, SceneData, render_multi, bvh_build_host, device_count, film_cropped_bounds, film_sample_bounds,
-                  film_tile_bounds, film_to_rgb, look_at, quad_build_host, read_image, slab_pixel_index, write_image)
+                  film_from_acc, film_tile_bounds, film_to_rgb, look_at, quad_build_host, quad_build_host_ex, read_image, slab_pixel_index,
+                  write_image)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

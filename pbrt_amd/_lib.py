@@ -33,7 +33,7 @@ class RenderDesc(C.Structure):
     _fields_ = [
         ("integrator", C.c_uint32), ("max_depth", C.c_uint32), ("spp_x", C.c_uint32), ("spp_y", C.c_uint32),
         ("seed", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32), ("flags", C.c_uint32),
-        ("sampler", C.c_uint32), ("filter_xwidth", C.c_float), ("filter_ywidth", C.c_float),
+        ("sampler", C.c_uint32), ("filter_xwidth", C.c_float), ("filter_ywidth", C.c_float), ("max_sample_luminance", C.c_float),
     ]
 
 
@@ -68,6 +68,10 @@ SYMBOLS = {
     "pbrt_hip_render_device": (C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp]),
     "pbrt_hip_render_wait": (C.c_int, [_vp, C.POINTER(Stats)]),
     "pbrt_hip_film_assemble_device": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "pbrt_hip_render_buffer_bytes": (_i64, [_vp, C.POINTER(RenderDesc)]),
+    "pbrt_hip_render_acc": (C.c_int, [_vp, C.POINTER(RenderDesc), _pi64, C.POINTER(Stats)]),
+    "pbrt_hip_film_from_acc_device": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pbrt_hip_film_from_acc": (None, [_pi64, _i64, _pf]),
     "pbrt_hip_slab_floats": (_i64, [_i32, _i32, _pf, _u32, _u32]),
     "pbrt_hip_slab_pixel_index": (C.c_int, [_i32, _i32, _pf, _u32, _u32, _pi64]),
     "pbrt_hip_multi_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, _u32, C.POINTER(_vp)]),

@@ -101,10 +101,12 @@ SAMPLERS = {"stratified": 0, "sobol": 1}
 
 
 def make_render_desc(desc_t, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
-                     flags=0, sampler="stratified", filter_width=(0.0, 0.0)):
+                     flags=0, sampler="stratified", filter_width=(0.0, 0.0), max_sample_luminance=0.0):
     r = desc_t()
     r.sampler = SAMPLERS[sampler] if isinstance(sampler, str) else int(sampler)
+    filter_width = filter_width or (0.0, 0.0)
     r.filter_xwidth, r.filter_ywidth = float(filter_width[0]), float(filter_width[1])
+    r.max_sample_luminance = float(max_sample_luminance)
     r.integrator = integrator
     r.max_depth = max_depth
     r.spp_x, r.spp_y = int(spp[0]), int(spp[1])
@@ -215,6 +217,14 @@ def quad_build_host_ex(P, idx, tree="default", split_leaves=True):
           "pbrt_hip_quad_build_host_ex")
     return {"quads": quads[:nq.value].copy(), "stack_need": need.value, "order": order[:nt].copy(), "root_box": box, "n_refs": nrefs.value,
             "exact_boxes": exact[:nq.value].copy()}
+
+
+def film_from_acc(acc):
+    """pbrt_hip_film_from_acc: (..., 4) int64 accumulators -> (..., 4) float32 film pixels {X, Y, Z, weight}."""
+    a = np.ascontiguousarray(acc, np.int64)
+    film = np.zeros(a.shape[:-1] + (4,), np.float32)
+    lib().pbrt_hip_film_from_acc(a.ctypes.data_as(C.POINTER(C.c_int64)), a.size // 4, _fp(film))
+    return film
 
 
 def slab_pixel_index(xres, yres, crop, rank, world_size):
@@ -362,6 +372,26 @@ class Scene:
         st = Stats()
         check(lib().pbrt_hip_render(self._h, C.byref(r), _fp(film), C.byref(st)), "pbrt_hip_render")
         return film, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def render_acc(self, filter_width, **kw):
+        """A box filter radius other than 0.5: this rank's fixed-point film accumulators (h, w, 4) int64 {r, g, b, samples}
+        (pbrt_hip_render_acc); accumulators of ranks add exactly, film_from_acc converts.  kw as render."""
+        r = make_render_desc(RenderDesc, filter_width=filter_width, **kw)
+        w, h = self.sd.crop_size()
+        acc = np.zeros((h, w, 4), np.int64)
+        st = Stats()
+        check(lib().pbrt_hip_render_acc(self._h, C.byref(r), acc.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(st)), "pbrt_hip_render_acc")
+        return acc, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def render_buffer_bytes(self, **kw):
+        """bytes render_device writes for this render description (slab of the rank, or the accumulators of a wide filter)"""
+        kw.pop("counters", None)
+        r = make_render_desc(RenderDesc, **kw)
+        return lib().pbrt_hip_render_buffer_bytes(self._h, C.byref(r))
+
+    def film_from_acc_device(self, d_acc_ptr, d_film_ptr, stream_ptr=None):
+        check(lib().pbrt_hip_film_from_acc_device(self._h, C.c_void_p(d_acc_ptr), C.c_void_p(d_film_ptr), C.c_void_p(stream_ptr or 0)),
+              "pbrt_hip_film_from_acc_device")
 
     def render_device(self, d_slab_ptr, stream_ptr=None, **kw):
         """Asynchronous render into a device slab (e.g. a torch tensor's data_ptr())."""

@@ -46,9 +46,8 @@ struct Shard {
   int32_t w, h;
   uint32_t stx, sty, total, n_local;
 };
-Shard make_shard(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world) {
-  int32_t b[4];
-  film_cropped_bounds(xres, yres, crop, b);
+// the super-tiles of a rank over the pixel rectangle b (x0 y0 x1 y1): the cropped window, or the sample bounds of a wide filter
+Shard make_shard_bounds(const int32_t b[4], uint32_t rank, uint32_t world) {
   Shard s;
   s.w = b[2] - b[0];
   s.h = b[3] - b[1];
@@ -59,6 +58,41 @@ Shard make_shard(int32_t xres, int32_t yres, const float crop[4], uint32_t rank,
   s.total = s.stx * s.sty;
   s.n_local = (world && rank < world && s.total > rank) ? (s.total - rank + world - 1) / world : 0;
   return s;
+}
+Shard make_shard(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world) {
+  int32_t b[4];
+  film_cropped_bounds(xres, yres, crop, b);
+  return make_shard_bounds(b, rank, world);
+}
+
+// Film geometry of one render: the cropped window (film.rs:92-101), the sample bounds (film.rs:166-175) and whether the
+// box filter has the default radius 0.5 -- then a sample lands in its own pixel and the two rectangles coincide -- or
+// another one (samples reach pad = ceil(radius - 0.5) pixels beyond the window, fixed-point film).
+struct FilmGeom {
+  bool wide;
+  float rx, ry;
+  int32_t pad_x, pad_y;
+  int32_t crop[4], sb[4];
+  size_t crop_px() const { return (size_t)std::max(0, crop[2] - crop[0]) * (size_t)std::max(0, crop[3] - crop[1]); }
+};
+inline float filter_radius(float w) { return w == 0.f ? 0.5f : w; }
+FilmGeom film_geom(const pbrt_hip_scene_desc &d, const pbrt_hip_render_desc &r) {
+  FilmGeom g;
+  g.rx = filter_radius(r.filter_xwidth);
+  g.ry = filter_radius(r.filter_ywidth);
+  g.wide = g.rx != 0.5f || g.ry != 0.5f;
+  film_cropped_bounds(d.xres, d.yres, d.crop, g.crop);
+  g.pad_x = g.pad_y = 0;
+  for (int k = 0; k < 4; k++) g.sb[k] = g.crop[k];
+  if (g.wide) {
+    g.sb[0] = (int32_t)std::floor(((float)g.crop[0] + 0.5f) - g.rx);
+    g.sb[1] = (int32_t)std::floor(((float)g.crop[1] + 0.5f) - g.ry);
+    g.sb[2] = (int32_t)std::ceil(((float)g.crop[2] - 0.5f) + g.rx);
+    g.sb[3] = (int32_t)std::ceil(((float)g.crop[3] - 0.5f) + g.ry);
+    g.pad_x = std::max(0, (int32_t)std::ceil(g.rx - 0.5f));
+    g.pad_y = std::max(0, (int32_t)std::ceil(g.ry - 0.5f));
+  }
+  return g;
 }
 
 // Scheduling thresholds of the traversal loop (kernels.hip trav_run).  They change only how lanes
@@ -846,9 +880,13 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if ((uint64_t)r->spp_x * (uint64_t)r->spp_y > PBRT_HIP_MAX_SPP)
     return fail(PBRT_HIP_ERR_LIMIT, "render: more than 2^20 samples per pixel");
   if (r->max_depth > PBRT_HIP_MAX_DEPTH) return fail(PBRT_HIP_ERR_LIMIT, "render: maxdepth above 1023");
-  // box filter, box.rs:57-61: only the default radius (a sample lands in its own pixel; film.rs:264-273's tile overlap is 0)
-  const float fx = r->filter_xwidth == 0.f ? 0.5f : r->filter_xwidth, fy = r->filter_ywidth == 0.f ? 0.5f : r->filter_ywidth;
-  if (fx != 0.5f || fy != 0.5f) return fail(PBRT_HIP_ERR_LIMIT, "render: only the box filter of radius 0.5 is implemented");
+  // box filter radii, box.rs:57-61 (0 = the default 0.5): any positive radius up to 16 pixels
+  const float fx = filter_radius(r->filter_xwidth), fy = filter_radius(r->filter_ywidth);
+  if (!(fx > 0.f) || !(fy > 0.f) || !std::isfinite(fx) || !std::isfinite(fy)) return fail(PBRT_HIP_ERR_INVALID, "render: the filter radii must be positive");
+  if (fx > 16.f || fy > 16.f) return fail(PBRT_HIP_ERR_LIMIT, "render: filter radius above 16 pixels");
+  if ((fx != 0.5f || fy != 0.5f) && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
+    return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags need the default box filter (radius 0.5)");
+  if (!(r->max_sample_luminance >= 0.f)) return fail(PBRT_HIP_ERR_INVALID, "render: max_sample_luminance must be >= 0 (0 = none)");
   return PBRT_HIP_OK;
 }
 
@@ -860,9 +898,16 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     if (s->pending) return fail(PBRT_HIP_ERR_INVALID, "render_device: a render of this scene is still in flight (call pbrt_hip_render_wait first)");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t st = (hipStream_t)stream;
-    const Shard sh = make_shard(s->desc.xres, s->desc.yres, s->desc.crop, r->rank, r->world_size);
-    if (sh.n_local && !d_slab) return fail(PBRT_HIP_ERR_INVALID, "render_device: null slab");
+    const FilmGeom fg = film_geom(s->desc, *r);
+    const Shard sh = make_shard_bounds(fg.sb, r->rank, r->world_size);
+    if ((sh.n_local || (fg.wide && fg.crop_px())) && !d_slab) return fail(PBRT_HIP_ERR_INVALID, "render_device: null slab");
     RenderParams R;
+    R.sx0 = fg.sb[0]; R.sy0 = fg.sb[1]; R.sw = sh.w; R.sh = sh.h;
+    R.seq_x0 = fg.sb[0] + fg.pad_x; R.seq_y0 = fg.sb[1] + fg.pad_y;
+    R.seq_w = (uint32_t)(s->desc.xres + 2 * fg.pad_x); R.seq_h = (uint32_t)(s->desc.yres + 2 * fg.pad_y);
+    R.max_lum = r->max_sample_luminance > 0.f ? r->max_sample_luminance : std::numeric_limits<float>::infinity();
+    R.filter_rx = fg.rx; R.filter_ry = fg.ry;
+    R.acc = fg.wide ? (unsigned long long *)d_slab : nullptr;
     R.integrator = r->integrator;
     R.max_depth = r->max_depth;
     R.spp_x = r->spp_x;
@@ -902,7 +947,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
       if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
       R.lane_state = s->d_lane_state.p;
     }
-    {
+    R.partials = nullptr;
+    if (!fg.wide) {
       const size_t need = (size_t)sh.n_local * 4096u * n_chunks;  // one float4 per item
       if (s->d_partials.n < need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
       R.partials = s->d_partials.p;
@@ -921,10 +967,12 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     if (counters == 1 && s->gpu_built)
       return fail(PBRT_HIP_ERR_INVALID, "render: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 80 * sizeof(unsigned long long), st));
+    if (fg.wide && fg.crop_px()) HIP_TRY(hipMemsetAsync(d_slab, 0, fg.crop_px() * 32, st));  // this rank's accumulators start at zero
     HIP_TRY(hipEventRecord(s->ev0, st));
-    // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order
-    HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, st));
-    HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
+    // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order (a wide
+    // filter has no partial sums: its samples go straight into the accumulators)
+    HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, st));
+    if (!fg.wide) HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
     s->pending_counters = counters != 0;
@@ -982,15 +1030,17 @@ int pbrt_hip_render(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, float *fil
   if (rc) return rc;
   if (!film) return fail(PBRT_HIP_ERR_INVALID, "render: null film");
   HIP_TRY(hipSetDevice(s->device));
-  const Shard sh = make_shard(s->desc.xres, s->desc.yres, s->desc.crop, r->rank, r->world_size);
-  const size_t n_px = (size_t)sh.w * (size_t)sh.h;
-  const size_t slab_n = (size_t)sh.n_local * 4096;
+  const FilmGeom fg = film_geom(s->desc, *r);
+  const Shard sh = make_shard_bounds(fg.sb, r->rank, r->world_size);
+  const size_t n_px = fg.crop_px();
+  const size_t slab_n = fg.wide ? 2 * n_px : (size_t)sh.n_local * 4096;  // (wide: four int64 accumulators per pixel = two float4)
   if (s->d_slab.n < slab_n) { s->d_slab.release(); HIP_TRY(s->d_slab.alloc(slab_n)); }
   if (s->d_film.n < n_px) { s->d_film.release(); HIP_TRY(s->d_film.alloc(n_px)); }
   if (n_px) HIP_TRY(hipMemsetAsync(s->d_film.p, 0, n_px * 16, s->stream));
   rc = pbrt_hip_render_device(s, r, s->d_slab.p, s->stream);
   if (rc) return rc;
-  rc = pbrt_hip_film_assemble_device(s, s->d_slab.p, r->rank, r->world_size, s->d_film.p, s->stream);
+  if (fg.wide) rc = pbrt_hip_film_from_acc_device(s, s->d_slab.p, s->d_film.p, s->stream);
+  else rc = pbrt_hip_film_assemble_device(s, s->d_slab.p, r->rank, r->world_size, s->d_film.p, s->stream);
   hipError_t e = hipSuccess;
   if (!rc && n_px) e = hipMemcpyAsync(film, s->d_film.p, n_px * 16, hipMemcpyDeviceToHost, s->stream);
   const hipError_t e2 = hipStreamSynchronize(s->stream);  // (also on failure: the scene must not stay "in flight")
@@ -1000,6 +1050,56 @@ int pbrt_hip_render(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, float *fil
     return fail(PBRT_HIP_ERR_HIP, std::string("render: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   }
   return pbrt_hip_render_wait(s, stats);
+}
+
+int64_t pbrt_hip_render_buffer_bytes(const pbrt_hip_scene *s, const pbrt_hip_render_desc *r) {
+  if (!s || !r || r->world_size == 0 || r->rank >= r->world_size) return -1;
+  const FilmGeom fg = film_geom(s->desc, *r);
+  if (fg.wide) return (int64_t)fg.crop_px() * 32;
+  return (int64_t)make_shard_bounds(fg.sb, r->rank, r->world_size).n_local * 4096 * 16;
+}
+
+int pbrt_hip_film_from_acc_device(const pbrt_hip_scene *s, const void *d_acc, void *d_film, void *stream) {
+  if (!s || !d_film) return fail(PBRT_HIP_ERR_INVALID, "film_from_acc: null argument");
+  int32_t b[4];
+  film_cropped_bounds(s->desc.xres, s->desc.yres, s->desc.crop, b);
+  const size_t n_px = (size_t)std::max(0, b[2] - b[0]) * (size_t)std::max(0, b[3] - b[1]);
+  if (n_px && !d_acc) return fail(PBRT_HIP_ERR_INVALID, "film_from_acc: null accumulators");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(launch_film_from_acc((const unsigned long long *)d_acc, (float4 *)d_film, n_px, (hipStream_t)stream));
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_render_acc(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, int64_t *acc, pbrt_hip_stats *stats) {
+  int rc = check_render_desc(s, r);
+  if (rc) return rc;
+  const FilmGeom fg = film_geom(s->desc, *r);
+  if (!fg.wide) return fail(PBRT_HIP_ERR_INVALID, "render_acc: the default box filter has no accumulators (use pbrt_hip_render)");
+  const size_t n_px = fg.crop_px();
+  if (n_px && !acc) return fail(PBRT_HIP_ERR_INVALID, "render_acc: null output");
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->d_slab.n < 2 * n_px) { s->d_slab.release(); HIP_TRY(s->d_slab.alloc(2 * n_px)); }
+  rc = pbrt_hip_render_device(s, r, s->d_slab.p, s->stream);
+  if (rc) return rc;
+  hipError_t e = n_px ? hipMemcpyAsync(acc, s->d_slab.p, n_px * 32, hipMemcpyDeviceToHost, s->stream) : hipSuccess;
+  const hipError_t e2 = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess || e2 != hipSuccess) {
+    s->pending = false;
+    return fail(PBRT_HIP_ERR_HIP, std::string("render_acc: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  }
+  return pbrt_hip_render_wait(s, stats);
+}
+
+// host restatement of film_from_acc_kernel (kernels.hip), for hosts that add the accumulators of several ranks themselves
+void pbrt_hip_film_from_acc(const int64_t *acc, int64_t n_px, float *film) {
+  const float inv = 1.0f / kFixedOne;
+  for (int64_t i = 0; i < n_px; i++) {
+    const float r = (float)acc[4 * i] * inv, g = (float)acc[4 * i + 1] * inv, b = (float)acc[4 * i + 2] * inv;
+    film[4 * i] = 0.412453f * r + 0.357580f * g + 0.180423f * b;
+    film[4 * i + 1] = 0.212671f * r + 0.715160f * g + 0.072169f * b;
+    film[4 * i + 2] = 0.019334f * r + 0.119193f * g + 0.950227f * b;
+    film[4 * i + 3] = (float)acc[4 * i + 3];
+  }
 }
 
 int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world) {
@@ -1265,6 +1365,7 @@ int pbrt_hip_loaded_get(const pbrt_hip_loaded *l, pbrt_hip_scene_desc *d, pbrt_h
     r->seed = 0; r->rank = 0; r->world_size = 1;
     r->sampler = s.sampler;
     r->filter_xwidth = s.filter_radius[0]; r->filter_ywidth = s.filter_radius[1];
+    r->max_sample_luminance = s.max_sample_luminance;
   }
   copy_out(s.filename, filename, cap);
   return PBRT_HIP_OK;

@@ -141,7 +141,19 @@ struct RenderParams {
   uint32_t sampler;       // PBRT_HIP_SAMPLER_*
   uint32_t spp_mask;      // Sobol sampler: 2^ceil(log2(spp)) - 1
   uint32_t stx_recip, spp_x_recip;  // ceil(2^32 / super-tiles per row), ceil(2^32 / spp_x): the kernel's divisions by these two
+  // The pixels that are SAMPLED (Film::get_sample_bounds, film.rs:166-175): the cropped window for the default box filter,
+  // `pad` = ceil(radius - 0.5) pixels more on every side for a wider one.  The 64x64 super-tiles cover them.
+  int32_t sx0, sy0, sw, sh;  // origin and size of the sample bounds
+  int32_t seq_x0, seq_y0;    // sx0 + pad_x, sy0 + pad_y: a sampled pixel's coordinates in the numbering of the RNG streams ...
+  uint32_t seq_w, seq_h;     // ... whose rows are xres + 2 pad_x long (yres + 2 pad_y of them): the image plus its halo
+  float max_lum;             // Film "maxsampleluminance" (film.rs:75,279; pbrt-v3 FilmTile::AddSample); +inf = none
+  // box filter radii other than 0.5 (render_kernel<..., WIDE>): fixed-point film accumulators, int64 {r, g, b, samples} per
+  // pixel of the cropped window, added to with atomics
+  float filter_rx, filter_ry;
+  unsigned long long *acc;
 };
+// 2^24 fixed-point units per unit of radiance, a component clamped to [0, 2^15]
+constexpr float kFixedOne = 16777216.0f, kFixedMax = 32768.0f;
 
 struct RayBatch {
   const float *o, *d, *tmax;  // 3n, 3n, n
@@ -158,7 +170,9 @@ struct RayBatch {
 
 // launchers (kernels.hip)
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         int counters /* 0 none, 1 exact walk, 2 production walk */, hipStream_t stream);
+                         int counters /* 0 none, 1 exact walk, 2 production walk */, bool wide_filter, hipStream_t stream);
+// fixed-point accumulators -> film pixels {X, Y, Z, weight}
+hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, size_t n_px, hipStream_t stream);
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);

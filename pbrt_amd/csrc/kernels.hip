@@ -526,6 +526,17 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
          (uint32_t)__popcll(mleaf) * 2u >= (uint32_t)__popcll(__ballot(T.cur != kDone && !parked)))) {
       const uint32_t cnt = parked ? (T.cur >> 24) & 0x7fu : 0u, first = T.cur & 0xffffffu;
       bool stop = false;  // any-hit ray found its hit
+#ifdef PBRT_PREFETCH_POP
+      // Experiment: a parked lane's NEXT node is already known -- the entry below its stack top -- so one dword of it is
+      // requested beside the triangle fetch: when the lane pops, the node's line is in L1 / L2 instead of a serial
+      // ~700-cycle fetch after the leaf pass.  (Kept live until after the pass so that the load's register is not reused
+      // under it; entries beyond the LDS part of an overflow stack are not followed.)
+      uint32_t pf = 0u;
+      if (parked) {
+        const uint32_t top = lds_load(T.sp - kRowBytes);
+        if (!(top & kLeafRef)) pf = *reinterpret_cast<const uint32_t *>(quads + top);
+      }
+#endif
 #ifdef PBRT_PHASE_PROBE
       {  // flushes, and the passes they would take if the (lane, triangle) items were spread over all 64 lanes
         uint32_t items = 0;
@@ -572,6 +583,9 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           T.h.b2 = closer ? v : T.h.b2;
         }
       }
+#ifdef PBRT_PREFETCH_POP
+      asm volatile("" ::"v"(pf));
+#endif
       // (OVF: is any entry about to be popped one of the rare ones beyond the LDS part?  wave-uniform, as for the pushes)
       const bool far_pop = OVFR != 0u && !EXACT &&
                            __ballot(parked && !stop && T.sp >= lds_addr(stk - (threadIdx.x & 63u)) + OVFR * kRowBytes) != 0ull;
@@ -773,10 +787,12 @@ __device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const
 // One workgroup = one wavefront = one 8x8 pixel tile; 64 workgroups per 64x64 super-tile.
 // STACK: LDS entries of the exact walk; for the production walk the LDS rows of the overflow variant (deeper entries
 // in the HBM overflow area), or 0 = the whole stack in LDS.
-template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK>
+// WIDE: a box filter radius other than 0.5: a sample is added to every pixel within the radius, into
+// fixed-point accumulators with atomics, instead of to its chunk's partial sum.
+template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK, bool WIDE = false>
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
-__global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
+__global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
   // the walk's stack, rows of 64 lanes x 4 bytes as dynamic shared memory: the launch sizes it per scene (render_stack_plan;
   // exact walk: STACK rows of refs followed by STACK rows of entry distances)
   extern __shared__ uint32_t lds_stack[];
@@ -790,9 +806,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
   // pixels at chunk 0, then at chunk 1, ... so a wave that draws 64 consecutive items holds one 8x8 block at one
   // chunk.  Pixel number q = block * 64 + pixel is pixel (q & 63) of 8x8 block ((q >> 6) & 63) of local super-tile
   // (q >> 12), both row-major.
-  const int32_t W = S.cx1 - S.cx0, H = S.cy1 - S.cy0;
+  const int32_t W = R.sw, H = R.sh;  // the sampled pixels: the cropped window, plus the halo of a wide filter
   const uint32_t stx = (uint32_t)(W + 63) >> 6;
-  const uint64_t seq0 = R.seed * (uint64_t)S.xres * (uint64_t)S.yres;
+  const uint64_t seq0 = R.seed * (uint64_t)R.seq_w * (uint64_t)R.seq_h;
   uint32_t item = 0;
   // tsup / stx by R.stx_recip = ceil(2^32 / stx): exact for tsup * stx < 2^32 (checked by the host); the compiler's own
   // division by a run-time value keeps a float reciprocal in a VGPR for the whole kernel
@@ -844,14 +860,14 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     if (serve && state != ST_FETCH) {
       path_load(rec, P);
       pixel_xy(item_pixel(item), xr, yr);
-      P.rng.inc = ((((seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr)) << kb) + ((item >> 6) & chunk_mask)) << 1) | 1u;
+      P.rng.inc = ((((seq0 + (uint64_t)(R.seq_y0 + yr) * (uint64_t)R.seq_w + (uint64_t)(R.seq_x0 + xr)) << kb) + ((item >> 6) & chunk_mask)) << 1) | 1u;
       PROBE_SEC(1);
       if (state != ST_NEW) {
         if (SPH) trav_spheres(S, T);
         bool advance = false;  // take the prepared bounce (or end the sample)
         if (state == ST_SHADOW) {
 #ifdef PBRT_DEBUG_PIXEL_X
-          if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+          if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
             printf("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(rec_load(rec, kRecLpend).x), T.any >> 1, T.tmax);
 #endif
           if (T.any != 3u) {  // unoccluded: the light sample counts
@@ -863,7 +879,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
           const HitRec h = T.h;
           const bool hit = h.prim != kNoPrim;
 #ifdef PBRT_DEBUG_PIXEL_X
-          if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+          if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
           {
             printf("HIP s %u bounce %u prim %u t %08x b1 %a b2 %a L %08x beta %08x\n", P.s, P.bounces, h.prim, __float_as_uint(h.t), h.b1, h.b2,
                    __float_as_uint(P.L.x), __float_as_uint(P.beta.x));
@@ -934,7 +950,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
                 sample_2d(P, sobol, spp_mask, u1, u2);
                 const float z = cosine_about(nf, u1, u2, P.wi_next);
 #ifdef PBRT_DEBUG_PIXEL_X
-                if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+                if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
                   printf("HIP s %u   cos u1 %a u2 %a z %a nf %a %a %a wi %a %a %a\n", P.s, u1, u2, z, nf.x, nf.y, nf.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
 #endif
                 if (z == 0.f) alive = false;
@@ -985,10 +1001,33 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
             // radiance sanitising of SamplerIntegrator::Render, then FilmTile::AddSample (box filter)
             const float y = (0.212671f * P.L.x + 0.715160f * P.L.y) + 0.072169f * P.L.z;
             if (isnan(P.L.x) || isnan(P.L.y) || isnan(P.L.z) || y < -1e-5f || isinf(y)) P.L = {0.f, 0.f, 0.f};
+            else if (y > R.max_lum) P.L = P.L * (R.max_lum / y);  // Film "maxsampleluminance" (film.rs:75,279); +inf = none
 #ifdef PBRT_DEBUG_PIXEL_X  // parity debugging: per-sample radiance of one pixel, to diff against oracle pixel_samples()
-            if (S.cx0 + xr == PBRT_DEBUG_PIXEL_X && S.cy0 + yr == PBRT_DEBUG_PIXEL_Y)
+            if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
               printf("SAMPLE %u %08x %08x %08x\n", P.s, __float_as_uint(P.L.x), __float_as_uint(P.L.y), __float_as_uint(P.L.z));
 #endif
+            if (WIDE) {
+              // FilmTile::AddSample for a box filter of any radius: weight 1 to every pixel of the cropped
+              // window within the radius of the sample's film point (kept in the record the default path has its partial
+              // sum in), as 2^-24 fixed point: integer atomics make the sums independent of the order of arrival
+              const float4 fp = rec_load(rec, kRecSum);
+              const float dx = fp.x - 0.5f, dy = fp.y - 0.5f;
+              int32_t x0 = (int32_t)ceilf(dx - R.filter_rx), x1 = (int32_t)floorf(dx + R.filter_rx) + 1;
+              int32_t y0 = (int32_t)ceilf(dy - R.filter_ry), y1 = (int32_t)floorf(dy + R.filter_ry) + 1;
+              x0 = max(x0, S.cx0); x1 = min(x1, S.cx1);
+              y0 = max(y0, S.cy0); y1 = min(y1, S.cy1);
+              const unsigned long long qr = (unsigned long long)(long long)(fminf(fmaxf(P.L.x, 0.f), kFixedMax) * kFixedOne);
+              const unsigned long long qg = (unsigned long long)(long long)(fminf(fmaxf(P.L.y, 0.f), kFixedMax) * kFixedOne);
+              const unsigned long long qb = (unsigned long long)(long long)(fminf(fmaxf(P.L.z, 0.f), kFixedMax) * kFixedOne);
+              for (int32_t py = y0; py < y1; py++)
+                for (int32_t px = x0; px < x1; px++) {
+                  unsigned long long *a = R.acc + 4u * ((size_t)(py - S.cy0) * (size_t)(S.cx1 - S.cx0) + (size_t)(px - S.cx0));
+                  atomicAdd(a, qr); atomicAdd(a + 1, qg); atomicAdd(a + 2, qb); atomicAdd(a + 3, 1ull);
+                }
+              P.s++;
+              if (sobol) P.rng.state &= 0xffffffffull;
+              state = P.s == chunk_begin(((item >> 6) & chunk_mask) + 1u, spp, kb) ? ST_FETCH : ST_NEW;
+            } else {
             // FilmTile::AddSample with the box filter: this pixel, weight 1.  The chunk's partial sum lives in its record.
             const float4 sm = rec_load(rec, kRecSum);
             const V3 sum = mk(sm.x, sm.y, sm.z) + P.L;
@@ -1002,6 +1041,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
             } else {
               rec_store(rec, kRecSum, make_float4(sum.x, sum.y, sum.z, 0.f));
               state = ST_NEW;
+            }
             }
           }
           P.cont = false;
@@ -1043,14 +1083,14 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
           if (xr < W && yr < H) {  // (pixels of a ragged super-tile outside the image are skipped)
             if (chunk_begin(chunk, spp, kb) == chunk_begin(chunk + 1u, spp, kb)) {
               // an empty chunk (fewer than 8 samples per pixel): its partial sum is zero; the lane draws again
-              R.partials[(slab_pos(q) << kb) + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (!WIDE) R.partials[(slab_pos(q) << kb) + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
               item = it;
-              rec_store(rec, kRecSum, make_float4(0.f, 0.f, 0.f, 0.f));
+              if (!WIDE) rec_store(rec, kRecSum, make_float4(0.f, 0.f, 0.f, 0.f));
               P.L = {0.f, 0.f, 0.f};
               P.beta = {1.f, 1.f, 1.f};
               P.wi_next = {0.f, 0.f, 0.f};
-              const uint64_t pixel_seq = seq0 + (uint64_t)(S.cy0 + yr) * (uint64_t)S.xres + (uint64_t)(S.cx0 + xr);
+              const uint64_t pixel_seq = seq0 + (uint64_t)(R.seq_y0 + yr) * (uint64_t)R.seq_w + (uint64_t)(R.seq_x0 + xr);
               if (sobol) P.rng.state = mix32((uint32_t)pixel_seq ^ mix32((uint32_t)(pixel_seq >> 32) + 0x9e3779b9u));
               else pcg_seq(P.rng, (pixel_seq << kb) + chunk);
               P.s = chunk_begin(chunk, spp, kb);
@@ -1079,7 +1119,8 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
             jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
             jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
           }
-          const float fx = (float)(S.cx0 + xr) + jx, fy = (float)(S.cy0 + yr) + jy;
+          const float fx = (float)(R.sx0 + xr) + jx, fy = (float)(R.sy0 + yr) + jy;
+          if (WIDE) rec_store(rec, kRecSum, make_float4(fx, fy, 0.f, 0.f));  // the film point, for the filter's footprint
           const V3 dc = unit(mk(fx * S.cam_ax + S.cam_bx, fy * S.cam_ay + S.cam_by, 1.0f));
           rd = {(S.c2w[0] * dc.x + S.c2w[1] * dc.y) + S.c2w[2] * dc.z,
                 (S.c2w[4] * dc.x + S.c2w[5] * dc.y) + S.c2w[6] * dc.z,
@@ -1256,7 +1297,40 @@ __global__ void merge_kernel(const float4 *partials, float4 *slab, int32_t w, in
   slab[i] = o;
 }
 
+// fixed-point accumulators {r, g, b, samples} -> Film pixel {XYZ of the radiance sum, weight} (film.rs:313-326)
+__global__ void film_from_acc_kernel(const unsigned long long *acc, float4 *film, size_t n_px) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_px) return;
+  const float inv = 1.0f / kFixedOne;
+  const V3 sum = {(float)(long long)acc[4 * i] * inv, (float)(long long)acc[4 * i + 1] * inv, (float)(long long)acc[4 * i + 2] * inv};
+  float4 o;
+  o.x = 0.412453f * sum.x + 0.357580f * sum.y + 0.180423f * sum.z;
+  o.y = 0.212671f * sum.x + 0.715160f * sum.y + 0.072169f * sum.z;
+  o.z = 0.019334f * sum.x + 0.119193f * sum.y + 0.950227f * sum.z;
+  o.w = (float)(long long)acc[4 * i + 3];
+  film[i] = o;
+}
+
 }  // namespace
+
+hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, size_t n_px, hipStream_t stream) {
+  if (n_px == 0) return hipSuccess;
+  hipLaunchKernelGGL(film_from_acc_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, acc, film, n_px);
+  return hipGetLastError();
+}
+
+// a box filter radius other than 0.5: the WIDE instantiations of the production walk (no counting variants)
+template <bool SPH>
+static hipError_t launch_render_wide(const DevScene &S, const RenderParams &R, hipStream_t st) {
+  const dim3 grid(R.n_workgroups), block(64);
+  const RenderStackPlan plan = render_stack_plan(S.quad_stack_need, render_force_overflow(), render_prefer_lds());
+  const uint32_t lds = plan.rows * 256u;
+  if (plan.overflow && plan.rows == kQuadLdsStackOvfDeep && kQuadLdsStackOvfDeep != kQuadLdsStackOvf)
+    hipLaunchKernelGGL((render_kernel<SPH, false, false, (int)kQuadLdsStackOvfDeep, PBRT_STEPS_PER_CHECK, true>), grid, block, lds, st, S, R);
+  else if (plan.overflow) hipLaunchKernelGGL((render_kernel<SPH, false, false, (int)kQuadLdsStackOvf, PBRT_STEPS_PER_CHECK, true>), grid, block, lds, st, S, R);
+  else hipLaunchKernelGGL((render_kernel<SPH, false, false, 0, PBRT_STEPS_PER_CHECK, true>), grid, block, lds, st, S, R);
+  return hipGetLastError();
+}
 
 template <bool SPH, bool COUNT, bool EXACT>
 static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t depth,
@@ -1287,9 +1361,10 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
 }
 
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         int counters, hipStream_t stream) {
+                         int counters, bool wide_filter, hipStream_t stream) {
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
+  if (wide_filter) return sph ? launch_render_wide<true>(S, R, stream) : launch_render_wide<false>(S, R, stream);
 #ifdef PBRT_RAY_LOG
   if (counters == 0) {
     const unsigned long long cap = 160ull << 20, zero = 0;

@@ -687,7 +687,11 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
         out->film_scale = ps.one_float("scale", 1.f);
         if (const ParamItem *c = ps.find("cropwindow", "float"))
           if (c->nums.size() == 4) for (int i = 0; i < 4; i++) out->crop[i] = (float)c->nums[i];
-        ps.find("diagonal", "float"); ps.find("maxsampleluminance", "float");
+        ps.find("diagonal", "float");
+        {
+          const float ml = ps.one_float("maxsampleluminance", 0.f);  // (pbrt-v3's default is infinity: 0 stands for it here)
+          out->max_sample_luminance = (ml > 0.f && std::isfinite(ml)) ? ml : 0.f;
+        }
         api.report_unused("Film", ps);
       }
     } else if (tok == "Identity") {
@@ -741,7 +745,7 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
         out->filter_name = name;
         if (name != "box") api.warn("PixelFilter \"" + name + "\": only the box filter of radius 0.5 is implemented (box.rs:57-61)");
         const float xw = ps.one_float("xwidth", 0.5f), yw = ps.one_float("ywidth", 0.5f);
-        out->filter_radius[0] = xw; out->filter_radius[1] = yw;  // handed to the render desc: a radius other than 0.5 is refused there (PBRT_HIP_ERR_LIMIT)
+        out->filter_radius[0] = xw; out->filter_radius[1] = yw;  // handed to the render desc (radii other than 0.5: DESIGN.md 3.11)
         if (xw != 0.5f || yw != 0.5f) api.warn("PixelFilter: a box radius other than 0.5 is not implemented; pbrt_hip_render refuses it");
       }
     } else if (tok == "ReverseOrientation") {
