@@ -3,20 +3,25 @@
 // (/root/reference/src/core/api.rs:432-473, reached from src/bin/pbrt.rs:72-83) needs to use 8 MI355X.
 //
 //   * the scene is built once and REPLICATED device to device (hipMemcpyPeerAsync: xGMI, not PCIe);
-//   * one host thread, one stream and one scene replica per GPU; GPU g renders the 64x64 super-tiles t with
-//     t % n == g -- no communication while rendering;
-//   * one RCCL gather (ncclGather, /opt/rocm/include/rccl/rccl.h:745; communicators from ncclCommInitAll, one process)
-//     brings the slabs to GPU 0 over its 7 xGMI links, where assemble_kernel scatters them into the film.
+//   * one stream and one scene replica per GPU, all driven from the calling thread: GPU g renders the 64x64 super-tiles
+//     t with t % n == g -- the n launches are asynchronous, nothing is exchanged while rendering;
+//   * one RCCL collective per frame, enqueued on the n streams behind the render kernels as ONE group call
+//     (ncclGroupStart / ncclGroupEnd: the single-process form, rccl.h:904-923): ncclGather of the slabs to GPU 0 over its 7
+//     xGMI links, where assemble_kernel scatters them into the film -- or, for a box filter radius other than 0.5
+//     (DESIGN.md 3.11), ncclReduce(sum, int64) of the fixed-point accumulators, which add exactly;
+//   * a launch that fails is known BEFORE the collective is enqueued, so no rank is ever left waiting in it; if the
+//     collective itself fails the communicators are aborted and the handle refuses further renders.
 //
-// RCCL is loaded with dlopen on first use: the single-GPU entry points of the library do not depend on it.
+// One GPU needs none of this: n == 1 renders through the single-GPU entry points, RCCL is not even loaded (dlopen on
+// first use with n > 1).  The caller's current HIP device is restored on every exit.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/pbrt_hip.h"
@@ -29,13 +34,19 @@ namespace {
 
 // the few RCCL entry points this file uses (signatures of rccl.h)
 typedef struct ncclComm *ncclComm_t;
-typedef int ncclResult_t;    // ncclSuccess == 0
-constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h ncclDataType_t)
+typedef int ncclResult_t;      // ncclSuccess == 0
+constexpr int kNcclInt64 = 4;  // rccl.h ncclDataType_t
+constexpr int kNcclFloat = 7;  // ncclFloat32
+constexpr int kNcclSum = 0;    // ncclRedOp_t
 struct Rccl {
   void *so = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Gather)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
 };
@@ -50,12 +61,24 @@ Rccl &rccl() {
     if (!r.so) { r.why = std::string("cannot load librccl: ") + dlerror(); return; }
     r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.so, "ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.so, "ncclCommAbort");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.so, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.so, "ncclGroupEnd");
     r.Gather = (decltype(r.Gather))dlsym(r.so, "ncclGather");
+    r.Reduce = (decltype(r.Reduce))dlsym(r.so, "ncclReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
-    if (!r.CommInitAll || !r.CommDestroy || !r.Gather || !r.GetErrorString) r.why = "librccl lacks ncclCommInitAll / ncclGather";
+    if (!r.CommInitAll || !r.CommDestroy || !r.CommAbort || !r.GroupStart || !r.GroupEnd || !r.Gather || !r.Reduce || !r.GetErrorString)
+      r.why = "librccl lacks ncclCommInitAll / ncclGroupStart / ncclGather / ncclReduce";
   });
   return r;
 }
+
+// restores the calling thread's current device on scope exit (a host such as torch must not find itself retargeted)
+struct DeviceRestore {
+  int dev = -1;
+  DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 
 size_t shard_pixels(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world) {
   const int64_t f = pbrt_hip_slab_floats(xres, yres, crop, rank, world);
@@ -68,16 +91,18 @@ struct pbrt_hip_multi {
   int n = 0;
   std::vector<pbrt_hip_scene *> scenes;  // [g] lives on device g; [0] is the one that was built, the others are copies
   std::vector<hipStream_t> streams;
-  std::vector<DevBuf<float4>> slabs;     // per device: room for the largest shard (rank 0's), the gather's common count
-  DevBuf<float4> gathered;               // device 0: n x max_slab
+  std::vector<DevBuf<float4>> slabs;     // per device: what pbrt_hip_render_device fills (slab, or the accumulators of a wide filter)
+  DevBuf<float4> gathered;               // device 0: n x max_slab (default filter) or the summed accumulators (wide filter)
   DevBuf<float4> film;                   // device 0: the assembled film
-  std::vector<ncclComm_t> comms;
+  std::vector<ncclComm_t> comms;         // n > 1 only
   size_t max_slab = 0, n_px = 0;
   int32_t w = 0, h = 0;
+  bool broken = false;                   // a collective failed and the communicators were aborted
 
   ~pbrt_hip_multi() {
+    DeviceRestore keep;
     for (int g = 0; g < (int)comms.size(); g++)
-      if (comms[g]) { (void)hipSetDevice(scenes[g] ? scenes[g]->device : g); (void)rccl().CommDestroy(comms[g]); }
+      if (comms[g]) { (void)hipSetDevice(scenes[g] ? scenes[g]->device : g); (void)(broken ? rccl().CommAbort(comms[g]) : rccl().CommDestroy(comms[g])); }
     for (int g = 0; g < (int)scenes.size(); g++) {
       if (!scenes[g]) continue;
       (void)hipSetDevice(scenes[g]->device);
@@ -136,6 +161,144 @@ int clone_scene(const pbrt_hip_scene *src, int device, pbrt_hip_scene **out) {
   return PBRT_HIP_OK;
 }
 
+int multi_create(const pbrt_hip_scene_desc *d, int n_gpus, uint32_t flags, pbrt_hip_multi **out) {
+  const int ndev = pbrt_hip_device_count();
+  if (ndev <= 0) return fail(PBRT_HIP_ERR_NO_DEVICE, "multi_create: no HIP device (there is no CPU fallback)");
+  if (d->xres <= 0 || d->yres <= 0) return fail(PBRT_HIP_ERR_INVALID, "multi_create: resolution must be positive");
+  int32_t b[4];
+  film_cropped_bounds(d->xres, d->yres, d->crop, b);
+  const int32_t w = b[2] > b[0] ? b[2] - b[0] : 0, h = b[3] > b[1] ? b[3] - b[1] : 0;
+  if (n_gpus <= 0) {
+    // all visible devices -- but no more than there are 64x64 super-tiles to deal out (a 64x64 film on eight GPUs would
+    // replicate the scene seven times for ranks that own nothing)
+    const int64_t tiles = (int64_t)((w + 63) / 64) * (int64_t)((h + 63) / 64);
+    n_gpus = (int)std::max<int64_t>(1, std::min<int64_t>(ndev, tiles));
+  }
+  if (n_gpus > ndev) return fail(PBRT_HIP_ERR_INVALID, "multi_create: " + std::to_string(n_gpus) + " GPUs asked for, " + std::to_string(ndev) + " visible");
+  if (n_gpus > 1) {  // (one GPU: no collective, RCCL is not needed and not loaded)
+    Rccl &rc = rccl();
+    if (!rc.why.empty()) return fail(PBRT_HIP_ERR_INTERNAL, "multi_create: " + rc.why);
+  }
+  std::unique_ptr<pbrt_hip_multi> m(new pbrt_hip_multi());
+  m->n = n_gpus;
+  m->scenes.assign(n_gpus, nullptr);
+  m->streams.assign(n_gpus, nullptr);
+  m->slabs.resize(n_gpus);
+  int rcode = pbrt_hip_scene_create_ex(d, 0, flags, &m->scenes[0]);
+  if (rcode) return rcode;
+  for (int g = 1; g < n_gpus; g++) {
+    rcode = clone_scene(m->scenes[0], g, &m->scenes[g]);
+    if (rcode) return rcode;
+  }
+  m->w = w;
+  m->h = h;
+  m->n_px = (size_t)w * (size_t)h;
+  m->max_slab = shard_pixels(d->xres, d->yres, d->crop, 0, (uint32_t)n_gpus);  // rank 0 owns the most super-tiles
+  for (int g = 0; g < n_gpus; g++) {
+    HIP_TRY(hipSetDevice(g));
+    HIP_TRY(hipStreamCreate(&m->streams[g]));
+  }
+  HIP_TRY(hipSetDevice(0));
+  HIP_TRY(m->film.alloc(m->n_px ? m->n_px : 1));
+  if (n_gpus > 1) {
+    std::vector<int> devs(n_gpus);
+    for (int g = 0; g < n_gpus; g++) devs[g] = g;
+    m->comms.assign(n_gpus, nullptr);
+    const ncclResult_t nr = rccl().CommInitAll(m->comms.data(), n_gpus, devs.data());
+    if (nr != 0) return fail(PBRT_HIP_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(nr));
+  }
+  *out = m.release();
+  return PBRT_HIP_OK;
+}
+
+// room for `count` float4 on every device (and n x count gathered on device 0 when `gather`)
+int ensure_buffers(pbrt_hip_multi *m, size_t count, bool gather) {
+  count = count ? count : 1;
+  for (int g = 0; g < m->n; g++) {
+    if (m->slabs[g].n >= count) continue;
+    HIP_TRY(hipSetDevice(g));
+    m->slabs[g].release();
+    HIP_TRY(m->slabs[g].alloc(count));
+    HIP_TRY(hipMemsetAsync(m->slabs[g].p, 0, count * sizeof(float4), m->streams[g]));  // (a rank without tiles sends zeros)
+  }
+  const size_t need = gather ? (size_t)m->n * count : count;
+  if (m->n > 1 && m->gathered.n < need) {
+    HIP_TRY(hipSetDevice(0));
+    m->gathered.release();
+    HIP_TRY(m->gathered.alloc(need));
+  }
+  return PBRT_HIP_OK;
+}
+
+int multi_render(pbrt_hip_multi *m, const pbrt_hip_render_desc *r, float *film, pbrt_hip_stats *per_gpu) {
+  if (m->broken) return fail(PBRT_HIP_ERR_INTERNAL, "multi_render: an earlier collective failed and the communicators were aborted; create a new handle");
+  const int n = m->n;
+  const float fx = r->filter_xwidth == 0.f ? 0.5f : r->filter_xwidth, fy = r->filter_ywidth == 0.f ? 0.5f : r->filter_ywidth;
+  const bool wide = fx != 0.5f || fy != 0.5f;  // accumulators of the whole window, summed instead of gathered
+  const size_t per_gpu_f4 = wide ? 2 * m->n_px : m->max_slab;
+  int code = ensure_buffers(m, per_gpu_f4, !wide);
+  if (code) return code;
+  // ---- every GPU's shard, asynchronously on its own stream ----
+  std::vector<bool> started(n, false);
+  std::string err;
+  for (int g = 0; g < n && !code; g++) {
+    pbrt_hip_render_desc rd = *r;
+    rd.rank = (uint32_t)g;
+    rd.world_size = (uint32_t)n;
+    code = pbrt_hip_render_device(m->scenes[g], &rd, m->slabs[g].p, m->streams[g]);
+    if (code) err = "GPU " + std::to_string(g) + ": " + pbrt_hip_last_error();
+    else started[g] = true;
+  }
+  auto drain = [&]() {  // leave no render "in flight" behind an error
+    for (int g = 0; g < n; g++)
+      if (started[g]) { (void)hipSetDevice(g); (void)hipStreamSynchronize(m->streams[g]); (void)pbrt_hip_render_wait(m->scenes[g], nullptr); }
+  };
+  if (code) { drain(); return fail(code, "multi_render: " + err); }  // (known before any collective is enqueued: nobody waits in one)
+  // ---- the frame's one exchange, then the film on GPU 0 ----
+  const float4 *result = m->slabs[0].p;  // n == 1: GPU 0's own slab / accumulators
+  if (n > 1) {
+    Rccl &rc = rccl();
+    ncclResult_t nr = rc.GroupStart();
+    for (int g = 0; g < n && nr == 0; g++) {
+      if (hipSetDevice(g) != hipSuccess) { nr = -1; break; }
+      nr = wide ? rc.Reduce(m->slabs[g].p, g == 0 ? m->gathered.p : nullptr, 4 * m->n_px, kNcclInt64, kNcclSum, 0, m->comms[g], m->streams[g])
+                : rc.Gather(m->slabs[g].p, g == 0 ? m->gathered.p : nullptr, 4 * (m->max_slab ? m->max_slab : 1), kNcclFloat, 0, m->comms[g], m->streams[g]);
+    }
+    const ncclResult_t ne = rc.GroupEnd();
+    if (nr == 0) nr = ne;
+    if (nr != 0) {
+      // some ranks may sit in a collective the others never joined: abort every communicator (that releases them)
+      for (int g = 0; g < n; g++) { (void)hipSetDevice(g); (void)rc.CommAbort(m->comms[g]); m->comms[g] = nullptr; }
+      m->broken = true;
+      drain();
+      return fail(PBRT_HIP_ERR_HIP, std::string("multi_render: RCCL ") + (wide ? "reduce: " : "gather: ") + (nr > 0 ? rc.GetErrorString(nr) : "hipSetDevice failed"));
+    }
+    result = m->gathered.p;
+  }
+  HIP_TRY(hipSetDevice(0));
+  if (wide) {
+    code = pbrt_hip_film_from_acc_device(m->scenes[0], result, m->film.p, m->streams[0]);
+  } else {
+    if (m->n_px) HIP_TRY(hipMemsetAsync(m->film.p, 0, m->n_px * sizeof(float4), m->streams[0]));
+    for (int s = 0; s < n && !code; s++)
+      code = pbrt_hip_film_assemble_device(m->scenes[0], result + (size_t)s * (m->max_slab ? m->max_slab : 1), (uint32_t)s, (uint32_t)n, m->film.p, m->streams[0]);
+  }
+  hipError_t e = hipSuccess;
+  if (!code && film && m->n_px) e = hipMemcpyAsync(film, m->film.p, m->n_px * sizeof(float4), hipMemcpyDeviceToHost, m->streams[0]);
+  std::vector<pbrt_hip_stats> stats(n);
+  for (int g = 0; g < n; g++) {
+    (void)hipSetDevice(g);
+    const hipError_t es = hipStreamSynchronize(m->streams[g]);
+    if (es != hipSuccess && e == hipSuccess) e = es;
+    const int c3 = pbrt_hip_render_wait(m->scenes[g], &stats[g]);
+    if (c3 && !code) { code = c3; err = "GPU " + std::to_string(g) + ": " + pbrt_hip_last_error(); }
+  }
+  if (code) return fail(code, "multi_render: " + (err.empty() ? std::string(pbrt_hip_last_error()) : err));
+  if (e != hipSuccess) return fail(PBRT_HIP_ERR_HIP, std::string("multi_render: ") + hipGetErrorString(e));
+  if (per_gpu) std::memcpy(per_gpu, stats.data(), (size_t)n * sizeof(pbrt_hip_stats));
+  return PBRT_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -144,46 +307,8 @@ int pbrt_hip_multi_create(const pbrt_hip_scene_desc *d, int n_gpus, uint32_t fla
   if (!d || !out) return fail(PBRT_HIP_ERR_INVALID, "multi_create: null argument");
   *out = nullptr;
   try {
-    const int ndev = pbrt_hip_device_count();
-    if (ndev <= 0) return fail(PBRT_HIP_ERR_NO_DEVICE, "multi_create: no HIP device (there is no CPU fallback)");
-    if (n_gpus <= 0) n_gpus = ndev;
-    if (n_gpus > ndev) return fail(PBRT_HIP_ERR_INVALID, "multi_create: " + std::to_string(n_gpus) + " GPUs asked for, " + std::to_string(ndev) + " visible");
-    Rccl &rc = rccl();
-    if (!rc.why.empty()) return fail(PBRT_HIP_ERR_INTERNAL, "multi_create: " + rc.why);
-    std::unique_ptr<pbrt_hip_multi> m(new pbrt_hip_multi());
-    m->n = n_gpus;
-    m->scenes.assign(n_gpus, nullptr);
-    m->streams.assign(n_gpus, nullptr);
-    m->slabs.resize(n_gpus);
-    int rcode = pbrt_hip_scene_create_ex(d, 0, flags, &m->scenes[0]);
-    if (rcode) return rcode;
-    for (int g = 1; g < n_gpus; g++) {
-      rcode = clone_scene(m->scenes[0], g, &m->scenes[g]);
-      if (rcode) return rcode;
-    }
-    int32_t b[4];
-    film_cropped_bounds(d->xres, d->yres, d->crop, b);
-    m->w = b[2] > b[0] ? b[2] - b[0] : 0;
-    m->h = b[3] > b[1] ? b[3] - b[1] : 0;
-    m->n_px = (size_t)m->w * (size_t)m->h;
-    m->max_slab = shard_pixels(d->xres, d->yres, d->crop, 0, (uint32_t)n_gpus);  // rank 0 owns the most super-tiles
-    for (int g = 0; g < n_gpus; g++) {
-      HIP_TRY(hipSetDevice(g));
-      HIP_TRY(hipStreamCreate(&m->streams[g]));
-      HIP_TRY(m->slabs[g].alloc(m->max_slab ? m->max_slab : 1));
-      HIP_TRY(hipMemsetAsync(m->slabs[g].p, 0, (m->max_slab ? m->max_slab : 1) * sizeof(float4), m->streams[g]));
-    }
-    HIP_TRY(hipSetDevice(0));
-    HIP_TRY(m->gathered.alloc((size_t)n_gpus * (m->max_slab ? m->max_slab : 1)));
-    HIP_TRY(m->film.alloc(m->n_px ? m->n_px : 1));
-    std::vector<int> devs(n_gpus);
-    for (int g = 0; g < n_gpus; g++) devs[g] = g;
-    m->comms.assign(n_gpus, nullptr);
-    const ncclResult_t nr = rc.CommInitAll(m->comms.data(), n_gpus, devs.data());
-    if (nr != 0) return fail(PBRT_HIP_ERR_HIP, std::string("ncclCommInitAll: ") + rc.GetErrorString(nr));
-    for (int g = 0; g < n_gpus; g++) { HIP_TRY(hipSetDevice(g)); HIP_TRY(hipStreamSynchronize(m->streams[g])); }
-    *out = m.release();
-    return PBRT_HIP_OK;
+    DeviceRestore keep;
+    return multi_create(d, n_gpus, flags, out);
   } catch (const std::exception &e) {
     return fail(PBRT_HIP_ERR_INTERNAL, e.what());
   }
@@ -196,49 +321,8 @@ void pbrt_hip_multi_destroy(pbrt_hip_multi *m) { delete m; }
 int pbrt_hip_multi_render(pbrt_hip_multi *m, const pbrt_hip_render_desc *r, float *film, pbrt_hip_stats *per_gpu) {
   if (!m || !r) return fail(PBRT_HIP_ERR_INVALID, "multi_render: null argument");
   try {
-    const int n = m->n;
-    std::vector<int> rcs(n, PBRT_HIP_OK);
-    std::vector<std::string> errs(n);
-    std::vector<pbrt_hip_stats> stats(n);
-    Rccl &rc = rccl();
-    // one host thread per GPU: render its shard, join the gather; thread 0 also assembles the film on GPU 0
-    auto worker = [&](int g) {
-      auto bad = [&](int code, const std::string &what) { rcs[g] = code; errs[g] = "GPU " + std::to_string(g) + ": " + what; };
-      if (hipSetDevice(g) != hipSuccess) return bad(PBRT_HIP_ERR_HIP, "hipSetDevice");
-      pbrt_hip_render_desc rd = *r;
-      rd.rank = (uint32_t)g;
-      rd.world_size = (uint32_t)n;
-      int code = pbrt_hip_render_device(m->scenes[g], &rd, m->slabs[g].p, m->streams[g]);
-      // (a rank whose render could not start still has to join the collective, or the others would wait for ever)
-      if (code) bad(code, pbrt_hip_last_error());
-      const ncclResult_t nr = rc.Gather(m->slabs[g].p, g == 0 ? m->gathered.p : nullptr, 4 * (m->max_slab ? m->max_slab : 1), kNcclFloat, 0,
-                                         m->comms[g], m->streams[g]);
-      if (nr != 0 && !code) bad(PBRT_HIP_ERR_HIP, std::string("ncclGather: ") + rc.GetErrorString(nr));
-      if (g == 0 && nr == 0) {
-        hipError_t e = m->n_px ? hipMemsetAsync(m->film.p, 0, m->n_px * sizeof(float4), m->streams[0]) : hipSuccess;
-        for (int s = 0; s < n && e == hipSuccess && !rcs[0]; s++) {
-          const int c2 = pbrt_hip_film_assemble_device(m->scenes[0], m->gathered.p + (size_t)s * (m->max_slab ? m->max_slab : 1), (uint32_t)s, (uint32_t)n,
-                                                       m->film.p, m->streams[0]);
-          if (c2) bad(c2, pbrt_hip_last_error());
-        }
-        if (e == hipSuccess && film && m->n_px) e = hipMemcpyAsync(film, m->film.p, m->n_px * sizeof(float4), hipMemcpyDeviceToHost, m->streams[0]);
-        if (e != hipSuccess && !rcs[0]) bad(PBRT_HIP_ERR_HIP, hipGetErrorString(e));
-      }
-      const hipError_t es = hipStreamSynchronize(m->streams[g]);
-      if (es != hipSuccess && !rcs[g]) bad(PBRT_HIP_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(es));
-      if (!code) {
-        const int c3 = pbrt_hip_render_wait(m->scenes[g], &stats[g]);
-        if (c3 && !rcs[g]) bad(c3, pbrt_hip_last_error());
-      }
-    };
-    std::vector<std::thread> th;
-    for (int g = 1; g < n; g++) th.emplace_back(worker, g);
-    worker(0);
-    for (auto &t : th) t.join();
-    for (int g = 0; g < n; g++)
-      if (rcs[g]) return fail(rcs[g], "multi_render: " + errs[g]);
-    if (per_gpu) std::memcpy(per_gpu, stats.data(), (size_t)n * sizeof(pbrt_hip_stats));
-    return PBRT_HIP_OK;
+    DeviceRestore keep;
+    return multi_render(m, r, film, per_gpu);
   } catch (const std::exception &e) {
     return fail(PBRT_HIP_ERR_INTERNAL, e.what());
   }
@@ -252,7 +336,8 @@ int pbrt_hip_multi_film_device(pbrt_hip_multi *m, void **d_film) {
 
 int pbrt_hip_render_multi(const pbrt_hip_scene_desc *d, const pbrt_hip_render_desc *r, int n_gpus, float *film, pbrt_hip_stats *per_gpu) {
   pbrt_hip_multi *m = nullptr;
-  int rc = pbrt_hip_multi_create(d, n_gpus, 0u, &m);
+  // world_end has one frame to render: the accelerator is built on the device (milliseconds)
+  int rc = pbrt_hip_multi_create(d, n_gpus, PBRT_HIP_SCENE_GPU_BUILD, &m);
   if (rc) return rc;
   rc = pbrt_hip_multi_render(m, r, film, per_gpu);
   const std::string keep = rc ? pbrt_hip_last_error() : "";

@@ -132,6 +132,10 @@ struct Builder {
   };
 
   static float key_of(const Ref &r, int a) { return r.b.lo[a] + r.b.hi[a]; }
+  static int bin_of(float key, float c0, float scale, int nb) {
+    const float f = (key - c0) * scale;
+    return f >= (float)(nb - 1) ? nb - 1 : (f > 0.f ? (int)f : 0);  // (a NaN goes to bin 0)
+  }
 
   void sort_axis(Ref *r, uint32_t n, int a) const {
     std::sort(r, r + n, [a](const Ref &x, const Ref &y) {
@@ -195,10 +199,10 @@ struct Builder {
       if (only >= 0 && a != only) continue;
       if (!(cmax[a] > cmin[a])) continue;
       const float scale = (float)NB / (cmax[a] - cmin[a]);
+      if (!std::isfinite(scale)) continue;  // (a denormal extent: no plane to speak of)
       for (int b = 0; b < NB; b++) { bb[b].reset(); cnt[b] = 0; }
       for (uint32_t i = 0; i < n; i++) {
-        int b = (int)((key_of(r[i], a) - cmin[a]) * scale);
-        if (b >= NB) b = NB - 1;
+        int b = bin_of(key_of(r[i], a), cmin[a], scale, NB);
         bb[b].grow(r[i].b);
         cnt[b]++;
       }
@@ -227,11 +231,10 @@ struct Builder {
       const float origin = box.lo[a], ext = box.hi[a] - box.lo[a];
       if (!(ext > 0.f)) continue;
       const float bin_size = ext / (float)NB, inv = 1.0f / bin_size;
+      if (!(bin_size > 0.f) || !std::isfinite(inv)) continue;
       for (int b = 0; b < NB; b++) { bb[b].reset(); enter[b] = leave[b] = 0; }
       for (uint32_t i = 0; i < n; i++) {
-        int first = (int)((r[i].b.lo[a] - origin) * inv), last = (int)((r[i].b.hi[a] - origin) * inv);
-        first = std::min(std::max(first, 0), NB - 1);
-        last = std::min(std::max(last, first), NB - 1);
+        const int first = bin_of(r[i].b.lo[a], origin, inv, NB), last = std::max(first, bin_of(r[i].b.hi[a], origin, inv, NB));
         Ref cur = r[i];
         for (int b = first; b < last; b++) {
           Ref l, rr;
@@ -366,11 +369,7 @@ struct Builder {
         } else {
           const float c0 = os.c0, scale = os.scale;
           const int NB = prm.object_bins, bin = os.bin, ax = os.axis;
-          auto it = std::partition(refs.begin() + base, refs.begin() + base + n, [&](const Ref &r) {
-            int b = (int)((key_of(r, ax) - c0) * scale);
-            if (b >= NB) b = NB - 1;
-            return b <= bin;
-          });
+          auto it = std::partition(refs.begin() + base, refs.begin() + base + n, [&](const Ref &r) { return bin_of(key_of(r, ax), c0, scale, NB) <= bin; });
           n_left = (uint32_t)(it - (refs.begin() + base));
         }
         n_right = n - n_left;

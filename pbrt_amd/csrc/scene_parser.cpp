@@ -743,10 +743,9 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
       if (!p.named_params(&name, &ps, api)) return fin(false);
       if (in_options("PixelFilter")) {
         out->filter_name = name;
-        if (name != "box") api.warn("PixelFilter \"" + name + "\": only the box filter of radius 0.5 is implemented (box.rs:57-61)");
+        if (name != "box") api.warn("PixelFilter \"" + name + "\": only the box filter is implemented (box.rs:57-61); its radii are used");
         const float xw = ps.one_float("xwidth", 0.5f), yw = ps.one_float("ywidth", 0.5f);
         out->filter_radius[0] = xw; out->filter_radius[1] = yw;  // handed to the render desc (radii other than 0.5: DESIGN.md 3.11)
-        if (xw != 0.5f || yw != 0.5f) api.warn("PixelFilter: a box radius other than 0.5 is not implemented; pbrt_hip_render refuses it");
       }
     } else if (tok == "ReverseOrientation") {
       if (in_world("ReverseOrientation")) api.gs.reverse_orientation = !api.gs.reverse_orientation;

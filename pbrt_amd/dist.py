@@ -4,7 +4,8 @@ rendering, and ONE gather of the per-rank slabs to rank 0 (RCCL over xGMI when t
 backend is "nccl"; "gloo" in the CPU tests).  The box filter's radius 0.5 (reference
 src/filters/box.rs:57-61) keeps every sample inside its own pixel, so tiles never overlap and the
 assembly is a pure scatter -- the multi-process form of Film::merge_film_tile
-(src/core/film.rs:313-326).
+(src/core/film.rs:313-326).  Any other radius (film.rs:264-273: tiles overlap) is accumulated in fixed
+point and the exchange is one integer sum reduction (reduce_accumulators).
 
 torch is used for device buffers, streams and torch.distributed only.
 """
@@ -81,11 +82,45 @@ def gather_film(local_slab, xres, yres, crop, rank, world_size, group=None, scen
     return assemble_film(recv, xres, yres, crop, world_size, scene)
 
 
+def is_wide_filter(filter_width):
+    """a box filter radius other than the default 0.5 (0 stands for the default): DESIGN.md 3.11"""
+    fw = filter_width or (0.0, 0.0)
+    return any(float(v) not in (0.0, 0.5) for v in fw)
+
+
+def reduce_accumulators(local_acc, rank, world_size, group=None):
+    """A box filter radius other than 0.5: every rank holds fixed-point accumulators of the WHOLE cropped window
+    ([h * w, 4] int64; its own samples, which reach into its neighbours' tiles) -- integer sums are exact in any order, so
+    the film is ONE sum reduction to rank 0 (RCCL ncclReduce over xGMI under "nccl") instead of the gather.  Returns the
+    summed accumulators on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local_acc
+    t = local_acc
+    if world_size > 1 and dist.get_backend(group) == "gloo" and t.is_cuda:
+        t = t.cpu()  # gloo cannot reduce device tensors: stage through the host
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return t if rank == 0 else None
+
+
 def render_sharded(scene, rank, world_size, group=None, **render_kw):
     """Render this rank's super-tiles on its GPU (asynchronously on torch's current stream),
     gather, and return (film on rank 0 or None, stats of the local kernel)."""
     import torch
     sd = scene.sd
+    if is_wide_filter(render_kw.get("filter_width")):
+        w, h = sd.crop_size()
+        acc = torch.empty(max(h * w, 1), 4, dtype=torch.int64, device="cuda")  # (render_device zeroes it)
+        stream = torch.cuda.current_stream().cuda_stream
+        scene.render_device(acc.data_ptr(), stream, rank=rank, world_size=world_size, **render_kw)
+        total = reduce_accumulators(acc, rank, world_size, group)
+        film = None
+        if total is not None:
+            total = total.to("cuda")
+            film = torch.empty(h, w, 4, dtype=torch.float32, device="cuda")
+            scene.film_from_acc_device(total.data_ptr(), film.data_ptr(), stream)
+        return film, scene.render_wait()
     n_floats = scene.slab_floats(rank, world_size)
     slab = torch.empty(max(n_floats // 4, 1), 4, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream

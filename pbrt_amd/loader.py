@@ -23,10 +23,11 @@ class LoadedScene:
     film_scale: float = 1.0     # Film "float scale" (film.rs:368-371): pass to film_to_rgb
     sampler: int = 0            # PBRT_HIP_SAMPLER_*
     filter_width: tuple = (0.5, 0.5)
+    max_sample_luminance: float = 0.0  # Film "float maxsampleluminance" (film.rs:75,279); 0 = none
 
     def render_kwargs(self):
         return dict(integrator=self.integrator, max_depth=self.max_depth, spp=self.spp, sampler=self.sampler,
-                    filter_width=self.filter_width)
+                    filter_width=self.filter_width, max_sample_luminance=self.max_sample_luminance)
 
 
 def _collect(h):
@@ -57,7 +58,8 @@ def _collect(h):
                            [w for w in wbuf.value.decode().split("\n") if w][:nw], ctm.reshape(4, 4),
                            dict(zip(keys, names.value.decode().split(" "))),
                            film_scale=float(l.pbrt_hip_loaded_film_scale(h)), sampler=int(r.sampler),
-                           filter_width=(float(r.filter_xwidth), float(r.filter_ywidth)))
+                           filter_width=(float(r.filter_xwidth), float(r.filter_ywidth)),
+                           max_sample_luminance=float(r.max_sample_luminance))
     finally:
         l.pbrt_hip_loaded_free(h)
 

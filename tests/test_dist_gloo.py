@@ -45,6 +45,39 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
+def _worker_wide(rank, world, port, out_path):
+    """a box filter radius other than 0.5: the exchange is one integer sum reduction (pbrt_amd.dist.reduce_accumulators)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pbrt_amd
+        from oracle import binding as ob
+        from pbrt_amd import dist as pdist, scenes
+        sd = scenes.cornell_scene(200, 136)
+        acc, _ = ob.OracleScene(sd).render_acc((1.5, 1.0), max_depth=3, spp=(2, 1), seed=5, rank=rank, world_size=world, n_threads=2)
+        total = pdist.reduce_accumulators(torch.from_numpy(acc.reshape(-1, 4)), rank, world)
+        if rank == 0:
+            np.save(out_path, pbrt_amd.film_from_acc(total.numpy().reshape(acc.shape)))
+        else:
+            assert total is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_reduce_of_a_wide_filter_film(tmp_path, oracle):
+    out = str(tmp_path / "film.npy")
+    mp.spawn(_worker_wide, args=(2, _free_port(), out), nprocs=2, join=True)
+    from pbrt_amd import dist as pdist, scenes
+    sd = scenes.cornell_scene(200, 136)
+    want, _ = oracle.OracleScene(sd).render(max_depth=3, spp=(2, 1), seed=5, filter_width=(1.5, 1.0))
+    got = np.load(out)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert pdist.is_wide_filter((1.5, 1.0)) and not pdist.is_wide_filter((0.5, 0.0)) and not pdist.is_wide_filter(None)
+
+
 @pytest.mark.timeout(300)
 def test_two_rank_gather_assembles_the_single_rank_film(tmp_path, oracle):
     out = str(tmp_path / "film.npy")

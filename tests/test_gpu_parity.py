@@ -185,8 +185,9 @@ def test_render_limits(gpu):
     from pbrt_amd import _lib
     sd = SMALL_SCENES["cornell"]()
     with gpu.Scene(sd) as sc:
-        for kw, code in ((dict(spp=(2048, 1024)), -4), (dict(spp=(1, 1), max_depth=1024), -4), (dict(spp=(1, 1), filter_width=(1.0, 0.5)), -4),
-                         (dict(spp=(1, 1), sampler=7), -1)):
+        for kw, code in ((dict(spp=(2048, 1024)), -4), (dict(spp=(1, 1), max_depth=1024), -4), (dict(spp=(1, 1), filter_width=(17.0, 0.5)), -4),
+                         (dict(spp=(1, 1), filter_width=(-1.0, 0.5)), -1), (dict(spp=(1, 1), filter_width=(1.0, 0.5), counters=True), -1),
+                         (dict(spp=(1, 1), max_sample_luminance=-1.0), -1), (dict(spp=(1, 1), sampler=7), -1)):
             with pytest.raises(_lib.PbrtHipError) as e:
                 sc.render(**kw)
             assert e.value.code == code, (kw, str(e.value))
@@ -644,3 +645,97 @@ def test_bench_under_torchrun_uses_rccl(gpu):
         assert r.returncode == 0, r.stderr[-3000:]
         out2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out2["film_check"]["weight_ok"] and abs(out2["film_check"]["mean_Y"] - out["film_check"]["mean_Y"]) < 1e-12
+
+
+# ---- box filter radii other than 0.5 and Film "maxsampleluminance"  ----
+WIDE_CASES = [
+    ("mesh1k", INTEGRATOR_PATH, 6, (2, 2), 3, (1.5, 1.5), "stratified"),
+    ("mesh1k", INTEGRATOR_PATH, 6, (3, 2), 4, (1.0, 2.0), "sobol"),
+    ("cornell", INTEGRATOR_PATH, 8, (2, 2), 1, (0.3, 0.75), "stratified"),  # narrower than a pixel: some samples land nowhere
+    ("cornell", INTEGRATOR_PATH, 8, (9, 8), 2, (2.5, 0.5), "stratified"),   # 72 spp: two chunks per pixel; default radius on one axis
+    ("check_sphere", INTEGRATOR_PATH, 5, (2, 2), 9, (2.0, 2.0), "stratified"),  # the sphere kernel
+    ("sphere", INTEGRATOR_DIRECT, 5, (4, 2), 0, (1.25, 3.0), "sobol"),
+    ("ties", INTEGRATOR_PATH, 6, (2, 1), 5, (0.75, 0.75), "stratified"),
+]
+
+
+@pytest.mark.parametrize("name,integrator,depth,spp,seed,fw,sampler", WIDE_CASES)
+def test_wide_box_filter_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed, fw, sampler):
+    """`PixelFilter "box" "float xwidth" r`: every sample inside the sample bounds (film.rs:166-175) adds to all pixels
+    within the radius; the film is accumulated in 64-bit fixed point with integer atomics, so it is
+    reproducible and must equal the oracle's bit for bit -- film, accumulators, and the sum over three ranks."""
+    sd = SMALL_SCENES[name]()
+    kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=seed, sampler=sampler)
+    o = oracle.OracleScene(sd)
+    ref, _ = o.render(filter_width=fw, **kw)
+    ref_acc, _ = o.render_acc(fw, **kw)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(filter_width=fw, **kw)
+        again, _ = sc.render(filter_width=fw, **kw)
+        acc, _ = sc.render_acc(fw, **kw)
+        parts = [sc.render_acc(fw, rank=r, world_size=3, **kw)[0] for r in range(3)]
+        default, _ = sc.render(**kw)  # the default path still works on the same handle afterwards
+    assert_bit_equal(film, ref, f"{name} film, box filter {fw}")
+    assert_bit_equal(again, ref, "second frame (atomics: still deterministic)")
+    assert np.array_equal(acc, ref_acc), "accumulators"
+    assert np.array_equal(parts[0] + parts[1] + parts[2], ref_acc), "accumulators of three ranks add up to one rank's"
+    assert_bit_equal(gpu.film_from_acc(ref_acc), ref, "host conversion of the accumulators")
+    assert_bit_equal(default, o.render(**kw)[0], "default filter after a wide one")
+    # weights: a pixel collects the samples of (2 rx) x (2 ry) pixel areas (interior and border alike: the halo is sampled)
+    w = film[..., 3]
+    area = 4 * fw[0] * fw[1] * spp[0] * spp[1]
+    assert abs(w.mean() - area) < 0.2 * area + 1
+
+
+def test_wide_box_filter_crop_window_and_big_sums(gpu, oracle):
+    """A crop window (sample bounds reach outside it, negative pixel coordinates included at the image corner), and
+    radiance sums far beyond 2^24 fixed-point units: the int64 -> float conversion must round as the CPU's does."""
+    sd = scenes.cornell_scene(96, 80, crop=(0.0, 0.4, 0.0, 0.55))
+    kw = dict(max_depth=6, spp=(6, 6), seed=11, filter_width=(3.0, 1.5))
+    ref, _ = oracle.OracleScene(sd).render(**kw)
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(**kw)
+    assert_bit_equal(film, ref, "cropped film, box filter (3, 1.5)")
+    assert film[..., 3].max() >= 36 * 6 * 3 * 0.9
+
+
+def test_max_sample_luminance_matches_oracle(gpu, oracle):
+    """Film "float maxsampleluminance" (film.rs:75,279; pbrt-v3 FilmTile::AddSample): samples brighter than the bound are
+    scaled down to it -- on the default film path and on the fixed-point one."""
+    sd = scenes.cornell_scene(64, 64)  # the camera sees the ceiling light: Le = (17, 12, 4)
+    kw = dict(max_depth=5, spp=(3, 3), seed=4)
+    o = oracle.OracleScene(sd)
+    plain, _ = o.render(**kw)
+    ref, _ = o.render(max_sample_luminance=1.5, **kw)
+    refw, _ = o.render(max_sample_luminance=1.5, filter_width=(1.5, 1.5), **kw)
+    assert not np.array_equal(plain, ref)  # the bound bites
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(max_sample_luminance=1.5, **kw)
+        filmw, _ = sc.render(max_sample_luminance=1.5, filter_width=(1.5, 1.5), **kw)
+        unbounded, _ = sc.render(**kw)
+    assert_bit_equal(film, ref, "clamped film")
+    assert_bit_equal(filmw, refw, "clamped film, wide filter")
+    assert_bit_equal(unbounded, plain, "no bound")
+
+
+def test_wide_box_filter_in_one_process_multi_gpu_and_scene_file(gpu, oracle):
+    """The in-library multi-GPU path with a wide filter (accumulators summed -- ncclReduce for n > 1 -- then converted on
+    GPU 0), and the same through a scene file: `PixelFilter "box" "float xwidth" 1.5` + Film "maxsampleluminance"."""
+    import os
+    from pbrt_amd import loader
+    sd = scenes.cornell_scene(200, 136)
+    kw = dict(max_depth=3, spp=(2, 2), seed=8, filter_width=(1.5, 1.5))
+    ref, _ = oracle.OracleScene(sd).render(**kw)
+    n = min(2, gpu.device_count())
+    with gpu.MultiScene(sd, n) as ms:
+        film, _ = ms.render(**kw)
+    assert_bit_equal(film, ref, f"wide filter on {n} GPU(s) in one process")
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "c0_check_sphere.pbrt")).read()
+    text = text.replace("[400]", "[64]").replace('"integer pixelsamples" 128', '"integer pixelsamples" 4')
+    text = text.replace("Film ", 'PixelFilter "box" "float xwidth" 1.5 "float ywidth" 1.5\nFilm ', 1).replace('"string filename"', '"float maxsampleluminance" 0.75 "string filename"', 1)
+    ls = loader.load_string(text)
+    assert ls.filter_width == (1.5, 1.5) and ls.max_sample_luminance == 0.75
+    ref, _ = oracle.OracleScene(ls.scene).render(seed=0, **ls.render_kwargs())
+    with gpu.Scene(ls.scene) as sc:
+        film, _ = sc.render(seed=0, **ls.render_kwargs())
+    assert_bit_equal(film, ref, "C0 scene file with a wide box filter")

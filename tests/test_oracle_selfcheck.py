@@ -246,3 +246,50 @@ def test_sobol_sampler_points_are_stratified_per_pixel(oracle):
     f3, _ = sc.render(integrator=INTEGRATOR_DIRECT, spp=(4, 4), seed=8, sampler="sobol")
     assert_bit_equal(f1, f2, "thread-count invariance of the Sobol sampler")
     assert not np.array_equal(f1, f3) and (f1[..., 3] == 16).all()
+
+
+# ---- box filter radii other than 0.5 ----
+def test_wide_box_filter_weights_and_constant_radiance(oracle):
+    """Under a constant infinite light with nothing else in the scene every sample carries the same radiance c, so a film
+    pixel is c x (number of samples within the radius) whatever the radius: film / weight == c exactly where it is
+    representable, and the weights follow from the geometry -- (2 rx)(2 ry) spp for integer diameters, border pixels
+    included because the sample bounds (film.rs:166-175) reach beyond the image."""
+    sd = SceneData(xres=24, yres=20, lights=np.array([[LIGHT_INFINITE, 0, 0, 0, 0.25, 0.5, 1.0]], np.float32))
+    o = oracle.OracleScene(sd)
+    for fw, spp in (((1.5, 1.5), (2, 2)), ((1.0, 2.0), (4, 2)), ((0.25, 0.25), (4, 4))):
+        film, _ = o.render(spp=spp, filter_width=fw, seed=3)
+        w = film[..., 3]
+        if fw != (0.25, 0.25):
+            assert (w == 4 * fw[0] * fw[1] * spp[0] * spp[1]).all(), (fw, np.unique(w))
+        else:  # narrower than a pixel: the strata 1 and 2 of 4 per axis lie within 0.25 of the centre
+            assert (w == 4).all(), np.unique(w)
+        rgb = oracle.film_write_rgb(film)
+        assert np.allclose(rgb, [0.25, 0.5, 1.0], rtol=1e-5, atol=0)  # (the RGB -> XYZ -> RGB matrices of spectrum.rs:129-145 are not exact inverses)
+
+
+def test_wide_box_filter_ranks_add_and_threads_do_not_matter(oracle):
+    """Integer accumulators: the sum over ranks equals one rank's, and the thread count (= the order in which samples
+    arrive) changes nothing."""
+    sd = SMALL_SCENES["cornell"]()
+    kw = dict(max_depth=4, spp=(2, 2), seed=6)
+    o = oracle.OracleScene(sd)
+    one, _ = o.render_acc((1.5, 2.0), n_threads=1, **kw)
+    many, _ = o.render_acc((1.5, 2.0), n_threads=7, **kw)
+    assert np.array_equal(one, many)
+    parts = sum(o.render_acc((1.5, 2.0), rank=r, world_size=5, **kw)[0] for r in range(5))
+    assert np.array_equal(parts, one)
+    film, _ = o.render(filter_width=(1.5, 2.0), **kw)
+    assert_bit_equal(oracle.film_from_acc(one), film, "film from accumulators")
+    import pbrt_amd
+    assert_bit_equal(pbrt_amd.film_from_acc(one), film, "the product's host conversion")  # (host-only entry point, no GPU)
+
+
+def test_max_sample_luminance_clamps(oracle):
+    sd = SMALL_SCENES["cornell"]()
+    o = oracle.OracleScene(sd)
+    a, _ = o.render(max_depth=3, spp=(2, 2), seed=1)
+    b, _ = o.render(max_depth=3, spp=(2, 2), seed=1, max_sample_luminance=0.5)
+    ya, yb = a[..., 1] / a[..., 3], b[..., 1] / b[..., 3]
+    assert yb.max() <= 0.5 * (1 + 1e-6) and ya.max() > 2.0  # the light (Y about 12) is visible
+    dark = ya < 0.5 / 4  # the mean of 4 non-negative samples: none of them can exceed the bound
+    assert dark.any() and np.array_equal(a[dark], b[dark])  # such pixels are untouched

@@ -164,14 +164,16 @@ def test_recursive_include_is_an_error(tmp_path):
 
 def test_film_scale_and_filter_radius_leave_the_library():
     """Film "float scale" multiplies every pixel in Film::write_image (film.rs:368-371): the loader exports it; a
-    PixelFilter radius other than 0.5 reaches the render desc (where pbrt_hip_render refuses it)."""
+    PixelFilter radius reaches the render desc (radii other than 0.5: DESIGN.md 3.11)."""
     ls = loader.load_string('Film "image" "float scale" 2.5 "integer xresolution" 8 "integer yresolution" 8\n'
                             'PixelFilter "box" "float xwidth" 1.5 "float ywidth" 0.5\nWorldBegin\nWorldEnd\n')
     assert ls.film_scale == 2.5
-    assert ls.filter_width == (1.5, 0.5)
-    assert any("radius" in w for w in ls.warnings)
+    assert ls.filter_width == (1.5, 0.5) and ls.max_sample_luminance == 0.0
     ls = loader.load_string("WorldBegin\nWorldEnd\n")
     assert ls.film_scale == 1.0 and ls.filter_width == (0.5, 0.5)
+    # Film "float maxsampleluminance" (film.rs:75,279) reaches the render desc too; pbrt-v3's default (infinity) is 0 here
+    ls = loader.load_string('Film "image" "float maxsampleluminance" 12.5 "integer xresolution" 8 "integer yresolution" 8')
+    assert ls.max_sample_luminance == 12.5 and ls.render_kwargs()["max_sample_luminance"] == 12.5
     film = np.ones((2, 2, 4), np.float32)
     assert np.array_equal(pbrt_amd.film_to_rgb(film, scale=2.5), pbrt_amd.film_to_rgb(film) * np.float32(2.5))
 
