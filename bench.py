@@ -138,8 +138,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, nargs=2, default=None, help="override strata (diagnostics; invalid as a headline)")
-    ap.add_argument("--builder", default="host", choices=["host", "gpu"],
-                    help="accelerator builder: host binned SAH (headline) or the device builder (same film)")
+    ap.add_argument("--builder", default="gpu", choices=["host", "gpu"],
+                    help="accelerator builder: the device builder (the product's default: milliseconds) or the host's binned SAH "
+                         "(one core, about a second for 1M triangles); same film either way")
     ap.add_argument("--sampler", default="stratified", choices=["stratified", "sobol"])
     ap.add_argument("--single-process", action="store_true",
                     help="N GPUs from ONE process through pbrt_hip_multi_* (ncclGather inside the library) instead of one rank per GPU")
@@ -192,9 +193,7 @@ def main():
     else:
         scene = pbrt_amd.Scene(sd, device=device_index, builder=args.builder)
         info = scene.info()
-    if args.builder == "gpu":
-        args.no_counters = True  # the canonical counters exist only for the host-built tree
-    build_s = time.time() - t0
+    build_s = time.time() - t0  # scene data + accelerator build + upload (outside the timed region)
     kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=0, sampler=args.sampler)
 
     def barrier():
@@ -203,14 +202,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    per_gpu_ms = []  # --single-process: every GPU's kernel time of every timed step (the first real 8-GPU run shows its imbalance)
+
     def step():
         if in_process:
             film, sts = scene.render(host_film=False, **kw)
+            per_gpu_ms.append([s["kernel_ms"] for s in sts])
             return None, {"kernel_ms": max(s["kernel_ms"] for s in sts), "samples": sum(s["samples"] for s in sts)}
         return pdist.render_sharded(scene, rank, world, **kw)
 
     for _ in range(args.warmup):
         step()
+    per_gpu_ms.clear()
     barrier()
     t_start = time.perf_counter()
     kernel_ms, local_samples = [], 0
@@ -239,6 +242,15 @@ def main():
     roof["kernel_ms"] = avg_kernel_ms
     pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
+    # A profile prices the library it was taken on and no other: the committed counters carry the build id (hash of the
+    # sources and kernel flags, pbrt_hip_build_id) of that library; with a different one loaded every figure that rests on
+    # them is withheld ("frac is silently stale").
+    lib_id = pbrt_amd.build_id()
+    pmc_stale = pmc is not None and pmc.get("build_id") != lib_id
+    if pmc_stale:
+        roof["stale_profile"] = (f"{os.path.relpath(pmc_path, ROOT)} was taken on library build {pmc.get('build_id', '(none recorded)')}, "
+                                 f"this is {lib_id}: roofline.frac / valu / traffic withheld -- rerun tools/measure_round.sh")
+        pmc = None
     if not args.no_counters:
         # untimed counting pass: exact nodes-visited / triangles-tested of THIS rank's share (the counting instantiation
         # of the same kernel; equal to the oracle's counters, tests/test_gpu_parity.py) and the rays of the launch
@@ -257,7 +269,8 @@ def main():
         scene.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, rank=rank, world_size=world,
                             counters="walk", **kw)
         wst = scene.render_wait()
-        kbytes = (64.0 * wst["nodes_visited"] + 48.0 * wst["tris_tested"] + 112.0 * rays) / wst["samples"] + 28.0 + 128.0 / (spp[0] * spp[1])
+        # (64-byte quad nodes, 64-byte triangle records: 16 x kTriStride since r02j)
+        kbytes = (64.0 * wst["nodes_visited"] + 64.0 * wst["tris_tested"] + 112.0 * rays) / wst["samples"] + 28.0 + 128.0 / (spp[0] * spp[1])
         roof["hbm"] = {
             "note": "SURVEY 8(d) contract figure: algorithmic bytes of the CANONICAL binary-BVH walk (exact counters, equal to the "
                     "oracle's) / HIP-event kernel time, against the 8 TB/s HBM spec.  It is not a roof of this workload when "
@@ -297,10 +310,17 @@ def main():
                    "sharding": (f"64x64 super-tiles round-robin over {args.gpus} GPU(s), one gather"
                                 + (" (one process, ncclGather inside the library)" if in_process else " (one rank per GPU)")),
                    "bvh_nodes": info["n_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
-                   "scene_build_s": round(build_s, 2),
+                   "scene_build_s": round(build_s, 2), "library_build_id": lib_id,
+                   # build_ms: the builder's own time (device: HIP events); canonical_tree_host_build_ms: the host builder's time
+                   # for the oracle's tree, which only the untimed counting pass uses
                    "accelerator": dict(scene.build_info(), builder=args.builder) if not in_process else {"builder": args.builder}},
         "roofline": roof,
     }
+    if in_process and per_gpu_ms:
+        import statistics
+        cols = list(zip(*per_gpu_ms))
+        out["per_gpu_kernel_ms"] = {"mean_per_gpu": [round(statistics.mean(c), 3) for c in cols],
+                                    "max": round(max(map(max, cols)), 3), "min": round(min(map(min, cols)), 3)}
     if rank == 0:
         if world == 1 and not in_process and not args.no_cpu_baseline and args.workload != "big":
             out["cpu_baseline"] = cpu_baseline(kind, n, res, integrator, depth, spp,

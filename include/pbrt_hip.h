@@ -121,6 +121,9 @@ typedef struct pbrt_hip_scene pbrt_hip_scene;
 int pbrt_hip_device_count(void);
 const char *pbrt_hip_last_error(void);
 const char *pbrt_hip_version(void);
+/* identity of the build: a hash of the library's sources and kernel-shaping flags (pbrt_amd/build.py source_id).  A
+ * profile taken on one build must not price another: bench.py compares this with the id stored beside the counters */
+const char *pbrt_hip_build_id(void);
 
 /* ---- scene: flatten + BVH build on the host, upload to HBM.  device < 0: current device.
  * Input is validated before any device work: indices in range, vertices / spheres / camera matrix finite, sphere radii
@@ -128,14 +131,18 @@ const char *pbrt_hip_version(void);
 int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_scene **out);
 /* The same with options.  PBRT_HIP_SCENE_GPU_BUILD: build the accelerator on the device (Morton codes, radix sort,
  * binary radix tree, collapse into the quantised 4-wide nodes) instead of the host's binned-SAH
- * builder: milliseconds instead of seconds for 1M triangles, a tree that walks slower, the SAME film and hit
+ * builder: milliseconds instead of a second for 1M triangles, a tree of the same quality, the SAME film and hit
  * records bit for bit (a hit does not depend on the tree).  The counter flags of render / intersect
- * (the oracle's canonical walk) need the host-built tree and are refused for such a scene.
+ * count the oracle's canonical walk: for such a scene the canonical tree is built on the host at the first call that
+ * asks for them (vertex / index buffers read back; about a second for 1M triangles, never on the render path).
  * pbrt_hip_scene_create(desc, ...) == pbrt_hip_scene_create_ex(desc, ..., getenv("PBRT_HIP_BUILDER") == "gpu"). */
 #define PBRT_HIP_SCENE_GPU_BUILD 1u
 int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *desc, int device, uint32_t flags, pbrt_hip_scene **out);
 /* how the accelerator was built: *gpu_built 0 / 1, *build_ms = host build time (wall) or device build time (events) */
 int pbrt_hip_scene_build_info(const pbrt_hip_scene *scene, uint32_t *gpu_built, double *build_ms);
+/* the canonical tree behind the counter flags: *ready = it exists (always for a host-built scene; for a device-built one
+ * after the first call that counted), *build_ms = the host builder's time for it */
+int pbrt_hip_scene_canonical_info(const pbrt_hip_scene *scene, uint32_t *ready, double *build_ms);
 /* the production walk's tree as it sits in HBM: quads = 16 words per node (cap_nodes of them), order = leaf slot ->
  * triangle id (n_tris words); either may be NULL */
 int pbrt_hip_scene_export_quads(const pbrt_hip_scene *scene, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads,

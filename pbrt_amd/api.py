@@ -121,6 +121,11 @@ def device_count():
     return lib().pbrt_hip_device_count()
 
 
+def build_id():
+    """pbrt_hip_build_id: hash of the sources and flags the loaded library was built from"""
+    return lib().pbrt_hip_build_id().decode()
+
+
 def look_at(pos, look, up):
     """Transform::look_at (transform.rs:485-520) -> (world_to_camera, camera_to_world) 4x4 float32."""
     m = np.zeros(16, np.float32)
@@ -319,7 +324,9 @@ class Scene:
     def build_info(self):
         g, ms = C.c_uint32(), C.c_double()
         check(lib().pbrt_hip_scene_build_info(self._h, C.byref(g), C.byref(ms)), "pbrt_hip_scene_build_info")
-        return {"gpu_built": bool(g.value), "build_ms": ms.value}
+        r, cms = C.c_uint32(), C.c_double()
+        check(lib().pbrt_hip_scene_canonical_info(self._h, C.byref(r), C.byref(cms)), "pbrt_hip_scene_canonical_info")
+        return {"gpu_built": bool(g.value), "build_ms": ms.value, "canonical_tree_ready": bool(r.value), "canonical_tree_host_build_ms": cms.value}
 
     def export_quads(self):
         """(quads[n, 16] uint32, order[n_tris] uint32): the production walk's tree as it sits in HBM."""

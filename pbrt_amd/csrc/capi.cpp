@@ -534,6 +534,44 @@ void build_production_quads(const Bvh &canon, const float *P, const uint32_t *id
   if (n_refs) *n_refs = (uint32_t)rb.ref_tri.size();
 }
 
+// The counter flags (PBRT_HIP_FLAG_COUNTERS, counters of pbrt_hip_intersect) count the CANONICAL walk: the oracle's binary
+// tree of DESIGN.md 3.3.  A host-built scene has it; a device-built one gets it here on first use -- vertex / index buffers
+// read back from the device, the host builder (one core, about a second for 1M triangles: a measurement aid, off the
+// product's path), child-pair records and triangle records in the canonical leaf order uploaded beside the production arrays.
+int ensure_canonical(pbrt_hip_scene *s) {
+  if (s->canonical_ready) return PBRT_HIP_OK;
+  if (!s->gpu_built) { s->dev_exact = s->dev; s->canonical_ready = true; return PBRT_HIP_OK; }
+  const auto t0 = std::chrono::steady_clock::now();
+  const uint32_t nt = s->dev.n_tris;
+  std::vector<float> P(s->d_P.n);
+  std::vector<uint32_t> idx(s->d_idx.n);
+  HIP_TRY(hipSetDevice(s->device));
+  if (!P.empty()) HIP_TRY(hipMemcpy(P.data(), s->d_P.p, P.size() * 4, hipMemcpyDeviceToHost));
+  if (!idx.empty()) HIP_TRY(hipMemcpy(idx.data(), s->d_idx.p, idx.size() * 4, hipMemcpyDeviceToHost));
+  build_bvh(P.data(), idx.data(), nt, &s->bvh);
+  if (s->bvh.depth > 64) return fail(PBRT_HIP_ERR_LIMIT, "counters: canonical BVH deeper than the 64-entry traversal stack");
+  PairNodes pairs;
+  std::string why;
+  if (!make_pair_nodes(s->bvh, &pairs, &why)) return fail(PBRT_HIP_ERR_LIMIT, "counters: " + why);
+  s->d_nodes.release();
+  HIP_TRY(s->d_nodes.alloc(pairs.q.size()));
+  HIP_TRY(s->d_order_exact.alloc(nt));
+  HIP_TRY(s->d_tris_exact.alloc(kTriStride * (size_t)nt));
+  if (!pairs.q.empty()) HIP_TRY(hipMemcpyAsync(s->d_nodes.p, pairs.q.data(), pairs.q.size() * 16, hipMemcpyHostToDevice, s->stream));
+  if (nt) HIP_TRY(hipMemcpyAsync(s->d_order_exact.p, s->bvh.order.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order_exact.p, nt, s->d_tris_exact.p, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->dev_exact = s->dev;
+  s->dev_exact.nodes = s->d_nodes.p;
+  s->dev_exact.tris = s->d_tris_exact.p;
+  s->dev_exact.n_nodes = (uint32_t)s->bvh.nodes.size();
+  s->dev_exact.root_ref = pairs.root_ref;
+  for (int k = 0; k < 3; k++) { s->dev_exact.root_lo[k] = pairs.root_lo[k]; s->dev_exact.root_hi[k] = pairs.root_hi[k]; }
+  s->canonical_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  s->canonical_ready = true;
+  return PBRT_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -545,7 +583,11 @@ int pbrt_hip_device_count(void) {
 }
 
 const char *pbrt_hip_last_error(void) { return pbrt_hip::last_error_message(); }
-const char *pbrt_hip_version(void) { return "pbrt_hip 0.2 (gfx950)"; }
+const char *pbrt_hip_version(void) { return "pbrt_hip 0.3 (gfx950)"; }
+#ifndef PBRT_HIP_BUILD_ID
+#define PBRT_HIP_BUILD_ID "unknown"
+#endif
+const char *pbrt_hip_build_id(void) { return PBRT_HIP_BUILD_ID; }
 
 int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, uint32_t *nodes,
                             uint32_t *order, uint32_t *n_nodes, uint32_t *depth) {
@@ -841,6 +883,13 @@ int pbrt_hip_scene_build_info(const pbrt_hip_scene *s, uint32_t *gpu_built, doub
   return PBRT_HIP_OK;
 }
 
+int pbrt_hip_scene_canonical_info(const pbrt_hip_scene *s, uint32_t *ready, double *build_ms) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "canonical_info: null scene");
+  if (ready) *ready = (s->canonical_ready || !s->gpu_built) ? 1u : 0u;
+  if (build_ms) *build_ms = s->gpu_built ? s->canonical_build_ms : s->build_ms;
+  return PBRT_HIP_OK;
+}
+
 int pbrt_hip_render_stack_plan(uint32_t stack_need, uint32_t *lds_rows, uint32_t *waves_per_cu, uint32_t *overflow_entries) {
   const RenderStackPlan p = render_stack_plan(stack_need, render_force_overflow(), render_prefer_lds());
   if (lds_rows) *lds_rows = p.rows;
@@ -965,14 +1014,16 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", s->dev.quad_stack_need <= kShallowStackNeed ? kMinWalkersShallow : kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);
-    if (counters == 1 && s->gpu_built)
-      return fail(PBRT_HIP_ERR_INVALID, "render: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
+    if (counters == 1) {  // the canonical walk: a device-built scene gets the oracle's tree now (host build, first use only)
+      const int ce = ensure_canonical(s);
+      if (ce) return ce;
+    }
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 80 * sizeof(unsigned long long), st));
     if (fg.wide && fg.crop_px()) HIP_TRY(hipMemsetAsync(d_slab, 0, fg.crop_px() * 32, st));  // this rank's accumulators start at zero
     HIP_TRY(hipEventRecord(s->ev0, st));
     // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order (a wide
     // filter has no partial sums: its samples go straight into the accumulators)
-    HIP_TRY(launch_render(s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, st));
+    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, st));
     if (!fg.wide) HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
@@ -1133,9 +1184,11 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
     if (counters) counters[0] = counters[1] = 0;
     return PBRT_HIP_OK;
   }
-  if (counters && s->gpu_built)
-    return fail(PBRT_HIP_ERR_INVALID, "intersect: the canonical counters need the host-built tree (scene was built with PBRT_HIP_SCENE_GPU_BUILD)");
   HIP_TRY(hipSetDevice(s->device));
+  if (counters) {
+    const int ce = ensure_canonical(s);
+    if (ce) return ce;
+  }
   DevBuf<float> d_o, d_d, d_tmax, d_t, d_b1, d_b2;
   DevBuf<uint32_t> d_prim;
   DevBuf<uint8_t> d_occ;
@@ -1183,7 +1236,7 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
   }
   const bool timed = debug_knob("PBRT_HIP_TIME_INTERSECT") != nullptr;  // tuning aid: kernel time to stderr
   if (timed) RB_TRY(hipEventRecord(s->ev0, s->stream));
-  RB_TRY(launch_intersect(s->dev, B, any, s->bvh.depth, s->stream));
+  RB_TRY(launch_intersect(counters ? s->dev_exact : s->dev, B, any, s->bvh.depth, s->stream));
   if (timed) {
     RB_TRY(hipEventRecord(s->ev1, s->stream));
     RB_TRY(hipEventSynchronize(s->ev1));

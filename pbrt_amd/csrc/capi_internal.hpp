@@ -61,7 +61,15 @@ struct pbrt_hip_scene {
   bool pending = false;
   bool pending_counters = false;
   uint32_t n_quads_gpu = 0;
-  bool gpu_built = false;  // accelerator built on the device (no canonical tree: counter flags refused)
+  bool gpu_built = false;  // accelerator built on the device: the canonical tree (counter flags) is made on first use
+  // The canonical walk's view of a device-built scene (pbrt_hip::ensure_canonical): the oracle's binary tree, built on the
+  // host from the vertex / index buffers read back from the device, and triangle records in ITS leaf order.  For a
+  // host-built scene the production arrays serve both walks and dev_exact == dev.
+  pbrt_hip::DevScene dev_exact{};
+  bool canonical_ready = false;
+  pbrt_hip::DevBuf<float4> d_tris_exact;
+  pbrt_hip::DevBuf<uint32_t> d_order_exact;
+  double canonical_build_ms = 0.0;
   double build_ms = 0.0;
   uint64_t pending_samples = 0;
   uint64_t device_bytes = 0;
@@ -70,6 +78,7 @@ struct pbrt_hip_scene {
     d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release(); d_quads.release(); d_stack_overflow.release();
     d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
     d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release(); d_partials.release();
+    d_tris_exact.release(); d_order_exact.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);

@@ -4,6 +4,7 @@
 // verbose = + warnings/debug; pbrt.rs:48-62).  Where the reference parses and pretty-prints its state
 // (pbrt.rs:72-83, WorldEnd renders nothing), this parses, renders on the GPU through the C ABI and
 // writes the image named by Film "string filename" (or -o).
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -85,9 +86,10 @@ int main(int argc, char **argv) {
     std::vector<float> film((size_t)w * h * 4), rgb((size_t)w * h * 3);
     // every GPU of the node from this one process (the reference binary is one process, bin/pbrt.rs:72-83): the scene
     // is copied device to device, GPU g renders the super-tiles t % n == g, one ncclGather assembles the film
-    const int n = gpus > 0 ? gpus : pbrt_hip_device_count();
-    std::vector<pbrt_hip_stats> per_gpu(n > 0 ? n : 1);
-    const int rc = pbrt_hip_render_multi(&desc, &rd, n, film.data(), per_gpu.data());
+    // (--gpus 0 = all visible devices, but no more than the film has 64x64 super-tiles: the library decides)
+    const int n = std::max(1, pbrt_hip_device_count());
+    std::vector<pbrt_hip_stats> per_gpu((size_t)n);  // zero-initialised: entries of GPUs that were not used stay empty
+    const int rc = pbrt_hip_render_multi(&desc, &rd, gpus > 0 ? gpus : 0, film.data(), per_gpu.data());
     pbrt_hip_loaded_free(loaded);
     if (rc != 0) { logf(1, "%s: %s", path.c_str(), pbrt_hip_last_error()); return 1; }
     pbrt_hip_stats st = per_gpu[0];

@@ -510,17 +510,26 @@ def test_gpu_built_scene_matches_oracle(gpu, oracle, name):
     o, d, tmax = random_rays(100_000, 5)
     ref = oracle.OracleScene(sd)
     rt, rp, rb1, rb2, _ = ref.intersect(o, d, tmax)
-    film_ref, _ = ref.render(max_depth=6, spp=(2, 2), seed=11)
+    film_ref, rst = ref.render(max_depth=6, spp=(2, 2), seed=11)
+    rcnt = ref.intersect(o, d, tmax)[4]
     with gpu.Scene(sd, builder="gpu") as sc:
         bi = sc.build_info()
-        assert bi["gpu_built"] and bi["build_ms"] > 0
+        assert bi["gpu_built"] and bi["build_ms"] > 0 and not bi["canonical_tree_ready"]
         t, prim, b1, b2, _ = sc.intersect(o, d, tmax)
         occ = sc.occluded(o, d, tmax)
         film, st = sc.render(max_depth=6, spp=(2, 2), seed=11)
         quads, order = sc.export_quads()
         need = sc.info()["quad_stack_need"]
-        with pytest.raises(RuntimeError):
-            sc.render(max_depth=6, spp=(1, 1), counters=True)  # the canonical counters need the host-built tree
+        # the counter flags count the CANONICAL walk: the oracle's tree is built on the host at first use
+        film_c, stc = sc.render(max_depth=6, spp=(2, 2), seed=11, counters=True)
+        cnt = sc.intersect(o, d, tmax, counters=True)[4]
+        assert sc.build_info()["canonical_tree_ready"]
+        film_after, _ = sc.render(max_depth=6, spp=(2, 2), seed=11)  # the production arrays are untouched by it
+    assert_bit_equal(film_c, film_ref, "film of the counting pass")
+    assert_bit_equal(film_after, film_ref, "film after the canonical tree was added")
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+        assert stc[k] == rst[k], f"{k}: {stc[k]} vs oracle {rst[k]}"
+    assert tuple(cnt) == tuple(rcnt), f"ray-batch counters {cnt} vs oracle {rcnt}"
     assert_bit_equal(prim, rp, "prim")
     assert_bit_equal(t, rt, "t")
     assert_bit_equal(b1, rb1, "b1")
@@ -601,9 +610,7 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
         for r in range(world):
             part, _ = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, rank=r, world_size=world, sampler=sampler)
             acc = part if acc is None else acc + part
-        st = None
-        if not sc.build_info()["gpu_built"]:
-            _, st = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, counters=True, sampler=sampler)
+        _, st = sc.render(integrator=integ, max_depth=depth, spp=spp, seed=rseed, counters=True, sampler=sampler)
         o, d, tmax = random_rays(3000, seed, inside=2.5)
         hit = sc.intersect(o, d, tmax)
         occ = sc.occluded(o, d, tmax)

@@ -71,6 +71,13 @@ def main():
             model = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_model.py"), pmc], capture_output=True, text=True, check=True).stdout)
             summary.update(model)
             summary["valu_source"] = f"tools/pmc_passes.sh on tools/pmc_probe.py {wl} (low-spp frame) -> profiles/{tag}_{wl}_pmc_counters.txt -> tools/valu_model.py"
+        # the library the counters were taken on (bench.py withholds figures priced with another build's profile)
+        for line_file in (os.path.join(G, f"prof_{tag}_{wl}_trace.json"), os.path.join(G, f"bench_{wl}_{tag}.json")):
+            try:
+                summary["build_id"] = json.load(open(line_file))["config"]["library_build_id"]
+                break
+            except (OSError, ValueError, KeyError):
+                continue
         with open(os.path.join(P, f"{tag}_{wl}_summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         shutil.copy(os.path.join(P, f"{tag}_{wl}_summary.json"), os.path.join(P, f"pmc_{wl}.json"))
