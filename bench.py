@@ -14,10 +14,10 @@ timing starts.  N>1: one process per GPU under torch.distributed.run (the driver
 ncclGather inside the library).
 
 Rank 0 prints ONE JSON line.  `roofline` (dominant kernel = render_kernel):
-  bound "valu"  the resource the counters show binding: vector-instruction issue.  achieved =
-                VALU issue cycles the launch needs (instructions per ray from the committed PMC profile, priced with the
-                per-class issue costs measured by tools/ubench/valu_issue.hip, x the rays of this launch, counted live)
-                / the kernel's HIP-event time; peak = SIMDs x clock.  frac <= 1 by construction of a roof.
+  bound "valu"  the resource the counters show binding: vector-instruction issue.  achieved = the
+                quad-cycles in which the SIMDs issued vector instructions (MEASURED by the SQ: SQ_ACTIVE_INST_VALU -
+                SQ_ACTIVE_INST_VALU2 per ray, from the committed PMC profile of this very build, x the rays of this launch,
+                counted live) / the kernel's HIP-event time; peak = SIMDs x clock / 4.  frac <= 1 by construction.
   hbm           SURVEY 8(d)'s contract figure kept beside it: algorithmic bytes of the CANONICAL walk / kernel time
                 against 8 TB/s (can exceed 1: the scene is cache-resident and the production walk moves fewer bytes),
                 and what the memory-side counters saw (`traffic`, hbm_counter_frac).
@@ -142,6 +142,9 @@ def main():
                     help="accelerator builder: the device builder (the product's default: milliseconds) or the host's binned SAH "
                          "(one core, about a second for 1M triangles); same film either way")
     ap.add_argument("--sampler", default="stratified", choices=["stratified", "sobol"])
+    ap.add_argument("--filter", type=float, nargs=2, default=None, metavar=("XW", "YW"),
+                    help="box filter radii (diagnostics; the BASELINE configs use the default 0.5): other radii take the fixed-point film "
+                         "path, whose multi-GPU exchange is a sum reduction instead of the gather")
     ap.add_argument("--single-process", action="store_true",
                     help="N GPUs from ONE process through pbrt_hip_multi_* (ncclGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -195,6 +198,10 @@ def main():
         info = scene.info()
     build_s = time.time() - t0  # scene data + accelerator build + upload (outside the timed region)
     kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=0, sampler=args.sampler)
+    wide = pdist.is_wide_filter(args.filter)
+    if wide:
+        kw["filter_width"] = tuple(args.filter)
+        args.no_counters = True  # (the counter flags need the default filter)
 
     def barrier():
         torch.cuda.synchronize()
@@ -236,7 +243,7 @@ def main():
 
     n_simd = torch.cuda.get_device_properties(device_index).multi_processor_count * SIMDS_PER_CU
     peak = n_simd * CLOCK_GHZ  # G issue-cycles/s
-    roof = {"bound": "valu", "achieved": None, "peak": peak, "unit": "G VALU issue-cycles/s", "frac": None, "traffic": None,
+    roof = {"bound": "valu", "achieved": None, "peak": peak / 4.0, "unit": "G vector-issue quad-cycles/s", "frac": None, "traffic": None,
             "kernel": "render_kernel"}
     avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     roof["kernel_ms"] = avg_kernel_ms
@@ -254,7 +261,7 @@ def main():
     if not args.no_counters:
         # untimed counting pass: exact nodes-visited / triangles-tested of THIS rank's share (the counting instantiation
         # of the same kernel; equal to the oracle's counters, tests/test_gpu_parity.py) and the rays of the launch
-        slab = torch.empty(max(scene.slab_floats(rank, world) // 4, 1), 4, device="cuda")
+        slab = torch.empty(max(scene.render_buffer_bytes(rank=rank, world_size=world, **kw) // 16, 1), 4, device="cuda")
         scene.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, rank=rank, world_size=world,
                             counters=True, **kw)
         cst = scene.render_wait()
@@ -282,14 +289,22 @@ def main():
             "kernel_bytes_per_sample": kbytes, "kernel_fetches_per_ray": wst["nodes_visited"] / rays,
             "kernel_tris_per_ray": wst["tris_tested"] / rays, "kernel_gbps": kbytes * local_samples / (avg_kernel_ms * 1e-3) / 1e9,
         }
-        if pmc and "valu_issue_cycles_per_ray" in pmc:
-            # VALU roof: the launch's issue-cycle demand (per ray from the committed profile x rays counted live) / time
-            roof["achieved"] = pmc["valu_issue_cycles_per_ray"] * rays_per_s / 1e9
+        if pmc and pmc.get("valu_issue_quadcycles_per_ray"):
+            # VALU roof, MEASURED: the SQ counts the quad-cycles in which a SIMD issued a vector instruction (one, or two of
+            # the full-rate class: profiles/r03c_issue_counter_calibration.txt); per ray from the committed profile OF THIS
+            # BUILD (checked above), x the rays this launch traced, counted live, / the kernel's time; the roof is every
+            # quad-cycle of every SIMD at the nominal clock.  No instruction census and no per-class prices are involved.
+            roof["unit"] = "G vector-issue quad-cycles/s"
+            roof["peak"] = peak = n_simd * CLOCK_GHZ / 4.0
+            roof["achieved"] = pmc["valu_issue_quadcycles_per_ray"] * rays_per_s / 1e9
             roof["frac"] = roof["achieved"] / peak
-            roof["valu"] = {k: pmc.get(k) for k in ("valu_instructions_per_ray", "valu_issue_cycles_per_ray", "mean_issue_cycles_per_instruction",
-                                                    "valu_busy_frac_at_profile_clock", "valu_busy_bracket", "lane_utilisation", "l2_hit_rate",
-                                                    "clock_ghz_in_profile", "round")}
-            roof["valu"]["source"] = f"{os.path.relpath(pmc_path, ROOT)} (rocprofv3 --pmc passes of tools/measure_round.sh) + profiles/r02_valu_issue_ubench.txt"
+            m = pmc.get("valu_issue_busy_measured")
+            roof["valu"] = {k: pmc.get(k) for k in ("valu_issue_busy_measured", "valu_issue_quadcycles_per_ray", "valu_dual_issue_share_of_instructions",
+                                                    "valu_instructions_per_ray", "lane_utilisation", "l2_hit_rate", "wave_wait_frac",
+                                                    "clock_ghz_in_profile", "round", "build_id")}
+            roof["valu"]["valu_busy_bracket"] = [m, m]  # a measurement, not a model: the r02 bracket [0.72, 1.07] is gone
+            roof["valu"]["class_model_r02"] = {k: pmc.get(k) for k in ("valu_busy_frac_at_profile_clock", "valu_issue_cycles_per_ray", "mean_issue_cycles_per_instruction")}
+            roof["valu"]["source"] = f"{os.path.relpath(pmc_path, ROOT)} (rocprofv3 --pmc passes of tools/measure_round.sh; counters calibrated in profiles/r03c_issue_counter_calibration.txt)"
     # HBM-side traffic cannot be read in-process: it comes from the separate rocprofv3 --pmc passes of this same
     # workload whose summary is committed under profiles/; null when there is none.
     if pmc and world == 1 and not args.spp and "traffic_bytes_raw" in pmc:
@@ -306,7 +321,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": descr, "triangles": int(sd.idx.shape[0]), "resolution": [res, res], "spp": spp[0] * spp[1],
-                   "maxdepth": depth, "sampler": args.sampler,
+                   "maxdepth": depth, "sampler": args.sampler, "box_filter_radius": list(args.filter) if wide else [0.5, 0.5],
                    "sharding": (f"64x64 super-tiles round-robin over {args.gpus} GPU(s), one gather"
                                 + (" (one process, ncclGather inside the library)" if in_process else " (one rank per GPU)")),
                    "bvh_nodes": info["n_nodes"], "bvh_depth": info["depth"], "scene_bytes": info["device_bytes"],
@@ -329,8 +344,8 @@ def main():
         if film is not None:
             import numpy as np
             f = film.cpu().numpy()
-            out["film_check"] = {"weight_ok": bool((f[..., 3] == spp[0] * spp[1]).all()), "finite": bool(np.isfinite(f).all()),
-                                 "mean_Y": float(f[..., 1].mean() / (spp[0] * spp[1]))}
+            out["film_check"] = {"weight_ok": bool((f[..., 3] == spp[0] * spp[1]).all()) if not wide else None, "finite": bool(np.isfinite(f).all()),
+                                 "mean_Y": float(f[..., 1].mean() / (spp[0] * spp[1])), "mean_weight": float(f[..., 3].mean())}
         print(json.dumps(out), flush=True)
     scene.close()
     if use_pg:

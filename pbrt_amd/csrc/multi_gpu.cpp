@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -245,7 +246,9 @@ int multi_render(pbrt_hip_multi *m, const pbrt_hip_render_desc *r, float *film, 
     pbrt_hip_render_desc rd = *r;
     rd.rank = (uint32_t)g;
     rd.world_size = (uint32_t)n;
-    code = pbrt_hip_render_device(m->scenes[g], &rd, m->slabs[g].p, m->streams[g]);
+    const char *inject = debug_knob("PBRT_HIP_MULTI_FAIL_RANK");  // tests: a rank whose launch fails (the others must not be left waiting)
+    if (inject && std::atoi(inject) == g) code = fail(PBRT_HIP_ERR_INTERNAL, "injected launch failure (PBRT_HIP_MULTI_FAIL_RANK)");
+    else code = pbrt_hip_render_device(m->scenes[g], &rd, m->slabs[g].p, m->streams[g]);
     if (code) err = "GPU " + std::to_string(g) + ": " + pbrt_hip_last_error();
     else started[g] = true;
   }

@@ -206,10 +206,10 @@ def test_render_limits(gpu):
 
 @pytest.mark.parametrize("n_gpus", [1, 2])
 def test_multi_gpu_render_in_one_process(gpu, oracle, n_gpus):
-    """pbrt_hip_multi_*: the scene replicated device to device, one host thread + stream per GPU, ONE RCCL gather
-    (ncclGather on communicators from ncclCommInitAll) and the assembly on GPU 0 -- the film must equal the oracle's
-    and the single-GPU path's bit for bit.  n_gpus = 1 runs the same RCCL calls on a one-rank communicator, so the
-    path is exercised on a single-GPU box as well; n_gpus = 2 needs two devices."""
+    """pbrt_hip_multi_*: the scene replicated device to device, one stream per GPU, ONE RCCL gather (a group call of
+    ncclGather on communicators from ncclCommInitAll) and the assembly on GPU 0 -- the film must equal the oracle's and
+    the single-GPU path's bit for bit.  n_gpus = 1 needs no collective (RCCL is not even loaded); n_gpus = 2 needs two
+    devices."""
     if gpu.device_count() < n_gpus:
         pytest.skip(f"needs {n_gpus} GPUs")
     sd = scenes.cornell_scene(200, 136)  # 4 x 3 super-tiles, ragged edges
@@ -652,6 +652,70 @@ def test_bench_under_torchrun_uses_rccl(gpu):
         assert r.returncode == 0, r.stderr[-3000:]
         out2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out2["film_check"]["weight_ok"] and abs(out2["film_check"]["mean_Y"] - out["film_check"]["mean_Y"]) < 1e-12
+
+
+@pytest.mark.timeout(300)
+def test_multi_gpu_launch_failure_leaves_nobody_waiting(gpu, oracle, monkeypatch):
+    """VERDICT r02 item 7b / ADVICE: a GPU whose launch fails must not leave the others in a collective for ever.  The
+    in-library path launches every shard BEFORE the frame's one collective is enqueued, so a failure (injected here on the
+    last rank) returns an error at once, drains the launches that did start, and the handle renders correctly afterwards;
+    the caller's current device is untouched."""
+    import ctypes as C
+    sd = scenes.cornell_scene(200, 136)
+    kw = dict(max_depth=3, spp=(2, 1), seed=2)
+    n = min(2, gpu.device_count())
+    hip = C.CDLL("libamdhip64.so")
+    before = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(before)) == 0
+    with gpu.MultiScene(sd, n) as ms:
+        monkeypatch.setenv("PBRT_HIP_MULTI_FAIL_RANK", str(n - 1))
+        with pytest.raises(RuntimeError) as e:
+            ms.render(**kw)
+        assert "injected launch failure" in str(e.value)
+        monkeypatch.delenv("PBRT_HIP_MULTI_FAIL_RANK")
+        film, _ = ms.render(**kw)
+    after = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(after)) == 0 and after.value == before.value
+    assert_bit_equal(film, oracle.OracleScene(sd).render(**kw)[0], "frame after a failed one")
+    # all visible GPUs asked for, but a 64x64 film has one super-tile: the library uses one GPU (no scene copies for idle ranks)
+    with gpu.MultiScene(scenes.cornell_scene(64, 64), 0) as ms:
+        assert ms.n_gpus == 1
+
+
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_share_one_gpu_under_gloo(gpu):
+    """The driver's 8-GPU command line -- torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 -- end to end before
+    an 8-GPU node ever sees it: eight ranks share this box's GPU(s) with PBRT_DIST_BACKEND=gloo
+    (RCCL wants one GPU per rank), every rank renders its eighth of the super-tiles, barrier, max-over-ranks timing,
+    gather on rank 0, one JSON line whose film is complete.  Then the same with a wide box filter: the exchange is the
+    integer sum reduction instead of the gather."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PBRT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29541",
+            os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", "c2", "--spp", "2", "2", "--no-cpu-baseline"]
+    r = subprocess.run(base, capture_output=True, text=True, cwd=root, env=env, timeout=1000)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["film_check"]["weight_ok"] and out["film_check"]["finite"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "c2", "--spp", "2", "2",
+                          "--no-cpu-baseline", "--no-counters"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert abs(ref["film_check"]["mean_Y"] - out["film_check"]["mean_Y"]) < 1e-12  # eight shares assemble the one-rank film
+    wide = subprocess.run(base + ["--filter", "1.5", "1.5", "--no-counters"], capture_output=True, text=True, cwd=root, env=env, timeout=1000)
+    assert wide.returncode == 0, wide.stderr[-3000:]
+    w8 = json.loads([l for l in wide.stdout.splitlines() if l.startswith("{")][-1])
+    w1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "c2", "--spp", "2", "2",
+                         "--no-cpu-baseline", "--no-counters", "--filter", "1.5", "1.5"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert w1.returncode == 0, w1.stderr[-3000:]
+    w1 = json.loads([l for l in w1.stdout.splitlines() if l.startswith("{")][-1])
+    assert w8["film_check"]["finite"] and abs(w8["film_check"]["mean_Y"] - w1["film_check"]["mean_Y"]) < 1e-12 and w8["film_check"]["mean_weight"] == 36.0
 
 
 # ---- box filter radii other than 0.5 and Film "maxsampleluminance" (SURVEY 8 row R3; DESIGN.md 3.11) ----

@@ -9,9 +9,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PROBE_COUNTERS=1
 i=0
+# (a group that starts with "ISSUE:" is the vector issue port's occupancy, tools/pmc_issue.sh / profiles/r03c_issue_counter_calibration.txt:
+# its counters come from ONE pass -- the others repeat elsewhere -- and are kept apart as ISSUE_<name>)
 while read -r group; do
   [ -z "$group" ] && continue
   i=$((i+1))
+  prefix=""
+  case "$group" in ISSUE:*) prefix="ISSUE_"; group=${group#ISSUE: };; esac
+  echo "$prefix" > $OUT/p$i.prefix
   timeout 600 rocprofv3 --pmc $group --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/pmc_probe.py "$@" > $OUT/p$i.log 2>&1
   echo "pass $i rc=$? : $group"
 done <<'GROUPS'
@@ -20,6 +25,7 @@ SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU 
 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VMEM_WR
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum GRBM_GUI_ACTIVE
 TA_FLAT_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_READ_sum TCP_TOTAL_ACCESSES_sum SQ_VMEM_TA_ADDR_FIFO_FULL SQ_LDS_BANK_CONFLICT
+ISSUE: SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE
 FETCH_SIZE
 WRITE_SIZE
 GROUPS
@@ -27,10 +33,13 @@ python3 - "$OUT" <<'PY'
 import csv, glob, re, sys, collections
 out = sys.argv[1]
 agg = collections.OrderedDict()
+import os
 for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True)):
+    pdir = f[len(out) + 1:].split("/")[0]
+    prefix = open(os.path.join(out, pdir + ".prefix")).read().strip() if os.path.exists(os.path.join(out, pdir + ".prefix")) else ""
     for r in csv.DictReader(open(f)):
         if re.search(r"render_kernel<(true|false), false, false", r["Kernel_Name"]):  # the production kernel only
-            agg[r["Counter_Name"]] = agg.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            agg[prefix + r["Counter_Name"]] = agg.get(prefix + r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 probe = {}
 for line in open(out + "/p1.log"):
     m = re.match(r"RAYS (\d+) SAMPLES (\d+) KERNEL_MS ([0-9.]+)", line)

@@ -127,6 +127,17 @@ def main():
         "probe_counter_gbps": (c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024 / c["PROBE_KERNEL_NS"] if c.get("PROBE_KERNEL_NS") else None,
         "costs": {"fast": FAST, "slow": SLOW, "trans": TRANS, "int64": INT64, "source": "profiles/r02_valu_issue_ubench.txt"},
     }
+    # ---- MEASURED occupancy of the vector issue port (r03): quad-cycles in which a vector instruction was issued =
+    # SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 (a quad-cycle takes one instruction, or two of the full-rate class:
+    # profiles/r03c_issue_counter_calibration.txt), over the SIMDs' quad-cycles of the same pass.  No census, no prices.
+    if c.get("ISSUE_SQ_ACTIVE_INST_VALU") and c.get("ISSUE_GRBM_GUI_ACTIVE"):
+        busy_qc = c["ISSUE_SQ_ACTIVE_INST_VALU"] - c.get("ISSUE_SQ_ACTIVE_INST_VALU2", 0.0)
+        total_qc = c["ISSUE_GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * n_simd
+        out["valu_issue_busy_measured"] = busy_qc / total_qc
+        out["valu_issue_quadcycles_per_ray"] = busy_qc / rays if rays else None
+        out["valu_dual_issue_share_of_instructions"] = 2.0 * c.get("ISSUE_SQ_ACTIVE_INST_VALU2", 0.0) / c["ISSUE_SQ_INSTS_VALU"] if c.get("ISSUE_SQ_INSTS_VALU") else None
+        out["valu_issue_source"] = ("SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 over GRBM_GUI_ACTIVE / 8 / 4 x SIMDs, one rocprofv3 --pmc pass "
+                                    "(tools/pmc_passes.sh group ISSUE); what the two counters count: profiles/r03c_issue_counter_calibration.txt")
     print(json.dumps(out, indent=1))
 
 
