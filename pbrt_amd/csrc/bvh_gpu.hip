@@ -1,16 +1,18 @@
-// BVH construction on the device: Morton codes -> radix sort -> binary tree -> greedy
-// collapse into the quantised 4-wide nodes the production walk reads.  Two ways to the binary tree:
-//   * PLOC (default): parallel locally-ordered clustering (Meister & Bittner, "Parallel Locally-Ordered Clustering for
-//     Bounding Volume Hierarchy Construction", IEEE TVCG 2018): the Morton-sorted triangles are clusters; every round
-//     each cluster finds, among its kPlocRadius neighbours on either side, the one whose union box with it has the
-//     smallest surface area; mutual nearest neighbours merge into a node; the list is compacted; ~20-30 rounds to one
-//     root.  Agglomerative by surface area, so the tree has SAH quality close to the host's binned top-down builder;
-//   * LBVH (PBRT_HIP_GPU_BUILDER=lbvh behind the debug switch): the binary radix tree of Karras 2012 + a bottom-up box
-//     fit -- faster to build, and a tree that walks ~9 % slower on C3.
+// BVH construction on the device: the host builder's algorithm --
+// top-down binned SAH (centre bounds -> widest axis -> 16 buckets -> plane of least n_l A_l + n_r A_r) -- run
+// LEVEL-SYNCHRONOUSLY over the Morton-sorted triangles (every segment of a level is split by the same launches), followed
+// by the host's dynamic-programming collapse into the quantised 4-wide nodes the production walk reads (DESIGN.md section
+// 4).  This is the DEFAULT builder (`sah`): 34 ms for 1M triangles against the host's second, a tree within 0.3 % of the
+// host's in walk time.  Two earlier builders stay selectable behind the debug switch for A-B runs
+// (PBRT_HIP_GPU_BUILDER=lbvh|ploc):
+//   * LBVH: the binary radix tree of Karras 2012 + a bottom-up box fit -- faster to build, a tree that walks ~9 % slower on C3;
+//   * PLOC: parallel locally-ordered clustering (Meister & Bittner, IEEE TVCG 2018) -- a better SAH-style cost than the LBVH's
+//     and a WORSE walk in a random soup (bottom-up merging leaves heavily overlapping siblings).
 // The reference has no accelerator at all (core/api.rs:237 is a name), so there is nothing to conform to but the RESULT:
 // by the tie rule of DESIGN.md 3.4 a ray's hit does not depend on the shape of the tree, so a scene built here renders
 // the same film, bit for bit, as one built by the host's SAH builder (tests/test_gpu_parity.py::test_gpu_built_scene_*).
-// The canonical counters (oracle order) exist only for the host-built tree.
+// The canonical counters (the oracle's walk of ITS tree) of such a scene come from the oracle's tree, built on the host
+// the first time they are asked for (capi.cpp ensure_canonical).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -713,9 +715,13 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
   GB_TRY(sort_tmp.alloc(sort_bytes));
 
-  hipEvent_t e0, e1;
-  GB_TRY(hipEventCreate(&e0));
-  GB_TRY(hipEventCreate(&e1));
+  struct Events {  // (destroyed on every exit, early returns of GB_TRY included)
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  GB_TRY(hipEventCreate(&ev.a));
+  GB_TRY(hipEventCreate(&ev.b));
+  const hipEvent_t e0 = ev.a, e1 = ev.b;
   GB_TRY(hipEventRecord(e0, stream));
   const uint32_t init_bounds[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   GB_TRY(hipMemcpyAsync(bounds.p, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, stream));
@@ -890,8 +896,6 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   GB_TRY(hipStreamSynchronize(stream));
   float ms = 0.f;
   GB_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   info->n_quads = h_counters[0];
   info->stack_need = h_counters[1];
   info->levels = levels;

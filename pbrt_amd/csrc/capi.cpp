@@ -978,8 +978,9 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.spp_x_recip = recip32(r->spp_x);
     if ((uint64_t)sh.total * (uint64_t)sh.stx >= (1ull << 32))
       return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for the kernel's tile arithmetic");
-    // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once (16 per CU: the
-    // LDS stack and the register budget both allow 4 per SIMD), each lane drawing item after item from the rank's list.
+    // The render kernel's waves are persistent: as many one-wave workgroups as the device holds at once (20 per CU: the
+    // LDS stack -- render_stack_plan -- and the register budget both allow 5 per SIMD), each lane drawing item after item
+    // from the rank's list.
     // An item is one CHUNK (a K-th of the samples, K <= 16 with at least 32 samples per chunk) of one pixel: DESIGN.md 3.1.
     R.chunk_shift = sample_chunk_shift(spp);
     const uint32_t n_chunks = 1u << R.chunk_shift;  // K: DESIGN.md 3.1
@@ -1000,7 +1001,9 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.partials = nullptr;
     if (!fg.wide) {
       const size_t need = (size_t)sh.n_local * 4096u * n_chunks;  // one float4 per item
-      if (s->d_partials.n < need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
+      // (one float4 per item = 16 K bytes per pixel of the rank's share: C3 1.07 GB, C4's 4096^2 x 16 chunks 4.3 GB on one
+      // GPU; the buffer follows the frame: released when a later render needs less than a quarter of it)
+      if (s->d_partials.n < need || s->d_partials.n / 4 > need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
       R.partials = s->d_partials.p;
     }
     {

@@ -18,7 +18,7 @@
 
 namespace pbrt_hip {
 
-// Tuning / A-B knobs (PBRT_HIP_MIN_WALKERS, PBRT_HIP_TWO_PHASE, PBRT_HIP_COLLAPSE, ...) are read from the environment
+// Tuning / A-B knobs (PBRT_HIP_MIN_WALKERS, PBRT_HIP_COLLAPSE, PBRT_HIP_TREE, ...) are read from the environment
 // only when PBRT_HIP_DEBUG_KNOBS is set (to anything but "0"): a production process is not steered by stray variables.
 inline const char *debug_knob(const char *name) {
   const char *on = std::getenv("PBRT_HIP_DEBUG_KNOBS");

@@ -273,19 +273,11 @@ __device__ __forceinline__ void trav_enter(Trav &T, uint32_t ref) { T.cur = ref;
 __device__ __forceinline__ bool trav_parked(const Trav &T) { return T.cur != kDone && (T.cur & kLeafRef) != 0u; }
 __device__ __forceinline__ uint32_t trav_leaf_cnt(const Trav &T) { return trav_parked(T) ? (T.cur >> 24) & 0x7fu : 0u; }
 
-#ifdef PBRT_PHASE_PROBE
-__shared__ unsigned long long s_probe[24];
-__device__ unsigned long long g_probe[24];
-#define PROBE_ADD(i_, v_) do { const unsigned long long pv_ = (v_); if (threadIdx.x == 0) s_probe[i_] += pv_; } while (0)
-// wave time (s_memtime cycles, stalls included) since the previous marker goes to section k_ (render_kernel's outer loop);
-// the time of the last marker is kept in LDS and the first ACTIVE lane does the bookkeeping, so a marker inside a branch
-// that lane 0 did not take still counts
-#define PROBE_SEC(k_) do { const unsigned long long pt_ = __builtin_amdgcn_s_memtime(); \
-    if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) { s_probe[8 + (k_)] += pt_ - s_probe[23]; s_probe[23] = pt_; } } while (0)
-#else
-#define PROBE_ADD(i_, v_) do { } while (0)
-#define PROBE_SEC(k_) do { } while (0)
-#endif
+// Measurement aids (phase probe, ray log, per-pixel trace, A-B sensitivity loads / instructions, measured-negative
+// variants kept for the record) live in experiments.inc and exist only in builds made with one of its switches
+// (PBRT_PHASE_PROBE, PBRT_RAY_LOG, PBRT_DEBUG_PIXEL_X/Y, PBRT_EXTRA_VALU, PBRT_EXTRA_LOADS, PBRT_PREFETCH_POP: tools/README.md);
+// in the product build every hook below expands to nothing.
+#include "experiments.inc"
 template <bool EXACT>
 __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t *stk, V3 o, V3 d, float tmax, bool any,
                                            unsigned long long &cn) {
@@ -396,7 +388,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
     // finishes in the first one idles through the rest; the checks cost about a fifth of a step)
 #pragma unroll
     for (int rep = 0; !EXACT && rep < STEPS; rep++) {
-    { const unsigned long long ma = __ballot(T.cur != kDone && !trav_parked(T)); if (ma) { PROBE_ADD(0, 1); PROBE_ADD(1, __popcll(ma)); } }
+    EXP_PROBE_LANES(0, T.cur != kDone && !trav_parked(T));
     if (T.cur != kDone && !trav_parked(T)) {
       // ---- one step of the production walk: the four children of quantised quad node T.cur (64 bytes) ----
       const uint32_t off = T.cur;  // the ref of an interior quad node IS its byte offset (node number x 64)
@@ -409,25 +401,11 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
       const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
       const uint4 W3 = *reinterpret_cast<const uint4 *>(quads + off + 48u);
-#ifdef PBRT_EXTRA_LOADS
-      {
-        uint4 X0, X1;
-        const char *pp = quads + off;
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:32\n\ts_waitcnt vmcnt(0)" : "=&v"(X0), "=&v"(X1) : "v"(pp) : "memory");
-        if ((X0.x ^ X1.y) == 0x9e3779b9u && X0.z == 0x12345u) T.tmax = 0.f;
-      }
-#endif
+      EXP_STEP_EXTRA_LOADS(quads, off, T);
       wave_prio(PBRT_PRIO_ARITH);
       if (COUNT) cn++;  // one 64-byte fetch
       const float tfar = fminf(T.h.t, T.tmax);
-#ifdef PBRT_EXTRA_VALU  // A-B experiment: PBRT_EXTRA_VALU extra independent VALU instructions per node step
-      {
-        float x0 = __uint_as_float(W0.x), x1 = __uint_as_float(W0.y);
-#pragma unroll
-        for (int k = 0; k < PBRT_EXTRA_VALU / 2; k++) asm volatile("v_fma_f32 %0, %0, %2, %2\n\tv_fma_f32 %1, %1, %2, %2" : "+v"(x0), "+v"(x1) : "v"(tfar));
-        if (x0 == 1.2345f && x1 == 5.4321f) T.tmax = 0.f;
-      }
-#endif
+      EXP_STEP_EXTRA_VALU(W0, tfar, T);
       // Node-relative slab test.  A decoded plane is the REAL number origin + q * cell (the builder
       // checks in exact arithmetic that these planes enclose the true box), so
       //     t = (origin + q*cell - o) * inv = q * (cell*inv) - (o - origin)*inv = fma(q, ci, -gi):
@@ -526,27 +504,11 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
          (uint32_t)__popcll(mleaf) * 2u >= (uint32_t)__popcll(__ballot(T.cur != kDone && !parked)))) {
       const uint32_t cnt = parked ? (T.cur >> 24) & 0x7fu : 0u, first = T.cur & 0xffffffu;
       bool stop = false;  // any-hit ray found its hit
-#ifdef PBRT_PREFETCH_POP
-      // Experiment: a parked lane's NEXT node is already known -- the entry below its stack top -- so one dword of it is
-      // requested beside the triangle fetch: when the lane pops, the node's line is in L1 / L2 instead of a serial
-      // ~700-cycle fetch after the leaf pass.  (Kept live until after the pass so that the load's register is not reused
-      // under it; entries beyond the LDS part of an overflow stack are not followed.)
-      uint32_t pf = 0u;
-      if (parked) {
-        const uint32_t top = lds_load(T.sp - kRowBytes);
-        if (!(top & kLeafRef)) pf = *reinterpret_cast<const uint32_t *>(quads + top);
-      }
-#endif
-#ifdef PBRT_PHASE_PROBE
-      {  // flushes, and the passes they would take if the (lane, triangle) items were spread over all 64 lanes
-        uint32_t items = 0;
-        for (uint32_t i = 0; i < 8; i++) items += (uint32_t)__popcll(__ballot(cnt > i));
-        PROBE_ADD(6, 1); PROBE_ADD(7, (items + 63u) / 64u);
-      }
-#endif
+      EXP_LEAF_PREFETCH_BEGIN(parked, quads, T);
+      EXP_PROBE_FLUSH(cnt);
       for (uint32_t i = 0;; i++) {
         if (__ballot(cnt > i && !stop) == 0ull) break;
-        PROBE_ADD(2, 1); PROBE_ADD(3, __popcll(__ballot(cnt > i && !stop)));
+        EXP_PROBE_LANES(2, cnt > i && !stop);
         if (cnt > i && !stop) {
           const uint32_t slot = first + i;
           wave_prio(PBRT_PRIO_FETCH);  // (as for the node fetch)
@@ -583,9 +545,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           T.h.b2 = closer ? v : T.h.b2;
         }
       }
-#ifdef PBRT_PREFETCH_POP
-      asm volatile("" ::"v"(pf));
-#endif
+      EXP_LEAF_PREFETCH_END();
       // (OVF: is any entry about to be popped one of the rare ones beyond the LDS part?  wave-uniform, as for the pushes)
       const bool far_pop = OVFR != 0u && !EXACT &&
                            __ballot(parked && !stop && T.sp >= lds_addr(stk - (threadIdx.x & 63u)) + OVFR * kRowBytes) != 0ull;
@@ -688,10 +648,6 @@ enum : uint32_t { ST_NEW = 0, ST_CLOSEST = 1, ST_SHADOW = 2, ST_DONE = 3, ST_FET
 #define PBRT_RENDER_WAVES_PER_SIMD 5
 #endif
 
-#ifdef PBRT_RAY_LOG
-__device__ float4 *g_raylog = nullptr;
-__device__ unsigned long long g_raylog_n = 0, g_raylog_cap = 0;
-#endif
 // Path state of one work item (a CHUNK of a pixel's samples) while its lane is busy walking the BVH:
 // five 16-byte records per lane in HBM, laid out [record][lane] per wave so that a wave's access is one coalesced
 // 1 KB transaction.  It is loaded and stored only in the service stage (once per ray, against ~41 gather steps),
@@ -845,12 +801,10 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
   T.any = 0;
   T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
 
-#ifdef PBRT_PHASE_PROBE
-  if (lane < 24) s_probe[lane] = lane == 23 ? __builtin_amdgcn_s_memtime() : 0ull;
-#endif
+  EXP_PROBE_INIT(lane);
   for (;;) {
     // ---- service stage: lanes whose walk is over consume the result and launch the next ray ----
-    { const unsigned long long ms = __ballot(state != ST_DONE && T.cur == kDone); if (ms) { PROBE_ADD(4, 1); PROBE_ADD(5, __popcll(ms)); } }
+    EXP_PROBE_LANES(4, state != ST_DONE && T.cur == kDone);
     const bool serve = state != ST_DONE && T.cur == kDone;
     PathState P;
     bool launch = false, launch_any = false;
@@ -866,10 +820,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
         if (SPH) trav_spheres(S, T);
         bool advance = false;  // take the prepared bounce (or end the sample)
         if (state == ST_SHADOW) {
-#ifdef PBRT_DEBUG_PIXEL_X
-          if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
-            printf("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(rec_load(rec, kRecLpend).x), T.any >> 1, T.tmax);
-#endif
+          EXP_DEBUG_PIXEL("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(rec_load(rec, kRecLpend).x), T.any >> 1, T.tmax);
           if (T.any != 3u) {  // unoccluded: the light sample counts
             const float4 lp = rec_load(rec, kRecLpend);
             P.L = P.L + mk(lp.x, lp.y, lp.z);
@@ -878,14 +829,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
         } else {
           const HitRec h = T.h;
           const bool hit = h.prim != kNoPrim;
-#ifdef PBRT_DEBUG_PIXEL_X
-          if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
-          {
-            printf("HIP s %u bounce %u prim %u t %08x b1 %a b2 %a L %08x beta %08x\n", P.s, P.bounces, h.prim, __float_as_uint(h.t), h.b1, h.b2,
-                   __float_as_uint(P.L.x), __float_as_uint(P.beta.x));
-            printf("HIP s %u   ray o %a %a %a d %a %a %a\n", P.s, T.o.x, T.o.y, T.o.z, T.d.x, T.d.y, T.d.z);
-          }
-#endif
+          EXP_DEBUG_PIXEL("HIP s %u bounce %u prim %u t %08x b1 %a b2 %a L %08x beta %08x\n", P.s, P.bounces, h.prim, __float_as_uint(h.t), h.b1, h.b2,
+                          __float_as_uint(P.L.x), __float_as_uint(P.beta.x));
+          EXP_DEBUG_PIXEL("HIP s %u   ray o %a %a %a d %a %a %a\n", P.s, T.o.x, T.o.y, T.o.z, T.d.x, T.d.y, T.d.z);
           V3 p = {0.f, 0.f, 0.f}, ng = {0.f, 0.f, 1.f};
           float4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
           const V3 wo = -T.d;
@@ -949,10 +895,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
                 float u1, u2;
                 sample_2d(P, sobol, spp_mask, u1, u2);
                 const float z = cosine_about(nf, u1, u2, P.wi_next);
-#ifdef PBRT_DEBUG_PIXEL_X
-                if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
-                  printf("HIP s %u   cos u1 %a u2 %a z %a nf %a %a %a wi %a %a %a\n", P.s, u1, u2, z, nf.x, nf.y, nf.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
-#endif
+                EXP_DEBUG_PIXEL("HIP s %u   cos u1 %a u2 %a z %a nf %a %a %a wi %a %a %a\n", P.s, u1, u2, z, nf.x, nf.y, nf.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
                 if (z == 0.f) alive = false;
                 else { P.beta = P.beta * k; P.specular = false; }
               }
@@ -1002,10 +945,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
             const float y = (0.212671f * P.L.x + 0.715160f * P.L.y) + 0.072169f * P.L.z;
             if (isnan(P.L.x) || isnan(P.L.y) || isnan(P.L.z) || y < -1e-5f || isinf(y)) P.L = {0.f, 0.f, 0.f};
             else if (y > R.max_lum) P.L = P.L * (R.max_lum / y);  // Film "maxsampleluminance" (film.rs:75,279); +inf = none
-#ifdef PBRT_DEBUG_PIXEL_X  // parity debugging: per-sample radiance of one pixel, to diff against oracle pixel_samples()
-            if (R.sx0 + xr == PBRT_DEBUG_PIXEL_X && R.sy0 + yr == PBRT_DEBUG_PIXEL_Y)
-              printf("SAMPLE %u %08x %08x %08x\n", P.s, __float_as_uint(P.L.x), __float_as_uint(P.L.y), __float_as_uint(P.L.z));
-#endif
+            EXP_DEBUG_PIXEL("SAMPLE %u %08x %08x %08x\n", P.s, __float_as_uint(P.L.x), __float_as_uint(P.L.y), __float_as_uint(P.L.z));  // (to diff against oracle pixel_samples())
             if (WIDE) {
               // FilmTile::AddSample for a box filter of any radius: weight 1 to every pixel of the cropped
               // window within the radius of the sample's film point (kept in the record the default path has its partial
@@ -1139,15 +1079,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
       }
       PROBE_SEC(7);
       path_store(rec, P);
-#ifdef PBRT_RAY_LOG  // experiment: every ray the frame traces, in the order it is launched (tools/raylog_probe.py)
-      if (launch && g_raylog) {
-        const unsigned long long k = atomicAdd(&g_raylog_n, 1ull);
-        if (k < g_raylog_cap) {
-          g_raylog[2 * k] = make_float4(ro.x, ro.y, ro.z, rtmax);
-          g_raylog[2 * k + 1] = make_float4(rd.x, rd.y, rd.z, launch_any ? 1.f : 0.f);
-        }
-      }
-#endif
+      EXP_RAY_LOG(launch, ro, rd, rtmax, launch_any);
       if (launch) trav_begin<EXACT>(S, T, stk, ro, rd, rtmax, launch_any, c_nodes);
     }
     PROBE_SEC(8);
@@ -1158,9 +1090,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
     PROBE_SEC(0);
   }
 
-#ifdef PBRT_PHASE_PROBE
-  if (lane < 23) atomicAdd(&g_probe[lane], s_probe[lane]);
-#endif
+  EXP_PROBE_FINI(lane);
   if (COUNT) {
     unsigned long long v[5] = {c_cam, c_bounce, c_shadow, c_nodes, c_tris};
     for (int i = 0; i < 5; i++) {
@@ -1171,15 +1101,6 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
   }
 }
 
-#ifdef PBRT_PHASE_PROBE
-__global__ void probe_dump() {
-  printf("PROBE step waves %llu lanes %llu | flush waves %llu lanes %llu | service waves %llu lanes %llu | flushes %llu dense passes %llu\n",
-         g_probe[0], g_probe[1], g_probe[2], g_probe[3], g_probe[4], g_probe[5], g_probe[6], g_probe[7]);
-  printf("PROBE wave cycles: traversal %llu | service: records+pixel %llu, shadow return / hit fetch / emission %llu, light sample %llu, bsdf + rr %llu, advance + film %llu, item fetch %llu, camera ray %llu, store + ray start %llu\n",
-         g_probe[8], g_probe[9], g_probe[10], g_probe[11], g_probe[12], g_probe[13], g_probe[14], g_probe[15], g_probe[16]);
-  for (int i = 0; i < 24; i++) g_probe[i] = 0;
-}
-#endif
 #ifndef PBRT_INTERSECT_WAVES_PER_SIMD
 #define PBRT_INTERSECT_WAVES_PER_SIMD 4
 #endif
@@ -1195,10 +1116,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
   uint32_t *ovf = B.stack_overflow + ((size_t)blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * B.stack_overflow_entries * 64u;  // wave-uniform
   const TravTuning tune = {B.min_walkers, B.min_parked};
   unsigned long long cn = 0, ct = 0;
-#ifdef PBRT_PHASE_PROBE
-  if (threadIdx.x < 8) s_probe[threadIdx.x] = 0;  // (thread 0 counts: wave 0 of the block is the sample)
-  __syncthreads();
-#endif
+  EXP_PROBE_INIT_BLOCK();
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t next = (int64_t)blockIdx.x * 256 + threadIdx.x, idx = 0;
   bool have = false;
@@ -1235,9 +1153,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
     if (__ballot(have) == 0ull) break;
     trav_run<COUNT, COUNT, (COUNT ? 0u : kQuadLdsStack)>(S, T, stk, stkt, ovf, have, tune, cn, ct);
   }
-#ifdef PBRT_PHASE_PROBE
-  if (threadIdx.x < 8) atomicAdd(&g_probe[threadIdx.x], s_probe[threadIdx.x]);
-#endif
+  EXP_PROBE_FINI_BLOCK();
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       cn += __shfl_down(cn, off, 64);
@@ -1365,36 +1281,14 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
   if (wide_filter) return sph ? launch_render_wide<true>(S, R, stream) : launch_render_wide<false>(S, R, stream);
-#ifdef PBRT_RAY_LOG
-  if (counters == 0) {
-    const unsigned long long cap = 160ull << 20, zero = 0;
-    float4 *buf = nullptr;
-    if (hipMalloc((void **)&buf, cap * 32) != hipSuccess) return hipErrorOutOfMemory;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raylog), &buf, sizeof(buf));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raylog_cap), &cap, sizeof(cap));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raylog_n), &zero, sizeof(zero));
-    hipError_t e = sph ? launch_render_t<true, false, false>(S, R, n_local_super, bvh_depth, stream)
-                       : launch_render_t<false, false, false>(S, R, n_local_super, bvh_depth, stream);
-    (void)hipStreamSynchronize(stream);
-    unsigned long long n = 0;
-    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_raylog_n), sizeof(n));
-    if (n > cap) n = cap;
-    std::vector<float4> host(2 * n);
-    (void)hipMemcpy(host.data(), buf, n * 32, hipMemcpyDeviceToHost);
-    if (FILE *f = std::fopen("/tmp/raylog.bin", "wb")) { std::fwrite(host.data(), 32, n, f); std::fclose(f); }
-    std::fprintf(stderr, "raylog: %llu rays -> /tmp/raylog.bin\n", n);
-    (void)hipFree(buf);
+  if (counters == 0 && kExperimentLaunch) {  // (ray log / phase probe builds: experiments.inc)
+    hipError_t e = hipSuccess;
+    if (experiment_launch_begin(&e)) return e;
+    e = sph ? launch_render_t<true, false, false>(S, R, n_local_super, bvh_depth, stream)
+            : launch_render_t<false, false, false>(S, R, n_local_super, bvh_depth, stream);
+    experiment_launch_end(stream);
     return e;
   }
-#endif
-#ifdef PBRT_PHASE_PROBE
-  if (counters == 0) {
-    hipError_t e = sph ? launch_render_t<true, false, false>(S, R, n_local_super, bvh_depth, stream)
-                       : launch_render_t<false, false, false>(S, R, n_local_super, bvh_depth, stream);
-    probe_dump<<<1, 1, 0, stream>>>();
-    return e;
-  }
-#endif
   if (counters == 1)
     return sph ? launch_render_t<true, true, true>(S, R, n_local_super, bvh_depth, stream)
                : launch_render_t<false, true, true>(S, R, n_local_super, bvh_depth, stream);
@@ -1412,9 +1306,7 @@ static hipError_t launch_intersect_t(const DevScene &S, const RayBatch &B, bool 
   const dim3 grid((uint32_t)blocks), block(256);
   if (depth <= 32) hipLaunchKernelGGL((intersect_kernel<SPH, COUNT, 32>), grid, block, 0, st, S, B, any_hit ? 1 : 0);
   else hipLaunchKernelGGL((intersect_kernel<SPH, COUNT, 64>), grid, block, 0, st, S, B, any_hit ? 1 : 0);
-#ifdef PBRT_PHASE_PROBE
-  probe_dump<<<1, 1, 0, st>>>();
-#endif
+  if (kExperimentLaunch) experiment_launch_end(st);
   return hipGetLastError();
 }
 

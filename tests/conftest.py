@@ -4,7 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the library reads its tuning / A-B knobs (PBRT_HIP_TWO_PHASE, PBRT_HIP_COLLAPSE, ...) only behind this switch
+# the library reads its tuning / A-B knobs (PBRT_HIP_MIN_WALKERS, PBRT_HIP_COLLAPSE, ...) only behind this switch
 os.environ.setdefault("PBRT_HIP_DEBUG_KNOBS", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -715,7 +715,9 @@ def test_bench_eight_ranks_share_one_gpu_under_gloo(gpu):
                          "--no-cpu-baseline", "--no-counters", "--filter", "1.5", "1.5"], capture_output=True, text=True, cwd=root, timeout=600)
     assert w1.returncode == 0, w1.stderr[-3000:]
     w1 = json.loads([l for l in w1.stdout.splitlines() if l.startswith("{")][-1])
-    assert w8["film_check"]["finite"] and abs(w8["film_check"]["mean_Y"] - w1["film_check"]["mean_Y"]) < 1e-12 and w8["film_check"]["mean_weight"] == 36.0
+    assert w8["film_check"]["finite"] and abs(w8["film_check"]["mean_Y"] - w1["film_check"]["mean_Y"]) < 1e-12
+    # 3 x 3 pixels x 4 spp (a film point x + jx that rounds up to x + 1 in fp32 reaches one pixel further: a few per thousand)
+    assert w8["film_check"]["mean_weight"] == w1["film_check"]["mean_weight"] and abs(w8["film_check"]["mean_weight"] - 36.0) < 0.01
 
 
 # ---- box filter radii other than 0.5 and Film "maxsampleluminance"  ----
