@@ -478,6 +478,50 @@ void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split
   }
 }
 
+// A-B aid (PBRT_HIP_QUAD_LAYOUT=pre|pre_big behind the debug switch): renumber the quad nodes in depth-first PRE-order, so
+// that a node and the first interior child visited after it share a 128-byte line (the collapse above keeps SIBLINGS
+// together instead: a family is one or two lines).  pre: children in slot order; pre_big: the child with the largest box
+// first.  The tree, and so every result, is unchanged.
+void relayout_quads(QuadNodes *q, bool big_first) {
+  const size_t n = q->q.size() / 4;
+  if (n < 2) return;
+  auto area = [&](size_t node, int k) {
+    const uint4 *w = &q->q[4 * node];
+    auto byte = [](uint32_t v, int i) { return (float)((v >> (8 * i)) & 0xffu); };
+    float cx, cy, cz;
+    std::memcpy(&cx, &w[0].w, 4); std::memcpy(&cy, &w[2].z, 4); std::memcpy(&cz, &w[2].w, 4);
+    const float dx = (byte(w[1].w, k) - byte(w[1].x, k)) * cx, dy = (byte(w[2].x, k) - byte(w[1].y, k)) * cy, dz = (byte(w[2].y, k) - byte(w[1].z, k)) * cz;
+    return (dx * dy + dx * dz) + dy * dz;
+  };
+  std::vector<uint32_t> new_of(n, 0xffffffffu), order;
+  order.reserve(n);
+  std::vector<uint32_t> st = {0u};
+  while (!st.empty()) {
+    const uint32_t me = st.back();
+    st.pop_back();
+    new_of[me] = (uint32_t)order.size();
+    order.push_back(me);
+    const uint32_t ref[4] = {q->q[4 * (size_t)me + 3].x, q->q[4 * (size_t)me + 3].y, q->q[4 * (size_t)me + 3].z, q->q[4 * (size_t)me + 3].w};
+    int ks[4], m = 0;
+    for (int k = 0; k < 4; k++)
+      if (!(ref[k] & kLeafRef)) ks[m++] = k;
+    if (big_first) std::sort(ks, ks + m, [&](int a, int b) { return area(me, a) > area(me, b); });
+    for (int i = m - 1; i >= 0; i--) st.push_back(ref[ks[i]] / 64u);  // (the first of ks is popped next: it follows its parent)
+  }
+  std::vector<uint4> nq(q->q.size());
+  std::vector<float> ne(q->exact.size());
+  for (size_t i = 0; i < n; i++) {
+    const size_t o = order[i];
+    for (int w = 0; w < 4; w++) nq[4 * i + w] = q->q[4 * o + w];
+    uint32_t *r = &nq[4 * i + 3].x;
+    for (int k = 0; k < 4; k++)
+      if (!(r[k] & kLeafRef)) r[k] = new_of[r[k] / 64u] * 64u;
+    if (!ne.empty()) std::memcpy(&ne[24 * i], &q->exact[24 * o], 24 * sizeof(float));
+  }
+  q->q.swap(nq);
+  q->exact.swap(ne);
+}
+
 // The tree the walk gets: the quantisation-aware dynamic-programming collapse for trees of 1024 triangles and more, the
 // greedy one below that.  Measured (r02f kernel): dp is 2.5 % faster on C3 (433 k instead of 488 k nodes, 40.2 instead of 41.0
 // fetches per ray), 1.6 % on C2, 3.1 % on the 12 M-triangle workload, but 2 % slower on C4's 19-node tree; its build takes a
@@ -492,6 +536,10 @@ void make_quad_nodes(const RefBvh &b, const uint32_t *slot_of_ref, bool split_le
   else if (c && std::strcmp(c, "dp") == 0) how = kCollapseDp;
   else if (c && std::strcmp(c, "greedy") == 0) how = kCollapseGreedy;
   make_quad_nodes_as(b, slot_of_ref, split_leaves, how, out);
+  if (const char *l = debug_knob("PBRT_HIP_QUAD_LAYOUT")) {
+    if (std::strcmp(l, "pre") == 0) relayout_quads(out, false);
+    else if (std::strcmp(l, "pre_big") == 0) relayout_quads(out, true);
+  }
 }
 
 // The production walk's 4-wide tree of a triangle soup.  `tree` picks the binary tree it is collapsed from: kTreeCanonical
