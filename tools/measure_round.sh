@@ -13,6 +13,7 @@ WLS=${@:-c3 big}
 O=$R/gpurun_out
 cd $R
 export PBRT_HIP_DEBUG_KNOBS=1
+export PROBE_BUILDER=gpu   # the probes use the builder bench.py's default does (the device builder)
 timeout 1800 python3 -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -4 > $O/${TAG}_pytest_gpu.log
 python3 -c "from oracle import binding as ob; ob.build(native=True)"   # (the CPU leg's oracle is built before any profiler runs)
 for w in $WLS; do
@@ -24,7 +25,14 @@ for w in $WLS; do
   # PMC on the workload's own frame (C3: 512 spp, big: 64): the chunk count and so the hand-out granularity follow the sample count
   if [ $w = c3 ]; then bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 32 16 > $O/pmc_${TAG}_${w}.log 2>&1; else bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 8 8 > $O/pmc_${TAG}_${w}.log 2>&1; fi
 done
-for w in c3 c2 c1 c4 big; do
+# the headline with the DRIVER's arguments, clocks logged beside it; the other workloads with 2 timed steps
+( while true; do date +%s.%N; rocm-smi --showclocks 2>/dev/null | grep -i "sclk"; sleep 2; done ) > $O/clocks_${TAG}.txt 2>&1 &
+CL=$!
+timeout 1800 python3 bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3_${TAG}.json 2> $O/bench_c3_${TAG}.err
+kill $CL
+for w in c2 c1 c4 big; do
   timeout 1200 python3 bench.py --workload $w --steps 2 --warmup 1 > $O/bench_${w}_${TAG}.json 2> $O/bench_${w}_${TAG}.err
 done
+timeout 900 python3 bench.py --workload c3 --steps 2 --warmup 1 --builder host --no-cpu-baseline > $O/bench_c3_hostbuilder_${TAG}.json 2> $O/bench_c3_hostbuilder_${TAG}.err
+bash tools/rank_shares.sh > $O/rank_shares_${TAG}.txt 2>&1
 tail -n 2 $O/${TAG}_pytest_gpu.log; cat $O/bench_c3_${TAG}.json
