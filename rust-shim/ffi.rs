@@ -26,7 +26,8 @@ use std::os::raw::{c_char, c_int, c_void};
     pub integrator: u32, pub max_depth: u32, pub spp_x: u32, pub spp_y: u32,
     pub seed: u64, pub rank: u32, pub world_size: u32, pub flags: u32,
     pub sampler: u32,                                // 0 stratified, 1 the (0,2)-sequence sampler
-    pub filter_xwidth: f32, pub filter_ywidth: f32,  // box filter radii; 0 = 0.5; anything else is refused
+    pub filter_xwidth: f32, pub filter_ywidth: f32,  // box filter radii (box.rs:57-61); 0 = 0.5; any radius in (0, 16]
+    pub max_sample_luminance: f32,                   // Film "maxsampleluminance" (film.rs:75,279); 0 = no bound
 }
 #[repr(C)] #[derive(Default)] pub struct HipStats {
     pub camera_rays: u64, pub bounce_rays: u64, pub shadow_rays: u64,
@@ -80,10 +81,12 @@ fn world_end(&mut self) {
                              max_depth: ro.integrator_params.find_one_int("maxdepth", 5) as u32,
                              spp_x, spp_y, seed: 0, rank: 0, world_size: 1, flags: 0,
                              sampler: if ro.sampler_name == "stratified" { 0 } else { 1 },
-                             filter_xwidth: filter.radius.x, filter_ywidth: filter.radius.y };
+                             filter_xwidth: filter.radius.x, filter_ywidth: filter.radius.y,
+                             max_sample_luminance: if max_lum.is_finite() { max_lum } else { 0. } };
     let n_gpus = unsafe { pbrt_hip_device_count() };   // all of them: 8 on an MI355X node
     let mut stats = vec![HipStats::default(); n_gpus.max(1) as usize];
-    let rc = unsafe { pbrt_hip_render_multi(&desc, &rd, n_gpus, xyzw.as_mut_ptr(), stats.as_mut_ptr()) };
+    // n_gpus = 0: every visible GPU (no more than the film has 64x64 super-tiles); the accelerator is built on the device
+    let rc = unsafe { pbrt_hip_render_multi(&desc, &rd, 0, xyzw.as_mut_ptr(), stats.as_mut_ptr()) };
     if rc != 0 { error!("pbrt_hip_render_multi: {}", hip_last_error()); return; }   // api.rs:291-332 style: log, continue
 
     // xyzw is Film.pixels AFTER merge_film_tile (film.rs:313-326): {xyz, filter_weight_sum}
