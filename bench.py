@@ -265,6 +265,7 @@ def main():
         scene.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, rank=rank, world_size=world,
                             counters=True, **kw)
         cst = scene.render_wait()
+        info = scene.info()  # (a device-built scene has its canonical tree -- node count, depth -- only now)
         bps = algorithmic_bytes_per_sample(cst, cst["samples"], spp[0] * spp[1])
         alg_bytes = bps * local_samples  # per launch of this rank's kernel
         ach = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
