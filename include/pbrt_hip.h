@@ -85,9 +85,13 @@ typedef struct {
                                         child-pair records fetched, tris_tested = triangles tested */
 
 #define PBRT_HIP_SAMPLER_STRATIFIED 0 /* Sampler "stratified" (north_star's sampler) */
-#define PBRT_HIP_SAMPLER_SOBOL 1      /* Sampler "sobol" / "halton" / "02sequence" / "lowdiscrepancy": the (0,2)-sequence
+#define PBRT_HIP_SAMPLER_SOBOL 1      /* Sampler "halton" / "02sequence" / "lowdiscrepancy": the (0,2)-sequence
                                          sampler of DESIGN.md 3.10 (the reference holds only the names, api.rs:235, and the
                                          generator matrices, sobolmatrices.rs:81) */
+#define PBRT_HIP_SAMPLER_SOBOL_ND 2   /* Sampler "sobol": Sobol' proper -- request j of a sample takes its own dimensions (2j, 2j + 1)
+                                         of the first ten of the reference's table (sobolmatrices.rs:81), later requests the
+                                         padded scheme of sampler 1.  Not with the counter flags, not with a box
+                                         filter radius other than 0.5 */
 #define PBRT_HIP_MAX_SPP (1u << 20)   /* spp_x * spp_y: the kernels pack the sample index into 20 bits */
 #define PBRT_HIP_MAX_DEPTH 1023u      /* max_depth: the bounce count is packed into 10 bits */
 
@@ -212,6 +216,9 @@ int64_t pbrt_hip_render_buffer_bytes(const pbrt_hip_scene *scene, const pbrt_hip
 int pbrt_hip_render_acc(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, int64_t *acc, pbrt_hip_stats *stats);
 int pbrt_hip_film_from_acc_device(const pbrt_hip_scene *scene, const void *d_acc, void *d_film_xyzw, void *stream);
 void pbrt_hip_film_from_acc(const int64_t *acc, int64_t n_pixels, float *film_xyzw);
+/* host only: the generator matrices sampler 2 uses -- 10 dimensions x 32 columns, rows 0 .. 9 of the reference's
+ * SOBOL_MATRICES32 (sobolmatrices.rs:81) -- for tests of that claim */
+void pbrt_hip_sobol_matrices(uint32_t *out_320_words);
 /* host-side geometry of the sharding (no device needed) */
 int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world_size);
 /* for every float4 slot of a rank's slab the row-major pixel index inside the cropped film, or -1 */

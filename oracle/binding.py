@@ -281,7 +281,7 @@ class OracleScene:
     def _rd(self, integrator, max_depth, spp, seed, rank, world_size, sampler=0, filter_width=None, max_sample_luminance=0.0):
         r = RenderDesc(); r.integrator = integrator; r.max_depth = max_depth; r.spp_x, r.spp_y = spp
         r.seed = seed; r.rank = rank; r.world_size = world_size
-        r.sampler = {"stratified": 0, "sobol": 1}.get(sampler, sampler)
+        r.sampler = {"stratified": 0, "sobol": 1, "sobol_nd": 2}.get(sampler, sampler)
         if filter_width is not None:
             r.filter_xwidth, r.filter_ywidth = filter_width
         r.max_sample_luminance = max_sample_luminance

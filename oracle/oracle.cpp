@@ -173,7 +173,7 @@ class SobolSampler : public Sampler {
   }
   void StartNextSample() override { ++s_; j_ = 0; }
 
- private:
+ protected:
   uint32_t spp_, log2_ = 0;
   uint64_t seed_, w_, h_;
   int pad_x_, pad_y_;
@@ -181,6 +181,35 @@ class SobolSampler : public Sampler {
   uint32_t key_ = 0, j_ = 0;
   int px_ = 0, py_ = 0;
   uint32_t s_ = 0, s_end_ = 0;
+};
+
+// Sobol' sampler proper (Sampler "sobol"): request j of a sample takes ITS OWN pair of Sobol' dimensions
+// (2j, 2j + 1) for j = 0 .. 4 -- the ten dimensions whose generator matrices are pinned to the reference's SOBOL_MATRICES32
+// (sobolmatrices.rs:81) -- at point index i = the sample number, each coordinate XOR-scrambled with mix32(key + (d + 1) *
+// 0x9e3779b9), d the dimension; later requests (j >= 5: the second bounce's BSDF sample onwards) are the padded
+// (0,2)-sequence requests of 3.10 with the same request counter.  Integer arithmetic only.
+class SobolNdSampler : public SobolSampler {
+ public:
+  SobolNdSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s, int pad_x = 0, int pad_y = 0) : SobolSampler(nx, ny, seed, s, pad_x, pad_y) {
+    for (int d = 0; d < kSobolDims; d++) sobol_matrix(d, m_[d]);
+  }
+  void Get2D(float *u1, float *u2) override {
+    if (j_ >= 5u) { SobolSampler::Get2D(u1, u2); return; }
+    const float one_minus_eps = 1.0f - std::numeric_limits<float>::epsilon();
+    const uint32_t d0 = 2u * j_;
+    j_++;
+    uint32_t x = 0, y = 0;
+    for (uint32_t b = 0; b < 32 && (s_ >> b) != 0u; b++)
+      if ((s_ >> b) & 1u) { x ^= m_[d0][b]; y ^= m_[d0 + 1][b]; }
+    x ^= mix32(key_ + (d0 + 1u) * 0x9e3779b9u);
+    y ^= mix32(key_ + (d0 + 2u) * 0x9e3779b9u);
+    const float f1 = (float)x * 2.3283064365386963e-10f, f2 = (float)y * 2.3283064365386963e-10f;
+    *u1 = f1 > one_minus_eps ? one_minus_eps : f1;
+    *u2 = f2 > one_minus_eps ? one_minus_eps : f2;
+  }
+
+ private:
+  uint32_t m_[kSobolDims][kSobolColumns];
 };
 
 // pbrt-v3 ConcentricSampleDisk with the fixed polynomials instead of libm sin/cos
@@ -448,7 +477,8 @@ static void render_pixel_wide(const Scene &s, const PathIntegrator &integ, const
                               int64_t *acc, RayStats &st) {
   StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
   SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
-  Sampler &sampler = r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat;
+  SobolNdSampler sobol_nd(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
+  Sampler &sampler = r.sampler == 2 ? (Sampler &)sobol_nd : (r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat);
   const int W = s.cropped[2] - s.cropped[0];
   for (uint32_t c = 0, n_chunks = sample_chunks(r.spp_x * r.spp_y); c < n_chunks; c++)
     for (sampler.StartChunk(x, y, c); !sampler.ChunkDone(); sampler.StartNextSample()) {
@@ -480,7 +510,8 @@ static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_
                          float out_xyzw[4], float *per_sample, RayStats &st) {
   StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s);
   SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s);
-  Sampler &sampler = r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat;
+  SobolNdSampler sobol_nd(r.spp_x, r.spp_y, r.seed, s);
+  Sampler &sampler = r.sampler == 2 ? (Sampler &)sobol_nd : (r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat);
   Vec3 sum = {0, 0, 0};
   uint32_t i = 0;
   for (uint32_t c = 0, n_chunks = sample_chunks(r.spp_x * r.spp_y); c < n_chunks; c++) {
@@ -678,7 +709,7 @@ void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int
 // fixed-point accumulators of DESIGN.md 3.11 over the sample bounds
 static int render_any(const orc_scene *sc, const orc_render_desc *r, float *film, int64_t *acc, orc_stats *out, int n_threads) {
   const Scene &s = sc->s;
-  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 1) return -1;
+  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 2) return -1;
   if (!(filter_radius(r->filter_xwidth) > 0.f) || !(filter_radius(r->filter_ywidth) > 0.f)) return -1;
   PathIntegrator integ(s, r->max_depth, r->integrator == 1);
   const WideFilter wf = wide_filter(s, *r);

@@ -70,7 +70,7 @@ typedef struct {
   uint64_t seed;
   uint32_t rank, world_size; /* which 64x64 super-tiles to render (t % world == rank) */
   uint32_t flags;
-  uint32_t sampler;    /* 0 = stratified, 1 = padded (0,2)-sequence "sobol" (3.10) */
+  uint32_t sampler;    /* 0 = stratified, 1 = padded (0,2)-sequence (3.10), 2 = Sobol' with its own dimensions per request (3.12) */
   float filter_xwidth, filter_ywidth; /* box filter radii (box.rs:57-61); 0 = the default 0.5.  Other radii: DESIGN.md 3.11 */
   float max_sample_luminance;         /* Film "maxsampleluminance" (film.rs:75,279); 0 = infinity */
 } orc_render_desc;

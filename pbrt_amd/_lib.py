@@ -74,6 +74,7 @@ SYMBOLS = {
     "pbrt_hip_render_acc": (C.c_int, [_vp, C.POINTER(RenderDesc), _pi64, C.POINTER(Stats)]),
     "pbrt_hip_film_from_acc_device": (C.c_int, [_vp, _vp, _vp, _vp]),
     "pbrt_hip_film_from_acc": (None, [_pi64, _i64, _pf]),
+    "pbrt_hip_sobol_matrices": (None, [_pu32]),
     "pbrt_hip_slab_floats": (_i64, [_i32, _i32, _pf, _u32, _u32]),
     "pbrt_hip_slab_pixel_index": (C.c_int, [_i32, _i32, _pf, _u32, _u32, _pi64]),
     "pbrt_hip_multi_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, _u32, C.POINTER(_vp)]),

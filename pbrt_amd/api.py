@@ -97,7 +97,7 @@ def fill_desc(desc, sd, mat_t, light_t, sphere_t):
     return [mats, lights, spheres, sd]
 
 
-SAMPLERS = {"stratified": 0, "sobol": 1}
+SAMPLERS = {"stratified": 0, "sobol": 1, "sobol_nd": 2}  # "sobol": the padded (0,2)-sequence sampler (3.10); "sobol_nd": Sobol' proper (3.12)
 
 
 def make_render_desc(desc_t, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
@@ -230,6 +230,13 @@ def film_from_acc(acc):
     film = np.zeros(a.shape[:-1] + (4,), np.float32)
     lib().pbrt_hip_film_from_acc(a.ctypes.data_as(C.POINTER(C.c_int64)), a.size // 4, _fp(film))
     return film
+
+
+def sobol_matrices():
+    """pbrt_hip_sobol_matrices: (10, 32) uint32 generator matrices of sampler 2 (host only)"""
+    out = np.zeros((10, 32), np.uint32)
+    lib().pbrt_hip_sobol_matrices(_u32p(out))
+    return out
 
 
 def slab_pixel_index(xres, yres, crop, rank, world_size):

@@ -971,7 +971,9 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (r->spp_x == 0 || r->spp_y == 0) return fail(PBRT_HIP_ERR_INVALID, "render: spp_x and spp_y must be >= 1");
   if (r->world_size == 0 || r->rank >= r->world_size) return fail(PBRT_HIP_ERR_INVALID, "render: rank must be < world_size");
   if (r->integrator > 1) return fail(PBRT_HIP_ERR_INVALID, "render: unknown integrator");
-  if (r->sampler > PBRT_HIP_SAMPLER_SOBOL) return fail(PBRT_HIP_ERR_INVALID, "render: unknown sampler");
+  if (r->sampler > PBRT_HIP_SAMPLER_SOBOL_ND) return fail(PBRT_HIP_ERR_INVALID, "render: unknown sampler");
+  if (r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
+    return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags are not available with the Sobol' sampler (sampler 2)");
   // the kernels pack the sample index into 20 bits and the bounce count into 10 (kernels.hip path_store): beyond that a
   // persistent wave would never see its pixel finish
   if ((uint64_t)r->spp_x * (uint64_t)r->spp_y > PBRT_HIP_MAX_SPP)
@@ -983,6 +985,8 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (fx > 16.f || fy > 16.f) return fail(PBRT_HIP_ERR_LIMIT, "render: filter radius above 16 pixels");
   if ((fx != 0.5f || fy != 0.5f) && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
     return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags need the default box filter (radius 0.5)");
+  if ((fx != 0.5f || fy != 0.5f) && r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND)
+    return fail(PBRT_HIP_ERR_LIMIT, "render: the Sobol' sampler (sampler 2) with a box filter radius other than 0.5 is not instantiated");
   if (!(r->max_sample_luminance >= 0.f)) return fail(PBRT_HIP_ERR_INVALID, "render: max_sample_luminance must be >= 0 (0 = none)");
   return PBRT_HIP_OK;
 }
@@ -1005,6 +1009,17 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.max_lum = r->max_sample_luminance > 0.f ? r->max_sample_luminance : std::numeric_limits<float>::infinity();
     R.filter_rx = fg.rx; R.filter_ry = fg.ry;
     R.acc = fg.wide ? (unsigned long long *)d_slab : nullptr;
+    R.sobol_mat = nullptr;
+    const bool sobol_nd = r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND;
+    if (sobol_nd) {
+      if (s->d_sobol.n == 0) {
+        uint32_t mat[kSobolNdDims * 32];
+        sobol_nd_matrices(mat);
+        HIP_TRY(s->d_sobol.alloc(kSobolNdDims * 32));
+        HIP_TRY(hipMemcpy(s->d_sobol.p, mat, sizeof(mat), hipMemcpyHostToDevice));
+      }
+      R.sobol_mat = s->d_sobol.p;
+    }
     R.integrator = r->integrator;
     R.max_depth = r->max_depth;
     R.spp_x = r->spp_x;
@@ -1037,7 +1052,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
     const RenderStackPlan plan = render_stack_plan(s->dev.quad_stack_need, render_force_overflow(), render_prefer_lds());
     // (so does the kernel for a box filter radius other than 0.5)
-    const uint32_t waves_per_cu = (s->dev.n_spheres || fg.wide) ? std::min(kRenderWavesPerCuSpheres, plan.waves_per_cu) : plan.waves_per_cu;
+    const uint32_t waves_per_cu = (s->dev.n_spheres || fg.wide || sobol_nd) ? std::min(kRenderWavesPerCuSpheres, plan.waves_per_cu) : plan.waves_per_cu;
     R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
     R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
@@ -1074,7 +1089,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     HIP_TRY(hipEventRecord(s->ev0, st));
     // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order (a wide
     // filter has no partial sums: its samples go straight into the accumulators)
-    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, st));
+    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, sobol_nd, st));
     if (!fg.wide) HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
@@ -1154,6 +1169,8 @@ int pbrt_hip_render(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, float *fil
   }
   return pbrt_hip_render_wait(s, stats);
 }
+
+void pbrt_hip_sobol_matrices(uint32_t *out) { sobol_nd_matrices(out); }
 
 int64_t pbrt_hip_render_buffer_bytes(const pbrt_hip_scene *s, const pbrt_hip_render_desc *r) {
   if (!s || !r || r->world_size == 0 || r->rank >= r->world_size) return -1;

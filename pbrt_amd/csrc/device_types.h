@@ -151,6 +151,8 @@ struct RenderParams {
   // pixel of the cropped window, added to with atomics
   float filter_rx, filter_ry;
   unsigned long long *acc;
+  // sampler 2 (render_kernel<..., SND>): generator matrices of the first ten Sobol' dimensions, 32 columns each
+  const uint32_t *sobol_mat;
 };
 // 2^24 fixed-point units per unit of radiance, a component clamped to [0, 2^15]
 constexpr float kFixedOne = 16777216.0f, kFixedMax = 32768.0f;
@@ -170,7 +172,7 @@ struct RayBatch {
 
 // launchers (kernels.hip)
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         int counters /* 0 none, 1 exact walk, 2 production walk */, bool wide_filter, hipStream_t stream);
+                         int counters /* 0 none, 1 exact walk, 2 production walk */, bool wide_filter, bool sobol_nd, hipStream_t stream);
 // fixed-point accumulators -> film pixels {X, Y, Z, weight}
 hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, size_t n_px, hipStream_t stream);
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);

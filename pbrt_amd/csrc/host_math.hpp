@@ -101,4 +101,29 @@ inline uint8_t to_byte(float v) {
   return (uint8_t)q;
 }
 
+// Generator matrices of the first ten Sobol' dimensions, 32 columns each: dimension 0 is the van der
+// Corput sequence (column b = bit 31 - b); dimension d >= 1 from the Joe-Kuo direction numbers (S. Joe, F. Y. Kuo 2008, table
+// new-joe-kuo-6: degree s, coefficient bits a, initial numbers m_1 .. m_s; m_i = XOR_{k=1..s-1} a_k 2^k m_{i-k} ^ 2^s m_{i-s} ^
+// m_{i-s}; column i = m_i << (32 - i)).  These are rows 0 .. 9 of the reference's SOBOL_MATRICES32 (sobolmatrices.rs:81, 52
+// columns per dimension, of which a 2^20-sample pixel needs 20); tests compare them with the oracle's own construction.
+constexpr int kSobolNdDims = 10;
+inline void sobol_nd_matrices(uint32_t out[kSobolNdDims * 32]) {
+  static const struct { uint32_t s, a, m[5]; } jk[kSobolNdDims - 1] = {
+      {1, 0, {1}}, {2, 1, {1, 3}}, {3, 1, {1, 3, 1}}, {3, 2, {1, 1, 1}}, {4, 1, {1, 1, 3, 3}},
+      {4, 4, {1, 3, 5, 13}}, {5, 2, {1, 1, 5, 5, 17}}, {5, 4, {1, 1, 5, 5, 5}}, {5, 7, {1, 1, 7, 11, 19}}};
+  for (int b = 0; b < 32; b++) out[b] = 1u << (31 - b);
+  for (int d = 1; d < kSobolNdDims; d++) {
+    const uint32_t s = jk[d - 1].s, a = jk[d - 1].a;
+    uint64_t m[33];
+    for (uint32_t i = 1; i <= s; i++) m[i] = jk[d - 1].m[i - 1];
+    for (uint32_t i = s + 1; i <= 32; i++) {
+      uint64_t v = m[i - s] ^ (m[i - s] << s);
+      for (uint32_t k = 1; k < s; k++)
+        if ((a >> (s - 1 - k)) & 1u) v ^= m[i - k] << k;
+      m[i] = v;
+    }
+    for (uint32_t i = 1; i <= 32; i++) out[d * 32 + (i - 1)] = (uint32_t)(m[i] << (32 - i));
+  }
+}
+
 }  // namespace pbrt_hip

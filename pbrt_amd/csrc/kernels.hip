@@ -713,10 +713,26 @@ __device__ __forceinline__ uint32_t mix32(uint32_t v) {  // lowbias32
 // One 2-D request of the sample in flight.  Sobol: point (s ^ mask_j) of the first two Sobol' dimensions -- the
 // van der Corput sequence (bit reversal) and the dimension whose generator matrix has the columns v, v ^ v >> 1, ...
 // (Joe-Kuo s = 1, a = 0, m = 1) -- XOR-scrambled with keys hashed from the pixel and the request number j.
-__device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const uint32_t spp_mask, float &u1, float &u2) {
+// SND (sampler 2): requests 0 .. 4 of a sample take their own Sobol' dimensions (2j, 2j + 1) from the
+// generator matrices in `mat` at point index s, XOR-scrambled per dimension; later requests are the padded ones below.
+template <bool SND = false>
+__device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const uint32_t spp_mask, float &u1, float &u2, const uint32_t *mat = nullptr) {
   if (!sobol) {
     u1 = pcg_float(P.rng);
     u2 = pcg_float(P.rng);
+    return;
+  }
+  if (SND && (uint32_t)(P.rng.state >> 32) < 5u) {
+    const uint32_t key = (uint32_t)P.rng.state, d0 = 2u * (uint32_t)(P.rng.state >> 32);
+    P.rng.state += 1ull << 32;  // next request
+    const uint32_t *m0 = mat + d0 * 32u;
+    uint32_t x = 0u, y = 0u;
+    for (uint32_t k = P.s, b = 0u; k != 0u; k >>= 1, b++)
+      if (k & 1u) { x ^= m0[b]; y ^= m0[32u + b]; }
+    x ^= mix32(key + (d0 + 1u) * 0x9e3779b9u);
+    y ^= mix32(key + (d0 + 2u) * 0x9e3779b9u);
+    u1 = fminf(kOneMinusEps, (float)x * 2.3283064365386963e-10f);
+    u2 = fminf(kOneMinusEps, (float)y * 2.3283064365386963e-10f);
     return;
   }
   const uint32_t a = mix32((uint32_t)P.rng.state + (uint32_t)(P.rng.state >> 32) * 0x9e3779b9u);
@@ -730,10 +746,11 @@ __device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const 
   u1 = fminf(kOneMinusEps, (float)x * 2.3283064365386963e-10f);
   u2 = fminf(kOneMinusEps, (float)y * 2.3283064365386963e-10f);
 }
-__device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const uint32_t spp_mask) {
+template <bool SND = false>
+__device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const uint32_t spp_mask, const uint32_t *mat = nullptr) {
   if (!sobol) return pcg_float(P.rng);
   float u1, u2;
-  sample_2d(P, true, spp_mask, u1, u2);
+  sample_2d<SND>(P, true, spp_mask, u1, u2, mat);
   return u1;
 }
 
@@ -745,10 +762,11 @@ __device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const
 // in the HBM overflow area), or 0 = the whole stack in LDS.
 // WIDE: a box filter radius other than 0.5: a sample is added to every pixel within the radius, into
 // fixed-point accumulators with atomics, instead of to its chunk's partial sum.
-template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK, bool WIDE = false>
+// SND: sampler 2, the Sobol' sampler with its own dimensions per request (3.12): generator-matrix lookups in the service stage.
+template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK, bool WIDE = false, bool SND = false>
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
-__global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
+__global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE || SND) ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
   // the walk's stack, rows of 64 lanes x 4 bytes as dynamic shared memory: the launch sizes it per scene (render_stack_plan;
   // exact walk: STACK rows of refs followed by STACK rows of entry distances)
   extern __shared__ uint32_t lds_stack[];
@@ -780,7 +798,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
   auto slab_pos = [](uint32_t q) {
     return (size_t)(q >> 12) * 4096u + (((q >> 9) & 7u) * 8u + ((q >> 3) & 7u)) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u);
   };
-  const bool sobol = R.sampler == 1u;
+  const bool sobol = SND ? true : R.sampler == 1u;  // (both low-discrepancy samplers keep {pixel key, request counter} in rng.state)
   const uint32_t spp = R.spp_x * R.spp_y;
   const uint32_t spp_mask = R.spp_mask;  // Sobol: 2^ceil(log2 spp) - 1
   const uint32_t nL = S.n_lights;
@@ -876,9 +894,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
             bool alive = true;
             if (__float_as_uint(m0.x) == 0u) {  // matte
               if (nL > 0u) {
-                const float xi = sample_1d(P, sobol, spp_mask);
+                const float xi = sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat);
                 float u1, u2;
-                sample_2d(P, sobol, spp_mask, u1, u2);
+                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat);
                 uint32_t li = (uint32_t)(xi * nLf);
                 li = min(li, nL - 1u);
                 V3 Ld;
@@ -893,7 +911,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
                 alive = false;
               } else {
                 float u1, u2;
-                sample_2d(P, sobol, spp_mask, u1, u2);
+                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat);
                 const float z = cosine_about(nf, u1, u2, P.wi_next);
                 EXP_DEBUG_PIXEL("HIP s %u   cos u1 %a u2 %a z %a nf %a %a %a wi %a %a %a\n", P.s, u1, u2, z, nf.x, nf.y, nf.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
                 if (z == 0.f) alive = false;
@@ -909,7 +927,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
             if (alive && P.bounces > 3u) {
               const float mx = fmaxf(P.beta.x, fmaxf(P.beta.y, P.beta.z));
               const float q = fmaxf(0.05f, 1.0f - mx);
-              if (sample_1d(P, sobol, spp_mask) < q) alive = false;
+              if (sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat) < q) alive = false;
               else P.beta = P.beta / (1.0f - q);
             }
             P.cont = alive;
@@ -1049,7 +1067,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE) ? 3 : PBRT_REN
         if (true) {
           // stratified camera sample and PerspectiveCamera ray (3.2)
           float u1, u2;
-          sample_2d(P, sobol, spp_mask, u1, u2);
+          sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat);
           float jx = u1, jy = u2;  // Sobol: the (0,2)-net point is the film offset
           if (!sobol) {
             // P.s / spp_x by R.spp_x_recip = ceil(2^32 / spp_x): the estimate is the quotient or one more
@@ -1235,16 +1253,17 @@ hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, siz
   return hipGetLastError();
 }
 
-// a box filter radius other than 0.5: the WIDE instantiations of the production walk (no counting variants)
-template <bool SPH>
-static hipError_t launch_render_wide(const DevScene &S, const RenderParams &R, hipStream_t st) {
+// the variants of the production walk outside the default path (no counting instantiations): WIDE = a box filter radius
+// other than 0.5 (3.11), SND = the Sobol' sampler with its own dimensions per request (3.12)
+template <bool SPH, bool WIDE, bool SND>
+static hipError_t launch_render_variant(const DevScene &S, const RenderParams &R, hipStream_t st) {
   const dim3 grid(R.n_workgroups), block(64);
   const RenderStackPlan plan = render_stack_plan(S.quad_stack_need, render_force_overflow(), render_prefer_lds());
   const uint32_t lds = plan.rows * 256u;
   if (plan.overflow && plan.rows == kQuadLdsStackOvfDeep && kQuadLdsStackOvfDeep != kQuadLdsStackOvf)
-    hipLaunchKernelGGL((render_kernel<SPH, false, false, (int)kQuadLdsStackOvfDeep, PBRT_STEPS_PER_CHECK, true>), grid, block, lds, st, S, R);
-  else if (plan.overflow) hipLaunchKernelGGL((render_kernel<SPH, false, false, (int)kQuadLdsStackOvf, PBRT_STEPS_PER_CHECK, true>), grid, block, lds, st, S, R);
-  else hipLaunchKernelGGL((render_kernel<SPH, false, false, 0, PBRT_STEPS_PER_CHECK, true>), grid, block, lds, st, S, R);
+    hipLaunchKernelGGL((render_kernel<SPH, false, false, (int)kQuadLdsStackOvfDeep, PBRT_STEPS_PER_CHECK, WIDE, SND>), grid, block, lds, st, S, R);
+  else if (plan.overflow) hipLaunchKernelGGL((render_kernel<SPH, false, false, (int)kQuadLdsStackOvf, PBRT_STEPS_PER_CHECK, WIDE, SND>), grid, block, lds, st, S, R);
+  else hipLaunchKernelGGL((render_kernel<SPH, false, false, 0, PBRT_STEPS_PER_CHECK, WIDE, SND>), grid, block, lds, st, S, R);
   return hipGetLastError();
 }
 
@@ -1277,10 +1296,12 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
 }
 
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         int counters, bool wide_filter, hipStream_t stream) {
+                         int counters, bool wide_filter, bool sobol_nd, hipStream_t stream) {
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
-  if (wide_filter) return sph ? launch_render_wide<true>(S, R, stream) : launch_render_wide<false>(S, R, stream);
+  if (wide_filter && sobol_nd) return hipErrorInvalidValue;  // (not instantiated: refused by check_render_desc)
+  if (wide_filter) return sph ? launch_render_variant<true, true, false>(S, R, stream) : launch_render_variant<false, true, false>(S, R, stream);
+  if (sobol_nd) return sph ? launch_render_variant<true, false, true>(S, R, stream) : launch_render_variant<false, false, true>(S, R, stream);
   if (counters == 0 && kExperimentLaunch) {  // (ray log / phase probe builds: experiments.inc)
     hipError_t e = hipSuccess;
     if (experiment_launch_begin(&e)) return e;

@@ -767,10 +767,11 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
           // "random" and anything unknown by the stratified one; pixelsamples = spp_x * spp_y either way
           auto s = strata_for(ps.one_int("pixelsamples", 16));
           out->spp_x = s.first; out->spp_y = s.second;
-          if (name == "halton" || name == "sobol" || name == "02sequence" || name == "lowdiscrepancy" || name == "zerotwosequence" ||
-              name == "maxmindist") {
+          if (name == "sobol") {
+            out->sampler = PBRT_HIP_SAMPLER_SOBOL_ND;  // Sobol' proper: own dimensions per request
+          } else if (name == "halton" || name == "02sequence" || name == "lowdiscrepancy" || name == "zerotwosequence" || name == "maxmindist") {
             out->sampler = PBRT_HIP_SAMPLER_SOBOL;
-            if (name != "sobol" && name != "02sequence" && name != "lowdiscrepancy" && name != "zerotwosequence")
+            if (name != "02sequence" && name != "lowdiscrepancy" && name != "zerotwosequence")
               api.warn("Sampler \"" + name + "\": served by the (0,2)-sequence (Sobol') sampler");
           } else {
             out->sampler = PBRT_HIP_SAMPLER_STRATIFIED;

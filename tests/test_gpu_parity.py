@@ -812,3 +812,28 @@ def test_wide_box_filter_in_one_process_multi_gpu_and_scene_file(gpu, oracle):
     with gpu.Scene(ls.scene) as sc:
         film, _ = sc.render(seed=0, **ls.render_kwargs())
     assert_bit_equal(film, ref, "C0 scene file with a wide box filter")
+
+
+@pytest.mark.parametrize("name,integrator,depth,spp,seed", [
+    ("mesh1k", INTEGRATOR_PATH, 8, (4, 4), 3), ("cornell", INTEGRATOR_PATH, 12, (9, 8), 1), ("check_sphere", INTEGRATOR_PATH, 5, (2, 2), 9),
+    ("sphere", INTEGRATOR_DIRECT, 5, (4, 2), 0), ("deep", INTEGRATOR_PATH, 6, (2, 2), 6), ("mesh20k", INTEGRATOR_PATH, 8, (5, 3), 2)])
+def test_sobol_nd_sampler_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
+    """Sampler "sobol" (sampler 2): every request of a sample takes its own pair of Sobol' dimensions from
+    the generator matrices (rows of the reference's SOBOL_MATRICES32), later requests fall back to the padded scheme: integer
+    arithmetic, so the film equals the oracle's bit for bit -- sphere and triangle kernels, LDS and overflow stacks, a
+    non-power-of-two sample count, three ranks."""
+    sd = SMALL_SCENES[name]()
+    kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=seed, sampler="sobol_nd")
+    ref, _ = oracle.OracleScene(sd).render(**kw)
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(**kw)
+        acc = sum(sc.render(rank=r, world_size=3, **kw)[0] for r in range(3))
+        from pbrt_amd import _lib
+        for bad, code in ((dict(counters=True), -1), (dict(filter_width=(1.5, 1.5)), -4)):
+            with pytest.raises(_lib.PbrtHipError) as e:
+                sc.render(**dict(kw, **bad))
+            assert e.value.code == code
+        other, _ = sc.render(**dict(kw, sampler="sobol"))
+    assert_bit_equal(film, ref, f"{name} film, sampler 2")
+    assert_bit_equal(acc, ref, "three ranks")
+    assert not np.array_equal(other, film)

@@ -369,8 +369,9 @@ def test_production_kernels_do_not_spill():
     for d, (_, vgpr, spill, scratch) in prod:
         assert spill == 0 and scratch == 0, f"{d}: {vgpr} VGPRs, {spill} spilled, {scratch} B scratch"
         # the triangle-scene render kernels are launched at 5 waves per SIMD (capi.cpp: 20 one-wave workgroups per CU)
-        # (the instantiations for a box filter radius other than 0.5 -- last argument true -- run at 3 waves per SIMD)
-        if re.search(r"render_kernel<false, false, false, \d+, \d+, false>", d):
+        # (the instantiations for a box filter radius other than 0.5 and for the Sobol' sampler -- one of the last two
+        # arguments true -- run at 3 waves per SIMD)
+        if re.search(r"render_kernel<false, false, false, \d+, \d+, false, false>", d):
             assert vgpr <= 96, f"{d}: {vgpr} VGPRs do not fit 5 waves per SIMD"
 
 
@@ -451,3 +452,27 @@ def test_production_tree_finds_the_oracles_hits(oracle, name, tree):
         assert np.array_equal(occ["occluded"], ref.occluded(o, d, tmax))
         assert max(got["max_stack"], occ["max_stack"]) <= q["stack_need"]
     assert q["n_refs"] >= sd.idx.shape[0] and (tree == "sah") == (q["n_refs"] == sd.idx.shape[0]) or sd.idx.shape[0] < 2 or tree == "sbvh"
+
+
+def test_sobol_nd_generator_matrices(oracle):
+    """Sampler 2 takes its dimensions from generator matrices the library builds on the host from the
+    Joe-Kuo direction numbers: they must equal the oracle's own construction (which tests/test_reference_vectors.py pins to
+    the reference's SOBOL_MATRICES32, sobolmatrices.rs:81) column for column, and -- where /root/reference is mounted --
+    the reference's table directly."""
+    from pbrt_amd.api import sobol_matrices
+    m = sobol_matrices()
+    ref = oracle.sobol_matrices()
+    assert m.shape == (10, 32) and ref.shape[0] >= 10
+    assert np.array_equal(m, ref[:10, :32])
+    path = "/root/reference/src/core/sobolmatrices.rs"
+    if os.path.exists(path):
+        text = open(path).read()
+        body = text[text.index("SOBOL_MATRICES32"):]
+        body = body[body.index("= [") + 3:]
+        vals = []
+        for tok in re.finditer(r"0x[0-9a-fA-F]+|\d+", body):
+            vals.append(int(tok.group(0), 0))
+            if len(vals) >= 10 * 52:
+                break
+        table = np.array(vals, np.uint64).reshape(10, 52)[:, :32].astype(np.uint32)
+        assert np.array_equal(m, table)

@@ -180,8 +180,9 @@ def test_film_scale_and_filter_radius_leave_the_library():
 
 def test_sampler_names():
     """Sampler "halton" (the reference's default name, api.rs:235) and the other low-discrepancy names select the
-    (0,2)-sequence sampler; "stratified" / "random" / unknown names the stratified one."""
-    for name, want in (("halton", 1), ("sobol", 1), ("02sequence", 1), ("lowdiscrepancy", 1), ("stratified", 0), ("random", 0), ("bogus", 0)):
+    (0,2)-sequence sampler, "sobol" the Sobol' sampler with its own dimensions per request (DESIGN.md 3.12);
+    "stratified" / "random" / unknown names the stratified one."""
+    for name, want in (("halton", 1), ("sobol", 2), ("02sequence", 1), ("lowdiscrepancy", 1), ("stratified", 0), ("random", 0), ("bogus", 0)):
         ls = loader.load_string(f'Sampler "{name}" "integer pixelsamples" 32')
         assert ls.sampler == want, name
         if name != "stratified":

@@ -4,7 +4,7 @@ the VALU instructions of the kernel (or of the address range of its node step: t
 v_cvt_f32_ubyte of an unrolled step), priced with the issue classes measured by tools/ubench/valu_issue.hip
 (profiles/r02_valu_issue_ubench.txt): FAST 2.33, SLOW 4.2, TRANS 8.1 cycles per wave64 instruction per SIMD.
 
-usage: tools/isa_stats.py [kernel-name-regex] [--step]     default regex: render_kernel<false, false, false, 0, 3, false>
+usage: tools/isa_stats.py [kernel-name-regex] [--step]     default regex: render_kernel<false, false, false, 0, 3, false, false>
 """
 import glob
 import os
@@ -42,7 +42,7 @@ def code_objects(lib):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    pat = re.compile(args[0] if args else r"render_kernel<false, false, false, 0, 3, false>")
+    pat = re.compile(args[0] if args else r"render_kernel<false, false, false, 0, 3, false, false>")
     lib = os.environ.get("PBRT_HIP_LIB_DIR", os.path.join(ROOT, "pbrt_amd", "lib")) + "/libpbrt_hip.so"
     for co in code_objects(lib):
         dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--demangle", co], capture_output=True, text=True, check=True).stdout
