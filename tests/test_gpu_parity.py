@@ -622,6 +622,17 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     if st is not None:
         for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
             assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
+    # round 3's film paths on the same random scene: a random box filter radius (fixed-point film; ranks add as integers),
+    # a luminance clamp, and the Sobol' sampler with its own dimensions
+    fw = (float(rng.uniform(0.3, 2.6)), float(rng.uniform(0.3, 2.6)))
+    ml = float(rng.uniform(0.2, 3.0)) if seed % 2 else 0.0
+    kw = dict(integrator=integ, max_depth=depth, spp=spp, seed=rseed, sampler=sampler, max_sample_luminance=ml)
+    o = oracle.OracleScene(sd)
+    with gpu.Scene(sd, builder="gpu" if seed % 3 == 1 else "host") as sc:
+        parts = sum(sc.render_acc(fw, rank=r, world_size=world, **kw)[0] for r in range(world))
+        nd, _ = sc.render(**dict(kw, sampler="sobol_nd"))
+    assert np.array_equal(parts, o.render_acc(fw, **kw)[0]), f"random scene {seed}: accumulators, box filter {fw}, {world} ranks, clamp {ml}"
+    assert_bit_equal(nd, o.render(**dict(kw, sampler="sobol_nd"))[0], f"random scene {seed}: sampler 2")
 
 
 @pytest.mark.timeout(900)
