@@ -341,6 +341,36 @@ def test_full_size_properties_c2(gpu, oracle):
     assert_bit_equal(film[256:320, 256:320], ref, "window of the full frame")
 
 
+def test_full_size_wide_filter_c2_and_c3(gpu, oracle):
+    """Box filter radius 1.5 at BASELINE sizes: the whole C2 frame (sobol sampler) and the whole C3 frame
+    (1M triangles, 2048x2048) at a reduced sample count -- deterministic although 327 680 lanes add with atomics, weights
+    9 x spp (a few per thousand more: film points that round up to the next pixel), eight ranks' accumulators adding to one
+    rank's, and a window of the frame equal to the oracle's render of that crop window (whose sample bounds reach into the
+    same neighbours), sampler 2 on the same scene likewise."""
+    for n_tris, res, sampler, crop, sl in ((100_000, 1024, "sobol", (0.25, 0.28125, 0.5, 0.53125), (slice(512, 544), slice(256, 288))),
+                                          (1_000_000, 2048, "stratified", (0.5, 0.515625, 0.25, 0.265625), (slice(512, 544), slice(1024, 1056)))):
+        sd = scenes.random_mesh_scene(n_tris, res, res)
+        kw = dict(max_depth=8, spp=(2, 2), seed=0, sampler=sampler)
+        with gpu.Scene(sd, builder="gpu") as sc:
+            film, st = sc.render(filter_width=(1.5, 1.5), **kw)
+            again, _ = sc.render(filter_width=(1.5, 1.5), **kw)
+            if n_tris == 100_000:
+                acc, _ = sc.render_acc((1.5, 1.5), **kw)
+                parts = sum(sc.render_acc((1.5, 1.5), rank=r, world_size=8, **kw)[0] for r in range(8))
+                assert np.array_equal(parts, acc), "eight ranks' accumulators add to one rank's"
+                nd, _ = sc.render(**dict(kw, sampler="sobol_nd"))
+        assert film.shape == (res, res, 4) and np.isfinite(film).all()
+        assert_bit_equal(film, again, "wide filter: run-to-run determinism")
+        assert abs(film[..., 3].mean() - 36.0) < 0.05 and film[..., 3].min() >= 36.0
+        assert st["samples"] == (res + 2) * (res + 2) * 4  # the sample bounds reach one pixel beyond the image on every side
+        win = scenes.random_mesh_scene(n_tris, res, res, crop=crop)
+        o = oracle.OracleScene(win)
+        ref, _ = o.render(filter_width=(1.5, 1.5), **kw)
+        assert_bit_equal(film[sl], ref, f"window of the full {res}x{res} frame, box filter 1.5")
+        if n_tris == 100_000:
+            assert_bit_equal(nd[sl], o.render(**dict(kw, sampler="sobol_nd"))[0], "window of the full frame, sampler 2")
+
+
 def test_c2_full_frame_eight_rank_shares_add_up(gpu):
     """BASELINE config C2 at its full size and sample count: the frame rendered by one rank equals, bit for bit, the sum
     of the eight shares of an 8-GPU job: sharding and the dynamic, XCD-aware hand-out of work items change no sample."""
