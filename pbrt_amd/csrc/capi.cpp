@@ -1051,8 +1051,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.n_items = sh.n_local * 4096u * n_chunks;
     // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
     const RenderStackPlan plan = render_stack_plan(s->dev.quad_stack_need, render_force_overflow(), render_prefer_lds());
-    // (so does the kernel for a box filter radius other than 0.5)
-    const uint32_t waves_per_cu = (s->dev.n_spheres || fg.wide || sobol_nd) ? std::min(kRenderWavesPerCuSpheres, plan.waves_per_cu) : plan.waves_per_cu;
+    // (the instantiations for another filter radius and for the Sobol' sampler fit the 96 VGPRs of 5 waves per SIMD like the default one)
+    const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, plan.waves_per_cu) : plan.waves_per_cu;
     R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
     R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));

@@ -763,10 +763,11 @@ __device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const
 // WIDE: a box filter radius other than 0.5: a sample is added to every pixel within the radius, into
 // fixed-point accumulators with atomics, instead of to its chunk's partial sum.
 // SND: sampler 2, the Sobol' sampler with its own dimensions per request (3.12): generator-matrix lookups in the service stage.
+// (Both variants keep the default path's register budget: 5 waves per SIMD, no spill -- tests/test_host.py.)
 template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK, bool WIDE = false, bool SND = false>
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
-__global__ void __launch_bounds__(64, (COUNT ? 1 : ((SPH || WIDE || SND) ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
+__global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
   // the walk's stack, rows of 64 lanes x 4 bytes as dynamic shared memory: the launch sizes it per scene (render_stack_plan;
   // exact walk: STACK rows of refs followed by STACK rows of entry distances)
   extern __shared__ uint32_t lds_stack[];
