@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Throughput of the kernel's instantiations outside the default path on BASELINE C3's scene at 64 spp: another box filter
+radius (fixed-point film), samplers 1 and 2 (3.10, 3.12), beside the default.  usage (GPU box): variant_throughput.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pbrt_amd  # noqa: E402
+from pbrt_amd import scenes  # noqa: E402
+
+sd = scenes.random_mesh_scene(1_000_000, 2048, 2048)
+with pbrt_amd.Scene(sd, builder="gpu") as sc:
+    for name, kw in (("default filter, stratified", {}), ("box filter radius 1.5 (fixed-point film)", dict(filter_width=(1.5, 1.5))),
+                     ("sampler 1 (padded 0,2)", dict(sampler="sobol")), ("sampler 2 (Sobol' proper)", dict(sampler="sobol_nd")),
+                     ("default again", {})):
+        film, st = sc.render(max_depth=8, spp=(8, 8), seed=0, **kw)
+        print(f"C3 scene, 2048x2048, 64 spp, {name}: kernel {st['kernel_ms']:.1f} ms, {st['samples'] / st['kernel_ms'] / 1e3:.1f} Msamples/s")
