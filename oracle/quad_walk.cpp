@@ -227,7 +227,7 @@ extern "C" void orc_quad_walk(const uint32_t *quads, uint32_t n_quads, uint32_t 
       if (b2) b2[i] = r.b2;
       if (occluded) occluded[i] = r.occluded ? 1 : 0;
       if (steps) steps[i] = (uint32_t)r.steps;
-      if (tris) tris[i] = (uint32_t)r.tris;
+      if (tris) tris[i] = (uint32_t)r.tris | (std::getenv("ORC_WALK_STACK_IN_TRIS") ? r.max_stack << 16 : 0u);  // (diagnostics: the ray's deepest stack in the high half)
       if (r.max_stack > worst_of[w]) worst_of[w] = r.max_stack;
     }
   };

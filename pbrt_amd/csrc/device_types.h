@@ -36,11 +36,15 @@ inline const char *debug_knob(const char *name) {
 #ifdef PBRT_QUAD_LDS_STACK
 constexpr uint32_t kQuadLdsStack = PBRT_QUAD_LDS_STACK, kQuadLdsStackOvf = PBRT_QUAD_LDS_STACK, kQuadLdsStackOvfDeep = PBRT_QUAD_LDS_STACK;
 #else
-constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 30, kQuadLdsStackOvfDeep = 35;
+constexpr uint32_t kQuadLdsStack = 40, kQuadLdsStackOvf = 30, kQuadLdsStackOvfDeep = 30;
 #endif
-// Very deep trees (stack bound >= 42: the 12 M-triangle `big` workload has 44) reach the end of a 30-row LDS part often
-// enough for the slow form of the step to cost more than two waves per CU buy: they get 35 rows at 18 waves (`big`: 870 ms
-// against 925 at 30 rows and 878 at 40; C3, bound 38: 162 / 169 / 178 ms at 30 / 35 / 40 rows).
+// Round 2 gave very deep trees (stack bound >= 42: the 12 M-triangle `big` workload has 48) a 35-row variant at 18 waves per
+// CU, on the assumption that they reach the end of a 30-row LDS part often.  They do not: the bound is a worst case that
+// walks do not come near (tools/walk_sim.py with ORC_WALK_STACK_IN_TRIS: a ray's deepest stack in the 12 M-triangle tree is
+// 8.5 entries on average, 19 at the 99.9th percentile, 23 at most over 40 000 rays; 1 M triangles: 7.6 / 17 / 20), so the
+// HBM overflow area is a safety net, not a path; and more resident waves help this latency-bound workload (r03q / r03r:
+// 20 waves with 30 rows 217 ms, 18 waves with 35 rows 219 ms, 16 waves 224 ms).  The deep variant is therefore the same
+// 30 rows (kept as a name so that a different choice stays a one-line change).
 constexpr uint32_t kOvfDeepNeed = 42;
 constexpr uint32_t kLdsGranule = 1280u;
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
