@@ -74,6 +74,31 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
   }
   std::vector<uint32_t> stack;
   stack.reserve(64);
+  // experiment (ORC_WALK_CULL=n): every stacked entry carries its entry distance rounded DOWN to its n top bits (32: exact);
+  // a popped entry farther than the closest hit so far is dropped without a fetch
+  static const int cull_bits = std::getenv("ORC_WALK_CULL") ? std::atoi(std::getenv("ORC_WALK_CULL")) : 0;
+  std::vector<float> skey;
+  auto pop = [&]() -> uint32_t {
+    while (!stack.empty()) {
+      const uint32_t ref = stack.back();
+      stack.pop_back();
+      if (cull_bits) {
+        const float k = skey.back();
+        skey.pop_back();
+        if (k > fminn(r.t, tmax)) continue;
+      }
+      return ref;
+    }
+    return kDone;
+  };
+  auto push = [&](uint32_t ref, float k) {
+    stack.push_back(ref);
+    if (cull_bits) {
+      uint32_t u; std::memcpy(&u, &k, 4);
+      if (cull_bits < 32) u &= ~((1u << (32 - cull_bits)) - 1u);  // k >= kRayTMin > 0: clearing low bits rounds down
+      skey.push_back(as_f(u));
+    }
+  };
   while (cur != kDone) {
     if (!(cur & kLeafRef)) {
       const uint32_t *W = T.quads + (size_t)(cur / 64u) * 16u;
@@ -128,7 +153,7 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
         for (int i = 0; i < m; i++)
           for (int j = i + 1; j < m; j++)
             if (key[ks[j]] > key[ks[i]]) { const int t2 = ks[i]; ks[i] = ks[j]; ks[j] = t2; }
-        for (int i = 0; i < m; i++) stack.push_back(W[12 + ks[i]]);
+        for (int i = 0; i < m; i++) push(W[12 + ks[i]], key[ks[i]]);
       } else if (order_mode == 2) {  // experiment: slot order, reversed when the ray runs against the axis along which the
         // children's centres are spread most (what a builder that sorts children along that axis + one sign test would do)
         float c[4][3];
@@ -160,20 +185,13 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
             const bool swap = neg ? c[ks[j]][ax] < c[ks[i]][ax] : c[ks[j]][ax] > c[ks[i]][ax];
             if (swap) { const int t2 = ks[i]; ks[i] = ks[j]; ks[j] = t2; }
           }
-        for (int i = 0; i < m; i++) stack.push_back(W[12 + ks[i]]);
+        for (int i = 0; i < m; i++) push(W[12 + ks[i]], key[ks[i]]);
         (void)used;
       } else
       for (int k = 3; k >= 0; k--)
-        if (hit[k] && k != nearest) stack.push_back(W[12 + k]);
+        if (hit[k] && k != nearest) push(W[12 + k], key[k]);
       if (stack.size() > r.max_stack) r.max_stack = (uint32_t)stack.size();
-      if (any_hit) {
-        cur = W[12 + nearest];
-      } else if (stack.empty()) {
-        cur = kDone;
-      } else {
-        cur = stack.back();
-        stack.pop_back();
-      }
+      cur = any_hit ? W[12 + nearest] : pop();
       continue;
     }
     // a leaf: its triangles in slot order (Moeller-Trumbore in the operation order of DESIGN.md 3.5)
@@ -197,12 +215,7 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
       if (valid && any) { r.occluded = true; stop = true; }
       if (valid && !any && (th < r.t || (th == r.t && id < r.prim))) { r.t = th; r.prim = id; r.b1 = u; r.b2 = v; }
     }
-    if (stop || stack.empty()) {
-      cur = kDone;
-    } else {
-      cur = stack.back();
-      stack.pop_back();
-    }
+    cur = stop ? kDone : pop();
   }
   *out = r;
 }
