@@ -585,7 +585,8 @@ def test_gpu_built_scene_equals_host_built_scene_c2(gpu):
 def _random_scene(seed):
     from pbrt_amd.scenes import MATTE, MIRROR, _camera, _mat
     rng = np.random.default_rng(1000 + seed)
-    n_tris = int(rng.choice([0, 1, 2, 5, 17, 64, 300]))
+    # (seeds of the soak run -- PBRT_SOAK_SEEDS > 48, tools/soak.sh -- also draw trees deep enough for every stack variant)
+    n_tris = int(rng.choice([0, 1, 2, 5, 17, 64, 300] if seed < 48 else [0, 1, 2, 5, 17, 64, 300, 2500, 20000]))
     c = rng.uniform(-1, 1, (n_tris, 1, 3))
     P = (c + rng.uniform(-0.4, 0.4, (n_tris, 3, 3))).reshape(-1, 3).astype(np.float32)
     if n_tris >= 5 and seed % 3 == 0:  # some exact duplicates and a degenerate triangle: the tie rule and |det| < 1e-8
@@ -621,7 +622,7 @@ def _random_scene(seed):
                      xres=xres, yres=yres, crop=crop).normalized(), rng
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PBRT_SOAK_SEEDS", "48"))))
 def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     """Triangle counts 0..300 (with duplicates and degenerate triangles), random materials (mirrors, emitters),
     0-3 lights of every kind, 0-2 spheres, random camera / resolution / crop / strata / depth / integrator /

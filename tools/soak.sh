@@ -1,0 +1,7 @@
+#!/bin/bash
+# Soak run of the randomised parity test (tests/test_gpu_parity.py::test_random_scenes_match_oracle) beyond the 48 seeds of
+# the suite: seeds 0..N-1, those from 48 on also drawing 2 500- and 20 000-triangle scenes.  On an MI355X:
+#   bash tools/soak.sh 2000 > gpurun_out/soak.txt
+n=${1:-1000}
+cd "$(dirname "$0")/.."
+PBRT_SOAK_SEEDS=$n python3 -m pytest tests/test_gpu_parity.py -q -m gpu -k test_random_scenes_match_oracle -n 4 -p no:cacheprovider 2>&1 | tail -15
