@@ -421,26 +421,43 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // g +- 3 eps |g| as one fma each (|x| and -x are operand modifiers): rounded once instead of twice, at least
       // g +- 5/2 eps |g|, still beyond the 2 eps |g| the margin has to cover
       constexpr float kMargin = 0x1.8p-22f;
-      const f32x2 gxx = {__builtin_fmaf(fabsf(gx), kMargin, gx), __builtin_fmaf(-fabsf(gx), kMargin, gx)};  // {near, far}: subtracted below
-      const f32x2 gyy = {__builtin_fmaf(fabsf(gy), kMargin, gy), __builtin_fmaf(-fabsf(gy), kMargin, gy)};
-      const f32x2 gzz = {__builtin_fmaf(fabsf(gz), kMargin, gz), __builtin_fmaf(-fabsf(gz), kMargin, gz)};
+      const float gxn = __builtin_fmaf(fabsf(gx), kMargin, gx), gxf = __builtin_fmaf(-fabsf(gx), kMargin, gx);  // near, far: subtracted below
+      const float gyn = __builtin_fmaf(fabsf(gy), kMargin, gy), gyf = __builtin_fmaf(-fabsf(gy), kMargin, gy);
+      const float gzn = __builtin_fmaf(fabsf(gz), kMargin, gz), gzf = __builtin_fmaf(-fabsf(gz), kMargin, gz);
       const float cix = __uint_as_float(W0.w) * inv.x, ciy = __uint_as_float(W2.z) * inv.y, ciz = __uint_as_float(W2.w) * inv.z;
       // near / far planes by the sign of the inverse direction: one select per axis serves all four
       // children (a dword holds the four children's bytes of one plane)
       const uint32_t bnx = negx ? W1.w : W1.x, bfx = negx ? W1.x : W1.w;
       const uint32_t bny = negy ? W2.x : W1.y, bfy = negy ? W1.y : W2.x;
       const uint32_t bnz = negz ? W2.y : W1.z, bfz = negz ? W1.z : W2.y;
-      // {near, far} of one axis side by side: one packed fma (v_pk_fma_f32, IEEE per element) per child and axis
-      const f32x2 cxx = {cix, cix}, cyy = {ciy, ciy}, czz = {ciz, ciz};
+      // How the 24 plane fmas are issued.  A gfx950 SIMD issues, per quad-cycle, one instruction of any kind plus one of
+      // the "simple" class (fma, mul, add, logic, right shift, mov) from another wave; a packed instruction goes alone
+      // (tools/ubench/valu_pairing.hip, profiles/r03w_valu_pairing_ubench.txt).  This step has three converts / min /
+      // max / compares / selects for every simple instruction, so 24 scalar v_fma_f32 ride along with them where 12
+      // v_pk_fma_f32 take 12 quad-cycles of their own -- but they are 12 more instructions for a wave that issues one
+      // every ~5 cycles at best.  Measured (profiles/r03w_scalar_fma_ab.txt): trees that sit in L2 (no wait to hide: C4
+      // +4.7 %, C2 +1.6 %) gain from the scalar form; the deep trees of the overflow variant, whose waves spend their time
+      // waiting for nodes, lose (C3 -0.8 %, 12 M triangles -6.5 %) and keep the packed one ({near, far} of a child side by
+      // side; IEEE per element: the same bits either way).
+      constexpr bool kScalarFma = OVFR == 0u;
+      const f32x2 gxx = {gxn, gxf}, gyy = {gyn, gyf}, gzz = {gzn, gzf}, cxx = {cix, cix}, cyy = {ciy, ciy}, czz = {ciz, ciz};
       float key[4];
       bool hit[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const f32x2 qx = {(float)((bnx >> (8 * k)) & 0xffu), (float)((bfx >> (8 * k)) & 0xffu)};
-        const f32x2 qy = {(float)((bny >> (8 * k)) & 0xffu), (float)((bfy >> (8 * k)) & 0xffu)};
-        const f32x2 qz = {(float)((bnz >> (8 * k)) & 0xffu), (float)((bfz >> (8 * k)) & 0xffu)};
-        const f32x2 tx = __builtin_elementwise_fma(qx, cxx, -gxx), ty = __builtin_elementwise_fma(qy, cyy, -gyy);
-        const f32x2 tz = __builtin_elementwise_fma(qz, czz, -gzz);
+        const float qxn = (float)((bnx >> (8 * k)) & 0xffu), qxf = (float)((bfx >> (8 * k)) & 0xffu);
+        const float qyn = (float)((bny >> (8 * k)) & 0xffu), qyf = (float)((bfy >> (8 * k)) & 0xffu);
+        const float qzn = (float)((bnz >> (8 * k)) & 0xffu), qzf = (float)((bfz >> (8 * k)) & 0xffu);
+        f32x2 tx, ty, tz;  // {near, far}
+        if (kScalarFma) {
+          tx = f32x2{__builtin_fmaf(qxn, cix, -gxn), __builtin_fmaf(qxf, cix, -gxf)};
+          ty = f32x2{__builtin_fmaf(qyn, ciy, -gyn), __builtin_fmaf(qyf, ciy, -gyf)};
+          tz = f32x2{__builtin_fmaf(qzn, ciz, -gzn), __builtin_fmaf(qzf, ciz, -gzf)};
+        } else {
+          tx = __builtin_elementwise_fma(f32x2{qxn, qxf}, cxx, -gxx);
+          ty = __builtin_elementwise_fma(f32x2{qyn, qyf}, cyy, -gyy);
+          tz = __builtin_elementwise_fma(f32x2{qzn, qzf}, czz, -gzz);
+        }
         const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, kRayTMin));
         const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar));
         hit[k] = tn <= tf * kBoxPad;

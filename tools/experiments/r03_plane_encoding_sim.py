@@ -66,3 +66,57 @@ run("uniform 6 bit", quantise(q["exact_boxes"],np.arange(64.0),False))
 run("e4m3 one origin", quantise(q["exact_boxes"],e4m3_grid(),False))
 run("e4m3 two origins", quantise(q["exact_boxes"],e4m3_grid(),True))
 run("e5m2 two origins", quantise(q["exact_boxes"],e5m2_grid(),True))
+
+
+# ---- r03u: signed fp8 planes around a per-node, per-axis ORIGIN chosen by the builder (the decode stays linear:
+# t = v * (cell * inv) - (o - origin) * inv, v = the fp8 value in -448 .. 448, cell a power of two) ----
+def quantise_signed(exact, grid, origin_mode, pow2=True):
+    ex = exact.reshape(-1, 4, 6).astype(np.float64).copy()
+    used = ex[:, :, 0] <= ex[:, :, 3]
+    lo = np.where(used[:, :, None], ex[:, :, 0:3], np.inf).min(1)
+    hi = np.where(used[:, :, None], ex[:, :, 3:6], -np.inf).max(1)
+    sg = np.concatenate([-grid[::-1], grid[1:]])  # signed value set, ascending
+    gmax = grid.max()
+    out = ex.copy()
+    for a in range(3):
+        L = np.where(used, ex[:, :, a], np.nan)      # (n, 4)
+        H = np.where(used, ex[:, :, 3 + a], np.nan)
+        if origin_mode == "centre":
+            cands = [0.5 * (lo[:, a] + hi[:, a])]
+        elif origin_mode == "lo":
+            cands = [lo[:, a]]
+        else:  # every plane position, both corners and the centre
+            cands = [lo[:, a], hi[:, a], 0.5 * (lo[:, a] + hi[:, a])] + [np.where(used[:, k], ex[:, k, a], lo[:, a]) for k in range(4)] + \
+                    [np.where(used[:, k], ex[:, k, 3 + a], hi[:, a]) for k in range(4)]
+        best_err = np.full(len(ex), np.inf)
+        best_ql = np.zeros_like(L)
+        best_qh = np.zeros_like(H)
+        for org in cands:
+            reach = np.maximum(np.maximum(hi[:, a] - org, org - lo[:, a]), 1e-30)
+            cell = reach / gmax
+            if pow2:
+                cell = 2.0 ** np.ceil(np.log2(cell))
+            l = (L - org[:, None]) / cell[:, None]
+            h = (H - org[:, None]) / cell[:, None]
+            li = np.clip(np.searchsorted(sg, np.nan_to_num(l), side='right') - 1, 0, len(sg) - 1)
+            hi_i = np.clip(np.searchsorted(sg, np.nan_to_num(h), side='left'), 0, len(sg) - 1)
+            ql = org[:, None] + sg[li] * cell[:, None]
+            qh = org[:, None] + sg[hi_i] * cell[:, None]
+            err = np.nansum(np.where(used, (L - ql) + (qh - H), 0.0), axis=1)
+            better = err < best_err
+            best_err = np.where(better, err, best_err)
+            best_ql = np.where(better[:, None], ql, best_ql)
+            best_qh = np.where(better[:, None], qh, best_qh)
+        for k in range(4):
+            out[:, k, a] = np.where(used[:, k], best_ql[:, k], np.inf)
+            out[:, k, 3 + a] = np.where(used[:, k], best_qh[:, k], -np.inf)
+    o32 = out.astype(np.float32)
+    o32[:, :, 0:3] = np.where(o32[:, :, 0:3].astype(np.float64) > out[:, :, 0:3], np.nextafter(o32[:, :, 0:3], -np.inf, dtype=np.float32), o32[:, :, 0:3])
+    o32[:, :, 3:6] = np.where(o32[:, :, 3:6].astype(np.float64) < out[:, :, 3:6], np.nextafter(o32[:, :, 3:6], np.inf, dtype=np.float32), o32[:, :, 3:6])
+    return o32.reshape(-1, 24)
+
+
+run("uniform 8 bit, pow2 cell", quantise_signed(q["exact_boxes"], np.arange(128.0), "lo") if False else quantise(q["exact_boxes"], u8, False))
+for mode in ("lo", "centre", "best"):
+    for p2 in (False, True):
+        run(f"e4m3 signed, origin {mode}{', pow2 cell' if p2 else ''}", quantise_signed(q["exact_boxes"], e4m3_grid(), mode, p2))

@@ -25,6 +25,11 @@ add("F1", "v_cvt_f32_f16")
 add("F3", "v_pk_fma_f16")
 add("F2", "v_pk_min_f16", "v_pk_max_f16", "v_pk_mul_f16")
 add("SDWA", "v_mul_f32_sdwa (src0 = byte 1)")
+# gfx950's narrow-float converts (r03: could the node planes be decoded two per instruction?)
+add("CVTPK", "v_cvt_pk_f32_fp8", "v_cvt_pk_f32_bf8", "v_cvt_pk_f32_fp8_sdwa (src0 = word 1)", "v_cvt_scalef32_pk_f32_fp8", "v_cvt_scalef32_pk_f32_fp8 (op_sel word 1)",
+    "v_cvt_scalef32_pk_f32_fp4")
+add("F1", "v_cvt_f32_fp8")
+add("CVT32", "v_cvt_scalef32_pk32_f32_fp6")
 add("DSW", "ds_write_b32", )
 add("DSR", "ds_read_b32", )
 
@@ -71,6 +76,24 @@ def body(kind, mn):
         return ('    f2 p0 = {a[0], a[1]}, p1 = {a[2], a[3]}, p2 = {a[4], a[5]}, p3 = {a[6], a[7]}, bb = {b, b}, cc = {c, c};\n'
                 f'    REP8(asm volatile("{ins}" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(bb), "v"(cc));)\n'
                 '    a[0] = p0.x; a[1] = p0.y; a[2] = p1.x; a[3] = p1.y; a[4] = p2.x; a[5] = p2.y; a[6] = p3.x; a[7] = p3.y;\n')
+    if kind == "CVTPK":
+        base = mn.split(" ")[0]
+        if "sdwa" in mn:
+            fmt = base + " %{r}, %4 src0_sel:WORD_1"
+        elif "scalef32" in mn:
+            fmt = base + " %{r}, %4, %5" + (" op_sel:[1,0,0]" if "op_sel" in mn else "")
+        else:
+            fmt = base + " %{r}, %4"
+        ins = ' "\n        "'.join(fmt.replace("{r}", str(k % 4)) + '\\n' for k in range(8))
+        return ('    f2 p0 = {a[0], a[1]}, p1 = {a[2], a[3]}, p2 = {a[4], a[5]}, p3 = {a[6], a[7]};\n'
+                f'    REP8(asm volatile("{ins}" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(u), "v"(b));)\n'
+                '    a[0] = p0.x; a[1] = p0.y; a[2] = p1.x; a[3] = p1.y; a[4] = p2.x; a[5] = p2.y; a[6] = p3.x; a[7] = p3.y;\n')
+    if kind == "CVT32":  # 32 results per instruction: 8 instructions write the same 32 registers from 6 source registers
+        return ('    typedef float f32v __attribute__((ext_vector_type(32)));\n    typedef uint32_t u6v __attribute__((ext_vector_type(6)));\n'
+                '    f32v big; for (int i = 0; i < 32; i++) big[i] = a[i & 7];\n    u6v src = {u, u + 1, u + 2, u + 3, u + 4, u + 5};\n'
+                '    REP8(asm volatile("v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2\\n v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2\\n v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2\\n v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2\\n"\n'
+                '        "v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2\\n v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2\\n v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2\\n v_cvt_scalef32_pk32_f32_fp6 %0, %1, %2" : "+v"(big) : "v"(src), "v"(b));)\n'
+                '    for (int i = 0; i < 32; i++) a[i & 7] += big[i];\n')
     if kind == "DEP":
         return f'    REP8(asm volatile({rep("v_fma_f32 %0, %0, %8, %9")} : {regs8} : "v"(b), "v"(c));)\n'
     if kind == "MIX":
@@ -178,6 +201,7 @@ static WaveRec *d_recs;
 static float *sink;
 static uint32_t *d_start;
 static int n_cu;
+static const char *g_only;  // "only <substring>": the sweep runs just the instructions whose name contains it
 
 template <int OP>
 double run(int W, int lanes, bool print = true) {
@@ -229,7 +253,7 @@ double run(int W, int lanes, bool print = true) {
 template <int OP>
 struct Sweep {
   static void go(const int *Ws, int nW, double *table) {
-    for (int i = 0; i < nW; i++) table[OP * nW + i] = run<OP>(Ws[i], 64);
+    for (int i = 0; i < nW && (!g_only || strstr(kNames[OP], g_only)); i++) table[OP * nW + i] = run<OP>(Ws[i], 64);
     Sweep<OP + 1>::go(Ws, nW, table);
   }
 };
@@ -252,12 +276,14 @@ int main(int argc, char **argv) {
     PMC_RUNS
     return 0;
   }
+  if (argc > 2 && !strcmp(argv[1], "only")) g_only = argv[2];
   const int Ws[] = {1, 2, 4, 8};
   std::vector<double> table((size_t)N_OPS * 4, 0.0);
   Sweep<0>::go(Ws, 4, table.data());
   printf("\n# summary: cycles per wave-instruction per SIMD\n# %-60s %8s %8s %8s %8s\n", "instruction", "W=1", "W=2", "W=4", "W=8");
   for (int o = 0; o < N_OPS; o++)
-    printf("| %-60s | %6.2f | %6.2f | %6.2f | %6.2f |\n", kNames[o], table[o * 4], table[o * 4 + 1], table[o * 4 + 2], table[o * 4 + 3]);
+    if (!g_only || strstr(kNames[o], g_only)) printf("| %-60s | %6.2f | %6.2f | %6.2f | %6.2f |\n", kNames[o], table[o * 4], table[o * 4 + 1], table[o * 4 + 2], table[o * 4 + 3]);
+  if (g_only) return 0;
   printf("\n# EXEC mask: does a partly empty wave64 instruction issue faster?\n");
 ''')
 idx = {o[0]: i for i, o in enumerate(ops)}
