@@ -301,7 +301,7 @@ def main():
             roof["frac"] = roof["achieved"] / peak
             m = pmc.get("valu_issue_busy_measured")
             roof["valu"] = {k: pmc.get(k) for k in ("valu_issue_busy_measured", "valu_issue_quadcycles_per_ray", "valu_dual_issue_share_of_instructions",
-                                                    "valu_instructions_per_ray", "lane_utilisation", "l2_hit_rate", "wave_wait_frac",
+                                                    "valu_instructions_per_ray", "lane_utilisation", "l2_hit_rate", "wave_wait_frac", "wave_issue_wait_frac", "wave_issuing_frac",
                                                     "clock_ghz_in_profile", "round", "build_id")}
             roof["valu"]["valu_busy_bracket"] = [m, m]  # a measurement, not a model: the r02 bracket [0.72, 1.07] is gone
             roof["valu"]["class_model_r02"] = {k: pmc.get(k) for k in ("valu_busy_frac_at_profile_clock", "valu_issue_cycles_per_ray", "mean_issue_cycles_per_instruction")}

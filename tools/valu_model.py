@@ -119,6 +119,9 @@ def main():
         "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") else None,
         "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if c.get("TCC_HIT_sum") else None,
         "wave_wait_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+        # where a resident wave's time goes: waiting for memory (s_waitcnt), waiting for its turn to issue, issuing
+        "wave_issue_wait_frac": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_INST_ANY") else None,
+        "wave_issuing_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and c.get("SQ_ACTIVE_INST_ANY") else None,
         "salu_per_valu": c.get("SQ_INSTS_SALU", 0.0) / total,
         "probe_rays": rays, "probe_samples": c.get("PROBE_SAMPLES"),
         "valu_instructions_per_ray": total / rays if rays else None, "valu_issue_cycles_per_ray": best / rays if rays else None,
