@@ -149,6 +149,7 @@ def main():
                     help="N GPUs from ONE process through pbrt_hip_multi_* (ncclGather inside the library) instead of one rank per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true", help="skip the untimed counting passes (roofline.achieved = null)")
+    ap.add_argument("--profiles", default=os.path.join(ROOT, "profiles"), help="directory of pmc_<workload>.json (tests point it at a copy)")
     args = ap.parse_args()
 
     import torch
@@ -247,7 +248,7 @@ def main():
             "kernel": "render_kernel"}
     avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     roof["kernel_ms"] = avg_kernel_ms
-    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
+    pmc_path = os.path.join(args.profiles, f"pmc_{args.workload}.json")
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
     # A profile prices the library it was taken on and no other: the committed counters carry the build id (hash of the
     # sources and kernel flags, pbrt_hip_build_id) of that library; with a different one loaded every figure that rests on

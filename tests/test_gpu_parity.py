@@ -667,6 +667,33 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
 
 
 @pytest.mark.timeout(900)
+def test_bench_withholds_a_stale_profile(gpu, tmp_path):
+    """VERDICT r02 item 2b / ADVICE: a committed profile prices only the library it was taken on.  bench.py run against a
+    copy of profiles/pmc_c2.json whose build id is not the loaded library's must say so and withhold the figures that rest
+    on it; with the right id it must not complain."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pmc = {"build_id": "0123456789abcdef", "valu_issue_quadcycles_per_ray": 100.0, "valu_issue_busy_measured": 0.5, "traffic_bytes_raw": 1.0}
+    (tmp_path / "pmc_c2.json").write_text(json.dumps(pmc))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "c2", "--spp", "1", "1", "--no-cpu-baseline",
+           "--no-counters", "--profiles", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "0123456789abcdef" in line["roofline"]["stale_profile"] and pbrt_amd.build_id() in line["roofline"]["stale_profile"]
+    assert line["roofline"]["frac"] is None and line["roofline"]["traffic"] is None and "valu" not in line["roofline"]
+    assert line["config"]["library_build_id"] == pbrt_amd.build_id()
+    pmc["build_id"] = pbrt_amd.build_id()
+    (tmp_path / "pmc_c2.json").write_text(json.dumps(pmc))
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "stale_profile" not in line["roofline"]
+
+
+@pytest.mark.timeout(900)
 def test_bench_under_torchrun_uses_rccl(gpu):
     """bench.py as the driver launches it for N > 1 -- torch.distributed.run, one rank per GPU, RCCL ("nccl") process
     group with device_id, barrier, all_reduce of the times, gather of the slabs -- on min(2, device_count) ranks.  On a

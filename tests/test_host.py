@@ -24,6 +24,17 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in l.pbrt_hip_version()
 
 
+def test_build_id_is_the_hash_of_the_sources():
+    """the library carries the identity of what it was built from (sources under csrc/, the public
+    header, kernel flags); profiles/pmc_<workload>.json records the id of the library its counters were taken on and
+    bench.py withholds roofline.frac when they differ (tests/test_gpu_parity.py::test_bench_withholds_a_stale_profile)."""
+    from pbrt_amd import build
+    bid = pbrt_amd.build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", bid), bid
+    assert bid == build.source_id(os.environ.get("PBRT_HIP_EXTRA_FLAGS", "").split())
+    assert build.source_id(["-DX"]) != build.source_id([])  # the flags are part of the identity
+
+
 def test_library_holds_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"render_kernel" in blob
