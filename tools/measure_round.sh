@@ -25,6 +25,10 @@ for w in $WLS; do
   # PMC on the workload's own frame (C3: 512 spp, big: 64): the chunk count and so the hand-out granularity follow the sample count
   if [ $w = c3 ]; then bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 32 16 > $O/pmc_${TAG}_${w}.log 2>&1; else bash tools/pmc_passes.sh pmc_${TAG}_${w} $w 8 8 > $O/pmc_${TAG}_${w}.log 2>&1; fi
 done
+# The profile of THIS build is in place before the bench lines are taken (on this box's copy of profiles/; run the same
+# command on the CPU box afterwards to keep it): their roofline.frac then rests on counters of the library they time
+# instead of being withheld as stale.
+python3 tools/summarize_profile.py $TAG $WLS > $O/summarize_${TAG}.log 2>&1
 # the headline with the DRIVER's arguments, clocks logged beside it; the other workloads with 2 timed steps
 ( while true; do date +%s.%N; rocm-smi --showclocks 2>/dev/null | grep -i "sclk"; sleep 2; done ) > $O/clocks_${TAG}.txt 2>&1 &
 CL=$!
