@@ -1057,9 +1057,12 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
     {
-      const size_t need = (size_t)R.n_workgroups * 320;  // float4 records: 5 x 64 per one-wave workgroup
+      // float4 records: 5 x 64 per one-wave workgroup (kernels.hip LaneRecords); with another box filter radius 16 x 2 x 64 more
+      // behind them (kWideSlotFloat4: a chunk's sums per footprint)
+      const size_t path = (size_t)R.n_workgroups * 320, need = path + (fg.wide ? (size_t)R.n_workgroups * 2048 : 0);
       if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
       R.lane_state = s->d_lane_state.p;
+      R.wide_slots = s->d_lane_state.p + path;
     }
     R.partials = nullptr;
     if (!fg.wide) {

@@ -134,6 +134,7 @@ struct RenderParams {
   unsigned long long *counters;  // 5: camera, bounce, shadow rays, nodes visited, triangles tested
   uint32_t min_walkers, min_parked;  // traversal scheduling thresholds (kernels.hip trav_run)
   float4 *lane_state;                // 5 x 64 float4 per workgroup: path state parked in HBM (kernels.hip PathState)
+  float4 *wide_slots;                // wide box filter: 16 x 2 x 64 float4 per workgroup, a chunk's sums per footprint (kernels.hip)
   uint32_t *stack_overflow;          // [workgroup][entry][lane]: stack entries beyond the LDS part
   uint32_t stack_overflow_entries;
   uint32_t *next_item;    // hand-out counters of the render kernel's item list, one per region, 16 words apart (zeroed before the launch)

@@ -742,10 +742,18 @@ __device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const 
   if (SND && (uint32_t)(P.rng.state >> 32) < 5u) {
     const uint32_t key = (uint32_t)P.rng.state, d0 = 2u * (uint32_t)(P.rng.state >> 32);
     P.rng.state += 1ull << 32;  // next request
-    const uint32_t *m0 = mat + d0 * 32u;
+    // x = XOR of the columns of dimension d0's matrix at the set bits of the sample index, y likewise for d0 + 1.  Branch-free
+    // over the bits a sample index of this frame can have (wave-uniform count), four columns per 16-byte load: the loads of a
+    // request are in flight together, where a loop over the set bits waited for two dependent loads per bit (r03: sampler 2
+    // at 64 spp 369 -> 4xx Msamples/s, profiles/r03z_variant_throughput.txt)
+    const uint4 *m0 = reinterpret_cast<const uint4 *>(mat + d0 * 32u);
     uint32_t x = 0u, y = 0u;
-    for (uint32_t k = P.s, b = 0u; k != 0u; k >>= 1, b++)
-      if (k & 1u) { x ^= m0[b]; y ^= m0[32u + b]; }
+    const uint32_t nq = ((uint32_t)__popc(spp_mask) + 3u) >> 2;  // groups of four bits below 2^ceil(log2 spp)
+    for (uint32_t q = 0u, k = P.s; q < nq; q++, k >>= 4) {
+      const uint4 cx = m0[q], cy = m0[8u + q];
+      x ^= (cx.x & (0u - (k & 1u))) ^ (cx.y & (0u - ((k >> 1) & 1u))) ^ (cx.z & (0u - ((k >> 2) & 1u))) ^ (cx.w & (0u - ((k >> 3) & 1u)));
+      y ^= (cy.x & (0u - (k & 1u))) ^ (cy.y & (0u - ((k >> 1) & 1u))) ^ (cy.z & (0u - ((k >> 2) & 1u))) ^ (cy.w & (0u - ((k >> 3) & 1u)));
+    }
     x ^= mix32(key + (d0 + 1u) * 0x9e3779b9u);
     y ^= mix32(key + (d0 + 2u) * 0x9e3779b9u);
     u1 = fminf(kOneMinusEps, (float)x * 2.3283064365386963e-10f);
@@ -781,6 +789,26 @@ __device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const
 // fixed-point accumulators with atomics, instead of to its chunk's partial sum.
 // SND: sampler 2, the Sobol' sampler with its own dimensions per request (3.12): generator-matrix lookups in the service stage.
 // (Both variants keep the default path's register budget: 5 waves per SIMD, no spill -- tests/test_host.py.)
+// Wide box filter: 16 footprint slots per lane, two float4 records each ({r, g} and {b, samples, footprint}), a slot's records
+// of the 64 lanes side by side: 16 x 2 x 64 float4 per one-wave workgroup (RenderParams::wide_slots)
+constexpr uint32_t kWideSlotFloat4 = 16u * 2u * 64u;
+__device__ __forceinline__ void wide_slots_clear(float4 *slots, uint32_t lane) {
+  uint32_t lo = lane * 16u;
+  asm volatile("" : "+v"(lo));
+  char *lb = reinterpret_cast<char *>(slots + (size_t)blockIdx.x * kWideSlotFloat4) + lo;
+#pragma nounroll
+  for (uint32_t sl = 0u; sl < 16u; sl++) *reinterpret_cast<float4 *>(lb + sl * 2048u + 1024u) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// `n` samples of summed fixed-point radiance (r, g, b) to every pixel [x0, x1) x [y0, y1) of the cropped window
+__device__ __forceinline__ void film_add(unsigned long long *acc, const DevScene &S, int32_t x0, int32_t x1, int32_t y0, int32_t y1,
+                                         unsigned long long r, unsigned long long g, unsigned long long b, uint32_t n) {
+  for (int32_t py = y0; py < y1; py++)
+    for (int32_t px = x0; px < x1; px++) {
+      unsigned long long *a = acc + 4u * ((size_t)(py - S.cy0) * (size_t)(S.cx1 - S.cx0) + (size_t)(px - S.cx0));
+      atomicAdd(a, r); atomicAdd(a + 1, g); atomicAdd(a + 2, b); atomicAdd(a + 3, (unsigned long long)n);
+    }
+}
+
 template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK, bool WIDE = false, bool SND = false>
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
@@ -826,6 +854,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
 
   const LaneRecords rec = {reinterpret_cast<char *>(R.lane_state + (size_t)blockIdx.x * 320u + 128u), lane * 16u};
   uint32_t state = ST_FETCH;
+  if (WIDE) wide_slots_clear(R.wide_slots, lane);  // the lane's footprint slots start empty, and every flush leaves them so
   uint32_t region = blockIdx.x % R.n_regions;  // the part of the pixel list this wave draws from
   unsigned long long c_cam = 0, c_bounce = 0, c_shadow = 0, c_nodes = 0, c_tris = 0;
   Trav T;
@@ -992,16 +1021,44 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
               int32_t y0 = (int32_t)ceilf(dy - R.filter_ry), y1 = (int32_t)floorf(dy + R.filter_ry) + 1;
               x0 = max(x0, S.cx0); x1 = min(x1, S.cx1);
               y0 = max(y0, S.cy0); y1 = min(y1, S.cy1);
-              const unsigned long long qr = (unsigned long long)(long long)(fminf(fmaxf(P.L.x, 0.f), kFixedMax) * kFixedOne);
-              const unsigned long long qg = (unsigned long long)(long long)(fminf(fmaxf(P.L.y, 0.f), kFixedMax) * kFixedOne);
-              const unsigned long long qb = (unsigned long long)(long long)(fminf(fmaxf(P.L.z, 0.f), kFixedMax) * kFixedOne);
-              for (int32_t py = y0; py < y1; py++)
-                for (int32_t px = x0; px < x1; px++) {
-                  unsigned long long *a = R.acc + 4u * ((size_t)(py - S.cy0) * (size_t)(S.cx1 - S.cx0) + (size_t)(px - S.cx0));
-                  atomicAdd(a, qr); atomicAdd(a + 1, qg); atomicAdd(a + 2, qb); atomicAdd(a + 3, 1ull);
-                }
+              unsigned long long ar = (unsigned long long)(long long)(fminf(fmaxf(P.L.x, 0.f), kFixedMax) * kFixedOne);
+              unsigned long long ag = (unsigned long long)(long long)(fminf(fmaxf(P.L.y, 0.f), kFixedMax) * kFixedOne);
+              unsigned long long ab = (unsigned long long)(long long)(fminf(fmaxf(P.L.z, 0.f), kFixedMax) * kFixedOne);
+              uint32_t an = 1u;
+              // Integer sums do not care how they are grouped, and the samples of a chunk -- all in one pixel -- have few
+              // distinct footprints: each bound takes one of two neighbouring values as the film point moves through the
+              // pixel.  The chunk's samples are therefore added up per footprint in 16 slots of the lane (indexed by the
+              // parities of the four bounds; a sample that finds another footprint in its slot goes to the film by
+              // itself, which does not happen while a bound keeps to two values) and go to the film in ONE set of atomics
+              // per footprint at the chunk's end, instead of (2r + 1)^2 x 4 atomics per sample.
+              const int32_t X = R.sx0 + (int32_t)xr - 64, Y = R.sy0 + (int32_t)yr - 64;  // the bounds lie within +-20 of the pixel
+              const uint32_t key = (uint32_t)(x0 - X) | ((uint32_t)(x1 - X) << 7) | ((uint32_t)(y0 - Y) << 14) | ((uint32_t)(y1 - Y) << 21);
+              const uint32_t slot = ((uint32_t)x0 & 1u) | (((uint32_t)x1 & 1u) << 1) | (((uint32_t)y0 & 1u) << 2) | (((uint32_t)y1 & 1u) << 3);
+              // (address = wave-uniform base + a 32-bit lane offset made opaque, as for the path records: nothing of it is
+              // hoisted out of the kernel's loop into long-lived registers)
+              uint32_t so = lane_here() * 16u + slot * 2048u;
+              asm volatile("" : "+v"(so));
+              char *sb = reinterpret_cast<char *>(R.wide_slots + (size_t)blockIdx.x * kWideSlotFloat4) + so;
+              const float4 a1 = *reinterpret_cast<const float4 *>(sb + 1024);  // {b, samples, footprint}
+              const uint32_t pn = __float_as_uint(a1.z), pkey = __float_as_uint(a1.w);
               P.s++;
               if (sobol) P.rng.state &= 0xffffffffull;
+              if (__builtin_expect(pn != 0u && pkey != key, 0)) {
+                // the slot holds another footprint of this pixel (a bound that takes three values: possible only when
+                // r +- 1/2 lies within rounding of an integer): this sample goes to the film by itself
+                film_add(R.acc, S, x0, x1, y0, y1, ar, ag, ab, 1u);
+              } else {
+                if (pn != 0u) {
+                  const float4 a0 = *reinterpret_cast<const float4 *>(sb);         // {r, g}
+                  ar += (unsigned long long)__float_as_uint(a0.x) | ((unsigned long long)__float_as_uint(a0.y) << 32);
+                  ag += (unsigned long long)__float_as_uint(a0.z) | ((unsigned long long)__float_as_uint(a0.w) << 32);
+                  ab += (unsigned long long)__float_as_uint(a1.x) | ((unsigned long long)__float_as_uint(a1.y) << 32);
+                  an += pn;
+                }
+                *reinterpret_cast<float4 *>(sb) = make_float4(__uint_as_float((uint32_t)ar), __uint_as_float((uint32_t)(ar >> 32)), __uint_as_float((uint32_t)ag), __uint_as_float((uint32_t)(ag >> 32)));
+                *reinterpret_cast<float4 *>(sb + 1024) = make_float4(__uint_as_float((uint32_t)ab), __uint_as_float((uint32_t)(ab >> 32)), __uint_as_float(an), __uint_as_float(key));
+              }
+              // (a complete chunk's sums go to the film where the lane asks for its next item: fewer live registers there)
               state = P.s == chunk_begin(((item >> 6) & chunk_mask) + 1u, spp, kb) ? ST_FETCH : ST_NEW;
             } else {
             // FilmTile::AddSample with the box filter: this pixel, weight 1.  The chunk's partial sum lives in its record.
@@ -1030,6 +1087,25 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     // sum are those of DESIGN.md 3.1 whichever lane happens to take it; what the dynamic hand-out removes is the
     // idling of lanes whose pixels have short paths (sky) beside long ones, and -- items being a K-th of a pixel --
     // the wait for the sequential samples of the frame's most expensive pixels at its end. ----
+    if (WIDE && state == ST_FETCH) {
+      // the finished chunk's sums, one set of atomics per footprint (xr, yr are still its pixel)
+      const int32_t X = R.sx0 + (int32_t)xr - 64, Y = R.sy0 + (int32_t)yr - 64;
+      uint32_t lo = lane_here() * 16u;
+      asm volatile("" : "+v"(lo));
+      const char *lb = reinterpret_cast<const char *>(R.wide_slots + (size_t)blockIdx.x * kWideSlotFloat4) + lo;
+#pragma nounroll
+      for (uint32_t sl = 0u; sl < 16u; sl++) {
+        const float4 f1 = *reinterpret_cast<const float4 *>(lb + sl * 2048u + 1024u);
+        const uint32_t fn = __float_as_uint(f1.z), fk = __float_as_uint(f1.w);
+        if (fn == 0u) continue;
+        const float4 f0 = *reinterpret_cast<const float4 *>(lb + sl * 2048u);
+        film_add(R.acc, S, X + (int32_t)(fk & 127u), X + (int32_t)((fk >> 7) & 127u), Y + (int32_t)((fk >> 14) & 127u), Y + (int32_t)((fk >> 21) & 127u),
+                 (unsigned long long)__float_as_uint(f0.x) | ((unsigned long long)__float_as_uint(f0.y) << 32),
+                 (unsigned long long)__float_as_uint(f0.z) | ((unsigned long long)__float_as_uint(f0.w) << 32),
+                 (unsigned long long)__float_as_uint(f1.x) | ((unsigned long long)__float_as_uint(f1.y) << 32), fn);
+        *reinterpret_cast<float4 *>(const_cast<char *>(lb) + sl * 2048u + 1024u) = make_float4(0.f, 0.f, 0.f, 0.f);  // empty again
+      }
+    }
     for (;;) {
       const unsigned long long mw = __ballot(state == ST_FETCH);
       if (mw == 0ull) break;

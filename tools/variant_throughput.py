@@ -11,6 +11,8 @@ from pbrt_amd import scenes  # noqa: E402
 sd = scenes.random_mesh_scene(1_000_000, 2048, 2048)
 with pbrt_amd.Scene(sd, builder="gpu") as sc:
     for name, kw in (("default filter, stratified", {}), ("box filter radius 1.5 (fixed-point film)", dict(filter_width=(1.5, 1.5))),
+                     ("box filter radius 1.3 (footprints change from sample to sample)", dict(filter_width=(1.3, 1.3))),
+                     ("box filter radius 4.0", dict(filter_width=(4.0, 4.0))),
                      ("sampler 1 (padded 0,2)", dict(sampler="sobol")), ("sampler 2 (Sobol' proper)", dict(sampler="sobol_nd")),
                      ("default again", {})):
         film, st = sc.render(max_depth=8, spp=(8, 8), seed=0, **kw)
