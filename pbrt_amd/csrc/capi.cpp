@@ -1299,7 +1299,7 @@ static int ray_batch(pbrt_hip_scene *s, int64_t n, const float *o, const float *
   }
   {
     // launch_intersect uses at most 4096 workgroups of 4 waves
-    const uint32_t extra = s->dev.quad_stack_need + 2u > kQuadLdsStack ? s->dev.quad_stack_need + 2u - kQuadLdsStack : 0;  // sentinel + entries beyond the kQuadLdsStack - 1 kept in LDS
+    const uint32_t extra = s->dev.quad_stack_need + 2u > kIntersectLdsStack ? s->dev.quad_stack_need + 2u - kIntersectLdsStack : 0;  // sentinel + entries beyond the kIntersectLdsStack - 1 kept in LDS
     const size_t need = (size_t)4096 * 4 * 64 * extra;
     if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); RB_TRY(s->d_stack_overflow.alloc(need)); }
     B.stack_overflow = s->d_stack_overflow.p;

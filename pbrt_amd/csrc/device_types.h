@@ -105,6 +105,10 @@ inline bool render_force_overflow() {  // A-B runs
 }
 // the traversal kernel over ray batches keeps static rows
 constexpr uint32_t kQuadLdsEntries = kQuadLdsStack - 1u;
+// The ray-batch kernel (pbrt_hip_intersect / pbrt_hip_occluded: the walk alone, ~64 VGPRs) runs 8 waves per SIMD with 20 rows of a
+// lane's stack in LDS (20 KB per 4-wave workgroup, 8 per CU) and deeper entries in HBM: +9 % on 4 waves with 40 rows, +12 % at equal
+// rows (tools/experiments/dual_ray, profiles/r03y_traversal_occupancy_1m.txt)
+constexpr uint32_t kIntersectLdsStack = 20;
 
 struct DevScene {
   const uint4 *nodes;

@@ -1214,13 +1214,13 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
 }
 
 #ifndef PBRT_INTERSECT_WAVES_PER_SIMD
-#define PBRT_INTERSECT_WAVES_PER_SIMD 4
+#define PBRT_INTERSECT_WAVES_PER_SIMD 8
 #endif
 // The traversal loop alone over a ray batch, as persistent waves with dynamic fetch: a lane whose
 // walk is over writes its result and pulls its next ray while the other lanes keep walking.
 template <bool SPH, bool COUNT, int STACK>
 __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIMD)) intersect_kernel(const DevScene S, const RayBatch B, const int any_hit) {
-  __shared__ uint32_t lds_stack[4][COUNT ? STACK : kQuadLdsStack][64];
+  __shared__ uint32_t lds_stack[4][COUNT ? STACK : kIntersectLdsStack][64];
   __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t *stk = &lds_stack[wave][0][lane];
@@ -1263,7 +1263,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
       }
     }
     if (__ballot(have) == 0ull) break;
-    trav_run<COUNT, COUNT, (COUNT ? 0u : kQuadLdsStack)>(S, T, stk, stkt, ovf, have, tune, cn, ct);
+    trav_run<COUNT, COUNT, (COUNT ? 0u : kIntersectLdsStack)>(S, T, stk, stkt, ovf, have, tune, cn, ct);
   }
   EXP_PROBE_FINI_BLOCK();
   if (COUNT) {

@@ -52,8 +52,8 @@ __device__ __forceinline__ uint32_t pop_d(Ctx &c, const uint32_t *ovf, uint32_t 
   return e < R - 1u ? lds_load(c.sp) : ovf[(((c.base - stk0) / (R * kRowBytes)) * E + (e - (R - 1u))) * 64u + lane_here()];
 }
 
-template <bool SPH, int STEPS, uint32_t R, bool DUAL>
-__global__ void __launch_bounds__(256, 4) intersect_dual_kernel(const DevScene S, const RayBatch B, const int any_hit, const uint32_t min_done,
+template <bool SPH, int STEPS, uint32_t R, bool DUAL, int WAVES = 4>
+__global__ void __launch_bounds__(256, WAVES) intersect_dual_kernel(const DevScene S, const RayBatch B, const int any_hit, const uint32_t min_done,
                                                                 unsigned long long *probe) {
   __shared__ uint32_t lds_stack[4][DUAL ? 2 * R : R][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -255,7 +255,8 @@ __global__ void __launch_bounds__(256, 4) intersect_dual_kernel(const DevScene S
 }  // namespace pbrt_hip
 
 // C entry of the experiment: rays already on the host; returns the kernel's time.  mode 0: the product's intersect_kernel;
-// 1: this kernel with one ray per lane (the control for its own structure); 2: two rays per lane.
+// 1: this kernel with one ray per lane (the control for its own structure); 2: two rays per lane; 3 / 4 / 5: one ray per lane
+// at 6 / 8 / 5 resident waves per SIMD (26 / 20 / 31 LDS stack rows; deeper entries in HBM).
 extern "C" int exp_dual_intersect(pbrt_hip_scene *s, int64_t n, const float *o, const float *d, const float *tmax, float *t, uint32_t *prim,
                                   float *b1, float *b2, uint8_t *occ, int any_hit, int mode, int steps, uint32_t min_done, uint32_t min_walkers,
                                   uint32_t min_parked, float *ms_out, unsigned long long *probe_out) {
@@ -296,6 +297,9 @@ extern "C" int exp_dual_intersect(pbrt_hip_scene *s, int64_t n, const float *o, 
       const dim3 grid((uint32_t)nb), block(256);
 #define LAUNCH_D(STEPS_, DUAL_) hipLaunchKernelGGL((intersect_dual_kernel<false, STEPS_, (DUAL_ ? R : 2 * R), DUAL_>), grid, block, 0, nullptr, s->dev, B, any_hit, min_done, probe_out ? d_probe : nullptr)
       if (mode == 2) { if (steps == 1) LAUNCH_D(1, true); else if (steps == 2) LAUNCH_D(2, true); else LAUNCH_D(3, true); }
+      else if (mode == 3) hipLaunchKernelGGL((intersect_dual_kernel<false, 3, 26u, false, 6>), grid, block, 0, nullptr, s->dev, B, any_hit, min_done, probe_out ? d_probe : nullptr);  // 6 waves per SIMD: 26 rows
+      else if (mode == 4) hipLaunchKernelGGL((intersect_dual_kernel<false, 3, 20u, false, 8>), grid, block, 0, nullptr, s->dev, B, any_hit, min_done, probe_out ? d_probe : nullptr);  // 8 waves per SIMD: 20 rows
+      else if (mode == 5) hipLaunchKernelGGL((intersect_dual_kernel<false, 3, 31u, false, 5>), grid, block, 0, nullptr, s->dev, B, any_hit, min_done, probe_out ? d_probe : nullptr);  // 5 waves per SIMD: 31 rows
       else { if (steps == 1) LAUNCH_D(1, false); else if (steps == 2) LAUNCH_D(2, false); else LAUNCH_D(3, false); }
       X_TRY(hipGetLastError());
     }

@@ -74,7 +74,9 @@ def rays_of(sd, sc, res, bounces=5, seed=1):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     res = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "dual_ray.hip")):
+    newest = max(os.path.getmtime(os.path.join(HERE, "dual_ray.hip")), os.path.getmtime(os.path.join(ROOT, "pbrt_amd", "csrc", "kernels.hip")),
+                 os.path.getmtime(os.path.join(ROOT, "pbrt_amd", "csrc", "device_types.h")))
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         build()
     lib = C.CDLL(LIB)
     fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
@@ -100,9 +102,13 @@ def main():
         for name, (o, d, tm), any_hit in (("closest-hit", (co, cd, ct), False), ("shadow", (so, sdd, stm), True)):
             ref, ms0, _ = run(o, d, tm, any_hit, 0)
             print(f"{name}: product intersect_kernel                  {ms0:8.2f} ms  {len(o) / ms0 / 1e3:7.1f} Mrays/s")
+            for mode, label in ((5, "one ray per lane, 5 waves per SIMD"), (3, "one ray per lane, 6 waves per SIMD"), (4, "one ray per lane, 8 waves per SIMD")):
+                out, ms, pr = run(o, d, tm, any_hit, mode, 3, 1, 36)
+                same = np.array_equal(out, ref) if any_hit else all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(out, ref))
+                print(f"{name}: experiment, {label}: {ms:8.2f} ms  {len(o) / ms / 1e3:7.1f} Mrays/s  ({'identical' if same else 'RESULTS DIFFER'}; node-step passes {pr[0]} with {pr[1] / max(pr[0], 1):.1f} lanes)")
             for mode, label in ((1, "one ray per lane"), (2, "TWO rays per lane")):
-                for steps in (3, 2):
-                    for min_done, min_walkers in ((1, 36), (1, 48), (1, 64), (4, 64), (8, 64)):
+                for steps in (3,):
+                    for min_done, min_walkers in ((1, 36),):
                         out, ms, pr = run(o, d, tm, any_hit, mode, steps, min_done, min_walkers)
                         same = np.array_equal(out, ref) if any_hit else all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(out, ref))
                         lanes = pr[1] / max(pr[0], 1)
