@@ -304,6 +304,12 @@ def main():
             roof["valu"] = {k: pmc.get(k) for k in ("valu_issue_busy_measured", "valu_issue_quadcycles_per_ray", "valu_dual_issue_share_of_instructions",
                                                     "valu_instructions_per_ray", "lane_utilisation", "l2_hit_rate", "wave_wait_frac", "wave_issue_wait_frac", "wave_issuing_frac",
                                                     "clock_ghz_in_profile", "round", "build_id")}
+            if pmc.get("l1_accesses_per_cu_clock") is not None:
+                # the other shared resource, from the same profile: the CU's vector L1.  A lane's 16-byte
+                # gather is one cache access; the address unit waits for the L1 `ta_stalled_by_l1_frac` of the cycles.  No peak
+                # is claimed for it (about one access per clock is what this kernel sustains), so no frac either.
+                roof["l1"] = {k: pmc.get(k) for k in ("l1_accesses_per_cu_clock", "l1_accesses_per_ray", "ta_stalled_by_l1_frac", "l1_tag_conflict_stall_frac")}
+                roof["l1"]["achieved_G_accesses_per_s"] = pmc["l1_accesses_per_ray"] * rays_per_s / 1e9
             roof["valu"]["valu_busy_bracket"] = [m, m]  # a measurement, not a model: the r02 bracket [0.72, 1.07] is gone
             roof["valu"]["class_model_r02"] = {k: pmc.get(k) for k in ("valu_busy_frac_at_profile_clock", "valu_issue_cycles_per_ray", "mean_issue_cycles_per_instruction")}
             roof["valu"]["source"] = f"{os.path.relpath(pmc_path, ROOT)} (rocprofv3 --pmc passes of tools/measure_round.sh; counters calibrated in profiles/r03c_issue_counter_calibration.txt)"

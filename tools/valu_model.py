@@ -122,6 +122,12 @@ def main():
         # where a resident wave's time goes: waiting for memory (s_waitcnt), waiting for its turn to issue, issuing
         "wave_issue_wait_frac": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_INST_ANY") else None,
         "wave_issuing_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") and c.get("SQ_ACTIVE_INST_ANY") else None,
+        # the CU's vector L1 (profiles/r03end_c3_l1_path_counters.txt): cache accesses per CU and clock (a lane's 16-byte gather is one
+        # access; the L1 handles one per clock), and how often the address unit waits for it
+        "l1_accesses_per_cu_clock": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (kernel_cycles * n_simd / 4.0) if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") else None,
+        "l1_accesses_per_ray": c["TCP_TOTAL_CACHE_ACCESSES_sum"] / rays if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and rays else None,
+        "ta_stalled_by_l1_frac": c["TA_ADDR_STALLED_BY_TC_CYCLES_sum"] / (kernel_cycles * n_simd / 4.0) if c.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum") else None,
+        "l1_tag_conflict_stall_frac": c["TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"] / (kernel_cycles * n_simd / 4.0) if c.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum") else None,
         "salu_per_valu": c.get("SQ_INSTS_SALU", 0.0) / total,
         "probe_rays": rays, "probe_samples": c.get("PROBE_SAMPLES"),
         "valu_instructions_per_ray": total / rays if rays else None, "valu_issue_cycles_per_ray": best / rays if rays else None,
