@@ -1,4 +1,4 @@
-// Microbenchmark: random record gathers of 64 / 128 / 256 bytes per lane (own-lane dwordx4 loads) from tables of
+// Microbenchmark: random record gathers of 32 / 48 / 64 / 128 / 256 bytes per lane (own-lane dwordx4 loads) from tables of
 // different sizes: is the limit past L2 a REQUEST rate (records/s flat) or a BYTE rate (TB/s flat)?
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -36,8 +36,8 @@ int main() {
   char *tab; float *out;
   const size_t cap = (size_t)2048 << 20;
   hipMalloc(&tab, cap); hipMalloc(&out, 64); hipMemset(tab, 1, cap);
-  for (size_t mb : {2, 16, 48, 112, 512, 2048}) {
-    run<2>(tab, mb << 20, out); run<4>(tab, mb << 20, out); run<8>(tab, mb << 20, out); run<16>(tab, mb << 20, out);
+  for (size_t mb : {1, 2, 16, 28, 48, 112, 512, 2048}) {  // (28 MB: the quad nodes of BASELINE C3; 48-byte records: r03, would a node of three 16-byte pieces gather faster?)
+    run<2>(tab, mb << 20, out); run<3>(tab, mb << 20, out); run<4>(tab, mb << 20, out); run<8>(tab, mb << 20, out); run<16>(tab, mb << 20, out);
   }
   return 0;
 }
