@@ -35,6 +35,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured stream)
 CLOCK_GHZ = 2.4         # max shader clock (same guide); the clock a kernel holds is lower, so frac is conservative
 SIMDS_PER_CU = 4
+# what the CUs' vector L1s deliver to random 16-byte-per-lane gathers of 64-byte records that hit in L2: 173.4 G records/s x 4 accesses,
+# measured with tools/ubench/gather_wide.hip (profiles/r03end_gather_wide_48B.txt); 1.13 accesses per CU and clock at 2.4 GHz
+L1_GATHER_ROOF_G_ACCESSES = 173.4 * 4
 
 WORKLOADS = {
     # name: (scene factory args, integrator, maxdepth, (spp_x, spp_y), description)
@@ -306,10 +309,14 @@ def main():
                                                     "clock_ghz_in_profile", "round", "build_id")}
             if pmc.get("l1_accesses_per_cu_clock") is not None:
                 # the other shared resource, from the same profile: the CU's vector L1.  A lane's 16-byte
-                # gather is one cache access; the address unit waits for the L1 `ta_stalled_by_l1_frac` of the cycles.  No peak
-                # is claimed for it (about one access per clock is what this kernel sustains), so no frac either.
+                # gather is one cache access; the address unit waits for the L1 `ta_stalled_by_l1_frac` of the cycles.
                 roof["l1"] = {k: pmc.get(k) for k in ("l1_accesses_per_cu_clock", "l1_accesses_per_ray", "ta_stalled_by_l1_frac", "l1_tag_conflict_stall_frac")}
                 roof["l1"]["achieved_G_accesses_per_s"] = pmc["l1_accesses_per_ray"] * rays_per_s / 1e9
+                # the roof this is measured against: random 64-byte records gathered as 4 x dwordx4 per lane from an L2-resident
+                # table, tools/ubench/gather_wide.hip on this chip (profiles/r03end_gather_wide_48B.txt: 173.4 G records/s x 4)
+                roof["l1"]["peak_G_accesses_per_s"] = L1_GATHER_ROOF_G_ACCESSES
+                roof["l1"]["frac"] = roof["l1"]["achieved_G_accesses_per_s"] / L1_GATHER_ROOF_G_ACCESSES
+                roof["l1"]["peak_source"] = "tools/ubench/gather_wide.hip, 1-2 MB table, 64-byte records: 173.4 G records/s (profiles/r03end_gather_wide_48B.txt)"
             roof["valu"]["valu_busy_bracket"] = [m, m]  # a measurement, not a model: the r02 bracket [0.72, 1.07] is gone
             roof["valu"]["class_model_r02"] = {k: pmc.get(k) for k in ("valu_busy_frac_at_profile_clock", "valu_issue_cycles_per_ray", "mean_issue_cycles_per_instruction")}
             roof["valu"]["source"] = f"{os.path.relpath(pmc_path, ROOT)} (rocprofv3 --pmc passes of tools/measure_round.sh; counters calibrated in profiles/r03c_issue_counter_calibration.txt)"
