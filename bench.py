@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, nargs=2, default=None, help="override strata (diagnostics; invalid as a headline)")
-    ap.add_argument("--builder", default="gpu", choices=["host", "gpu"],
+    ap.add_argument("--builder", default="gpu", choices=["host", "gpu", "host-optimized"],
                     help="accelerator builder: the device builder (the product's default: milliseconds) or the host's binned SAH "
                          "(one core, about a second for 1M triangles); same film either way")
     ap.add_argument("--sampler", default="stratified", choices=["stratified", "sobol"])

@@ -16,7 +16,8 @@ LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2
 INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
 FLAG_COUNTERS = 1
 FLAG_WALK_COUNTERS = 2
-SCENE_GPU_BUILD = 1  # pbrt_hip_scene_create_ex flag
+SCENE_GPU_BUILD = 1  # pbrt_hip_scene_create_ex flags
+SCENE_OPTIMIZED_TREE = 2
 
 
 def _fp(a):
@@ -202,7 +203,7 @@ def quad_build_host(P, idx, split_leaves=True):
     return quads[:nq.value].copy(), need.value
 
 
-TREES = {"sah": 0, "sbvh": 1, "default": 0xFFFFFFFF}
+TREES = {"sah": 0, "sbvh": 1, "reinsert": 2, "default": 0xFFFFFFFF}
 
 
 def quad_build_host_ex(P, idx, tree="default", split_leaves=True):
@@ -260,7 +261,7 @@ class MultiScene:
         desc = SceneDesc()
         keep = fill_desc(desc, self.sd, Material, Light, Sphere)
         h = C.c_void_p()
-        check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), {"host": 0, "gpu": SCENE_GPU_BUILD}[builder], C.byref(h)),
+        check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), {"host": 0, "gpu": SCENE_GPU_BUILD, "host-optimized": SCENE_OPTIMIZED_TREE}[builder], C.byref(h)),
               "pbrt_hip_multi_create")
         del keep
         self._h = h
@@ -323,7 +324,7 @@ class Scene:
         if builder is None:
             check(lib().pbrt_hip_scene_create(C.byref(desc), device, C.byref(h)), "pbrt_hip_scene_create")
         else:
-            flags = {"host": 0, "gpu": SCENE_GPU_BUILD}[builder]
+            flags = {"host": 0, "gpu": SCENE_GPU_BUILD, "host-optimized": SCENE_OPTIMIZED_TREE}[builder]
             check(lib().pbrt_hip_scene_create_ex(C.byref(desc), device, flags, C.byref(h)), "pbrt_hip_scene_create_ex")
         del keep
         self._h = h

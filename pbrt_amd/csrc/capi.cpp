@@ -546,7 +546,7 @@ void make_quad_nodes(const RefBvh &b, const uint32_t *slot_of_ref, bool split_le
 // = the canonical binned-SAH tree `canon` (the oracle's tree), kTreeSbvh = a tree of its own over triangle
 // references with spatial splits (sbvh_build.cpp).  Either way a leaf child's slot refers to the triangle records in
 // `canon`'s leaf order (a triangle reached through several references has ONE record).
-enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeSbvh = 1 };
+enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeSbvh = 1, kTreeReinsert = 2 };  // (= PBRT_HIP_TREE_*)
 SbvhParams sbvh_params() {
   SbvhParams p;
   if (const char *v = debug_knob("PBRT_HIP_SBVH_ALPHA")) p.alpha = (float)std::atof(v);
@@ -563,14 +563,24 @@ SbvhParams sbvh_params() {
 ProductionTree production_tree_default() {
   const char *v = debug_knob("PBRT_HIP_TREE");
   if (v && std::strcmp(v, "sbvh") == 0) return kTreeSbvh;
+  if (v && std::strcmp(v, "reinsert") == 0) return kTreeReinsert;
   if (v && std::strcmp(v, "sah") == 0) return kTreeCanonical;
   return kTreeCanonical;
 }
 void build_production_quads(const Bvh &canon, const float *P, const uint32_t *idx, uint32_t n_tris, ProductionTree tree,
                             bool split_leaves, QuadNodes *out, uint32_t *n_refs = nullptr) {
   RefBvh rb;
-  if (tree == kTreeSbvh && n_tris >= 2) {
-    build_sbvh(P, idx, n_tris, sbvh_params(), &rb);
+  if ((tree == kTreeSbvh || tree == kTreeReinsert) && n_tris >= 2) {
+    SbvhParams prm = sbvh_params();
+    if (tree == kTreeReinsert) {  // object splits only (every triangle one reference), then the global optimisation
+      prm.alpha = std::numeric_limits<float>::infinity();
+      prm.budget = 0.f;
+    }
+    build_sbvh(P, idx, n_tris, prm, &rb);
+    if (tree == kTreeReinsert) {
+      const char *np = debug_knob("PBRT_HIP_REINSERT"), *nf = debug_knob("PBRT_HIP_REINSERT_FRAC");
+      reinsert_optimize(&rb, np ? std::atoi(np) : 8, nf ? (float)std::atof(nf) : 1.0f);
+    }
     std::vector<uint32_t> slot_of_tri(n_tris), slot_of_ref(rb.ref_tri.size());
     for (uint32_t s = 0; s < n_tris; s++) slot_of_tri[canon.order[s]] = s;
     for (size_t r = 0; r < rb.ref_tri.size(); r++) slot_of_ref[r] = slot_of_tri[rb.ref_tri[r]];
@@ -667,7 +677,7 @@ int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t
                                 float *root_box, uint32_t *n_refs, float *exact_boxes) {
   try {
     if ((n_tris && (!P || !idx)) || !n_quads || !stack_need) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: null argument");
-    if (tree > PBRT_HIP_TREE_SBVH && tree != PBRT_HIP_TREE_DEFAULT) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: unknown tree");
+    if (tree > PBRT_HIP_TREE_REINSERT && tree != PBRT_HIP_TREE_DEFAULT) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: unknown tree");
     for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
       if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: vertex index out of range");
     if (first_non_finite_vertex(P, idx, n_tris) >= 0) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: a vertex is not finite");
@@ -742,7 +752,9 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
 
     // --- accelerator: the host's binned-SAH builder, or (PBRT_HIP_SCENE_GPU_BUILD) the device builder further down ---
-    if (flags & ~PBRT_HIP_SCENE_GPU_BUILD) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
+    if (flags & ~(PBRT_HIP_SCENE_GPU_BUILD | PBRT_HIP_SCENE_OPTIMIZED_TREE)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
+    if ((flags & PBRT_HIP_SCENE_GPU_BUILD) && (flags & PBRT_HIP_SCENE_OPTIMIZED_TREE))
+      return fail(PBRT_HIP_ERR_INVALID, "scene_create: PBRT_HIP_SCENE_OPTIMIZED_TREE is a host build, not combined with PBRT_HIP_SCENE_GPU_BUILD");
     s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && d->n_tris >= 2;
     if (d->n_tris > (1u << 24)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 2^24 triangles (leaf references hold a 24-bit slot)");
     PairNodes pairs;
@@ -815,7 +827,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     if (!s->gpu_built) {
       const auto t0 = std::chrono::steady_clock::now();
       const char *sl = debug_knob("PBRT_HIP_SPLIT_LEAVES");
-      build_production_quads(s->bvh, d->P, d->idx, d->n_tris, production_tree_default(), !(sl && sl[0] == '0'), &quads);
+      build_production_quads(s->bvh, d->P, d->idx, d->n_tris, (flags & PBRT_HIP_SCENE_OPTIMIZED_TREE) ? kTreeReinsert : production_tree_default(),
+                             !(sl && sl[0] == '0'), &quads);
       s->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     HIP_TRY(s->d_nodes.alloc(pairs.q.size()));

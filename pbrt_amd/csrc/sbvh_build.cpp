@@ -455,4 +455,132 @@ void refs_of_bvh(const Bvh &bv, const float *P, const uint32_t *idx, RefBvh *out
   }
 }
 
+
+// ---- global optimisation of a built tree by re-insertion (sbvh_build.hpp): an interior node is taken out (its sibling moves up), and
+// its two children are put back where they add the least surface area, found by branch and bound.  Leaves (one reference) stay whole.
+namespace {
+struct ON { float lo[3], hi[3]; int parent, l, r; uint32_t ref; };
+inline float on_area(const float *lo, const float *hi) { const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; return (dx * dy + dx * dz) + dy * dz; }
+inline float on_union_area(const ON &a, const ON &b) {
+  float lo[3], hi[3];
+  for (int k = 0; k < 3; k++) { lo[k] = std::min(a.lo[k], b.lo[k]); hi[k] = std::max(a.hi[k], b.hi[k]); }
+  return on_area(lo, hi);
+}
+}  // namespace
+
+void reinsert_optimize(RefBvh *t, int passes, float frac) {
+  const int n = (int)t->nodes.size();
+  if (n < 7) return;
+  std::vector<ON> T((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const BvhNode &b = t->nodes[i];
+    ON &o = T[i];
+    for (int k = 0; k < 3; k++) { o.lo[k] = b.lo[k]; o.hi[k] = b.hi[k]; }
+    o.parent = -1;
+    if (b.count_axis & 0xffffu) { o.l = o.r = -1; o.ref = b.offset; }
+    else { o.l = i + 1; o.r = (int)b.offset; o.ref = 0; }
+  }
+  for (int i = 0; i < n; i++) if (T[i].l >= 0) { T[T[i].l].parent = i; T[T[i].r].parent = i; }
+  int root = 0;
+  auto refit_up = [&](int i) {
+    for (; i >= 0; i = T[i].parent) {
+      const ON &a = T[T[i].l], &b = T[T[i].r];
+      for (int k = 0; k < 3; k++) { T[i].lo[k] = std::min(a.lo[k], b.lo[k]); T[i].hi[k] = std::max(a.hi[k], b.hi[k]); }
+    }
+  };
+  auto replace_child = [&](int p, int from, int to) {
+    if (p < 0) { root = to; T[to].parent = -1; return; }
+    if (T[p].l == from) T[p].l = to; else T[p].r = to;
+    T[to].parent = p;
+  };
+  struct QE { float c; int node; bool operator<(const QE &o) const { return c > o.c; } };
+  std::vector<QE> heap;
+  auto find_best = [&](int x) {
+    const float ax = on_area(T[x].lo, T[x].hi);
+    float best_cost = std::numeric_limits<float>::infinity();
+    int best = root;
+    heap.clear();
+    heap.push_back({0.f, root});
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end());
+      const QE e = heap.back();
+      heap.pop_back();
+      if (e.c + ax >= best_cost) break;
+      const ON &y = T[e.node];
+      const float direct = on_union_area(y, T[x]), total = e.c + direct;
+      if (total < best_cost) { best_cost = total; best = e.node; }
+      const float down = total - on_area(y.lo, y.hi);
+      if (y.l >= 0 && down + ax < best_cost) {
+        heap.push_back({down, y.l}); std::push_heap(heap.begin(), heap.end());
+        heap.push_back({down, y.r}); std::push_heap(heap.begin(), heap.end());
+      }
+    }
+    return best;
+  };
+  std::vector<int> cand;
+  for (int pass = 0; pass < passes; pass++) {
+    cand.clear();
+    for (int i = 0; i < n; i++)
+      if (T[i].l >= 0 && i != root && T[i].parent != root) cand.push_back(i);
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return on_area(T[a].lo, T[a].hi) > on_area(T[b].lo, T[b].hi); });
+    const size_t take = std::max<size_t>(1, (size_t)(frac * (float)cand.size()));
+    for (size_t ci = 0; ci < take && ci < cand.size(); ci++) {
+      const int N = cand[ci];
+      const int P = T[N].parent;
+      if (N == root || P < 0 || P == root || T[N].l < 0) continue;  // (the tree has changed under the list)
+      const int G = T[P].parent, S = T[P].l == N ? T[P].r : T[P].l;
+      int A = T[N].l, B = T[N].r;
+      if (on_area(T[A].lo, T[A].hi) < on_area(T[B].lo, T[B].hi)) std::swap(A, B);
+      replace_child(G, P, S);
+      refit_up(G);
+      const int freeN[2] = {N, P}, sub[2] = {A, B};
+      for (int k = 0; k < 2; k++) {
+        const int X = sub[k], F = freeN[k], best = find_best(X), bp = T[best].parent;
+        replace_child(bp, best, F);
+        T[F].l = best; T[F].r = X;
+        T[best].parent = F; T[X].parent = F;
+        refit_up(F);
+      }
+    }
+  }
+  // flatten (depth first, child 0 = the child whose centre is lower along the axis that separates the two centres most)
+  RefBvh out;
+  out.nodes.reserve((size_t)n);
+  out.ref_tri.reserve(t->ref_tri.size());
+  struct It { int node; int patch; uint32_t level; };
+  std::vector<It> st = {{root, -1, 1u}};
+  while (!st.empty()) {
+    const It it = st.back();
+    st.pop_back();
+    const int me = (int)out.nodes.size();
+    if (it.patch >= 0) out.nodes[it.patch].offset = (uint32_t)me;
+    if (it.level > out.depth) out.depth = it.level;
+    const ON &o = T[it.node];
+    BvhNode b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = o.lo[k]; b.hi[k] = o.hi[k]; }
+    if (o.l < 0) {
+      b.offset = (uint32_t)out.ref_tri.size();
+      b.count_axis = 1u;
+      out.ref_tri.push_back(t->ref_tri[o.ref]);
+      for (int k = 0; k < 3; k++) { out.ref_lo.push_back(t->ref_lo[3 * (size_t)o.ref + k]); }
+      for (int k = 0; k < 3; k++) { out.ref_hi.push_back(t->ref_hi[3 * (size_t)o.ref + k]); }
+      out.nodes.push_back(b);
+    } else {
+      int c0 = o.l, c1 = o.r, ax = 0;
+      float sep = -1.f;
+      for (int k = 0; k < 3; k++) {
+        const float d = std::fabs((T[c0].lo[k] + T[c0].hi[k]) - (T[c1].lo[k] + T[c1].hi[k]));
+        if (d > sep) { sep = d; ax = k; }
+      }
+      if ((T[c0].lo[ax] + T[c0].hi[ax]) > (T[c1].lo[ax] + T[c1].hi[ax])) std::swap(c0, c1);
+      b.offset = 0;
+      b.count_axis = (uint32_t)ax << 16;
+      out.nodes.push_back(b);
+      st.push_back({c1, me, it.level + 1});  // right: patched when reached
+      st.push_back({c0, -1, it.level + 1});  // left: the next node
+    }
+  }
+  *t = std::move(out);
+}
+
 }  // namespace pbrt_hip

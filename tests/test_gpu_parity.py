@@ -622,6 +622,31 @@ def _random_scene(seed):
                      xres=xres, yres=yres, crop=crop).normalized(), rng
 
 
+def test_optimized_tree_scene_matches_oracle(gpu, oracle):
+    """PBRT_HIP_SCENE_OPTIMIZED_TREE (host build + re-insertion): the same film, hit records and occlusion bit for bit (the tie
+    rule makes a hit independent of the tree), fewer node fetches than the default host tree, and the counter flags still count
+    the oracle's canonical walk."""
+    sd = SMALL_SCENES["mesh20k"]()
+    ref, rst = oracle.OracleScene(sd).render(max_depth=5, spp=(2, 2), seed=3)
+    o, d, tmax = random_rays(20000, 5, inside=2.5)
+    rhit = oracle.OracleScene(sd).intersect(o, d, tmax)
+    walk = {}
+    for builder in ("host", "host-optimized"):
+        with gpu.Scene(sd, builder=builder) as sc:
+            film, st = sc.render(max_depth=5, spp=(2, 2), seed=3, counters=True)
+            _, wk = sc.render(max_depth=5, spp=(2, 2), seed=3, counters="walk")
+            hit = sc.intersect(o, d, tmax)
+            occ = sc.occluded(o, d, tmax)
+        assert_bit_equal(film, ref, f"{builder}: film")
+        for a, b, what in zip(hit[:4], rhit[:4], ("t", "prim", "b1", "b2")):
+            assert_bit_equal(a, b, f"{builder}: {what}")
+        assert np.array_equal(occ != 0, oracle.OracleScene(sd).occluded(o, d, tmax) != 0)
+        for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+            assert st[k] == rst[k], f"{builder} {k}: {st[k]} vs oracle {rst[k]}"
+        walk[builder] = wk["nodes_visited"]
+    assert walk["host-optimized"] < walk["host"], walk
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PBRT_SOAK_SEEDS", "48"))))
 def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     """Triangle counts 0..300 (with duplicates and degenerate triangles), random materials (mirrors, emitters),
