@@ -41,7 +41,7 @@ extern "C" {
     pub fn pbrt_hip_device_count() -> c_int;
     pub fn pbrt_hip_last_error() -> *const c_char;
     pub fn pbrt_hip_scene_create(desc: *const HipSceneDesc, device: c_int, out: *mut *mut HipScene) -> c_int;
-    pub fn pbrt_hip_scene_create_ex(desc: *const HipSceneDesc, device: c_int, flags: u32, out: *mut *mut HipScene) -> c_int; // flags: 1 = build the BVH on the GPU
+    pub fn pbrt_hip_scene_create_ex(desc: *const HipSceneDesc, device: c_int, flags: u32, out: *mut *mut HipScene) -> c_int; // flags: 1 = build the BVH on the GPU; 2 = host build + re-insertion-optimised tree (~5 % fewer node fetches, ~30 s per 1 M triangles)
     pub fn pbrt_hip_scene_destroy(scene: *mut HipScene);
     pub fn pbrt_hip_render(scene: *mut HipScene, desc: *const HipRenderDesc,
                            film_xyzw: *mut f32, stats: *mut HipStats) -> c_int;
