@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Node steps / triangle tests per ray of the production walk's tree, on the CPU (no GPU needed): builds the 4-wide tree of
 a BASELINE mesh scene with each binary-tree builder (`sah` = canonical binned SAH, `sbvh` = SAH over references with
-spatial splits), walks a path-tracing-like set of rays through it with oracle/quad_walk.cpp (the kernel's step restated),
+spatial splits, `reinsert` = SAH over references optimised by re-insertion: PBRT_HIP_SCENE_OPTIMIZED_TREE's tree), walks a path-tracing-like set of rays through it with oracle/quad_walk.cpp (the kernel's step restated),
 checks every hit against the oracle's own BVH, and prints the per-ray work.
 
 usage: walk_sim.py [n_tris] [trees...]      e.g.  PBRT_HIP_DEBUG_KNOBS=1 PBRT_HIP_SBVH_BUDGET=0.3 walk_sim.py 100000 sah sbvh
