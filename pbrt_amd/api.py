@@ -315,8 +315,10 @@ class Scene:
     """A scene resident in HBM (flattened BVH + leaf-ordered triangles + tables)."""
 
     def __init__(self, sd, device=-1, builder=None):
-        """builder: None (host SAH builder unless PBRT_HIP_BUILDER=gpu), "host" or "gpu" (accelerator built on the
-        device: same film and hit records, no canonical counters)."""
+        """builder: None (host SAH builder unless PBRT_HIP_BUILDER=gpu), "host", "gpu" (accelerator built on the device:
+        milliseconds; the product's default elsewhere) or "host-optimized" (PBRT_HIP_SCENE_OPTIMIZED_TREE: the host's tree optimised
+        by re-insertion -- about 5 % fewer node fetches per ray for about half a minute per million triangles).  Same film and hit
+        records whichever is used."""
         self.sd = sd.normalized()
         desc = SceneDesc()
         keep = fill_desc(desc, self.sd, Material, Light, Sphere)
