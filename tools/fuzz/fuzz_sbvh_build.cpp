@@ -1,7 +1,8 @@
 // ASan / UBSan harness for the spatial-split builder (pbrt_amd/csrc/sbvh_build.cpp): random, huge, tiny, identical and
 // geometric-progression meshes (modes 0..3, 6; non-finite vertices are refused before any builder runs, so modes 4 / 5
 // of fuzz_bvh_build are not repeated).  Checks: every triangle has at least one reference, every leaf one reference,
-// every reference box lies inside the triangle's own box.   usage: fuzz_sbvh_build <seed> <iterations> [mode]
+// every reference box lies inside the triangle's own box; then the re-insertion pass (reinsert_optimize) on the same tree.   usage: fuzz_sbvh_build <seed> <iterations> [mode]
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +44,42 @@ int main(int argc, char **argv) {
     for (uint32_t t = 0; t < n; t++) if (!seen[t]) { std::printf("triangle %u has no reference (mode %d, n %u)\n", t, mode, n); return 1; }
     for (const auto &nd : b.nodes) if ((nd.count_axis & 0xffffu) > 1u) { std::printf("leaf with %u references\n", nd.count_axis & 0xffffu); return 1; }
     if (b.ref_tri.size() > (size_t)((double)n * (1.0 + prm.budget)) + 1) { std::printf("budget exceeded: %zu refs for %u triangles\n", b.ref_tri.size(), n); return 1; }
+    // the re-insertion pass of PBRT_HIP_SCENE_OPTIMIZED_TREE on the same tree: the references survive as a permutation, every leaf holds
+    // one, every node's box encloses its children's, child links stay inside the array, the depth field is the tree's depth
+    {
+      std::vector<uint32_t> before(b.ref_tri.begin(), b.ref_tri.end());
+      pbrt_hip::reinsert_optimize(&b, 1 + (int)(rng() % 3), (rng() & 1) ? 1.0f : 0.3f);
+      std::vector<uint32_t> after(b.ref_tri.begin(), b.ref_tri.end());
+      std::sort(before.begin(), before.end());
+      std::sort(after.begin(), after.end());
+      if (before != after) { std::printf("re-insertion changed the references (mode %d, n %u)\n", mode, n); return 1; }
+      if (b.ref_lo.size() != 3 * b.ref_tri.size() || b.ref_hi.size() != 3 * b.ref_tri.size()) { std::printf("reference boxes lost\n"); return 1; }
+      struct It { uint32_t node, level; };
+      std::vector<It> st = {{0u, 1u}};
+      uint32_t depth = 0, leaves = 0;
+      while (!st.empty() && !b.nodes.empty()) {
+        const It it = st.back();
+        st.pop_back();
+        if (it.node >= b.nodes.size()) { std::printf("child link out of range\n"); return 1; }
+        const auto &nd = b.nodes[it.node];
+        if (it.level > depth) depth = it.level;
+        if (nd.count_axis & 0xffffu) {
+          if ((nd.count_axis & 0xffffu) != 1u || nd.offset >= b.ref_tri.size()) { std::printf("bad leaf after re-insertion\n"); return 1; }
+          leaves++;
+          for (int a = 0; a < 3; a++)
+            if (nd.lo[a] > b.ref_lo[3 * (size_t)nd.offset + a] || nd.hi[a] < b.ref_hi[3 * (size_t)nd.offset + a]) { std::printf("leaf box does not hold its reference\n"); return 1; }
+          continue;
+        }
+        const uint32_t kids[2] = {it.node + 1, nd.offset};
+        for (uint32_t c : kids) {
+          if (c >= b.nodes.size()) { std::printf("child link out of range\n"); return 1; }
+          for (int a = 0; a < 3; a++)
+            if (b.nodes[c].lo[a] < nd.lo[a] || b.nodes[c].hi[a] > nd.hi[a]) { std::printf("node box does not enclose its child (mode %d)\n", mode); return 1; }
+          st.push_back({c, it.level + 1});
+        }
+      }
+      if (!b.nodes.empty() && (leaves != b.ref_tri.size() || depth != b.depth)) { std::printf("leaves %u of %zu refs, depth %u vs %u\n", leaves, b.ref_tri.size(), depth, b.depth); return 1; }
+    }
   }
   std::printf("ok\n");
 }
