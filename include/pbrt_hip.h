@@ -133,10 +133,11 @@ const char *pbrt_hip_build_id(void);
  * Input is validated before any device work: indices in range, vertices / spheres / camera matrix finite, sphere radii
  * positive, 0 < fov < 180 (PBRT_HIP_ERR_INVALID otherwise). ---- */
 int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_scene **out);
-/* The same with options.  PBRT_HIP_SCENE_GPU_BUILD: build the accelerator on the device (Morton codes, radix sort,
- * binary radix tree, collapse into the quantised 4-wide nodes) instead of the host's binned-SAH
- * builder: milliseconds instead of a second for 1M triangles, a tree of the same quality, the SAME film and hit
- * records bit for bit (a hit does not depend on the tree).  The counter flags of render / intersect
+/* The same with options.  PBRT_HIP_SCENE_GPU_BUILD: build the accelerator on the device (Morton order, level-synchronous
+ * binned SAH, the tree optimised by parallel re-insertion, collapse into the quantised 4-wide nodes; SURVEY.md 8 row f3;
+ * stands in for what core/api.rs:237 names "bvh" and api.rs:446-453 would have built) instead of the host's binned-SAH
+ * builder: tens of milliseconds instead of a second for 1M triangles, a tree rays cross in fewer steps, the SAME film and
+ * hit records bit for bit (a hit does not depend on the tree).  The counter flags of render / intersect
  * count the oracle's canonical walk: for such a scene the canonical tree is built on the host at the first call that
  * asks for them (vertex / index buffers read back; about a second for 1M triangles, never on the render path).
  * pbrt_hip_scene_create(desc, ...) == pbrt_hip_scene_create_ex(desc, ..., getenv("PBRT_HIP_BUILDER") == "gpu"). */
@@ -147,9 +148,15 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_
  * for a build of about a minute per million triangles on one core: for renders long enough to pay for it.  Same film and hit records
  * bit for bit.  Not combined with PBRT_HIP_SCENE_GPU_BUILD (PBRT_HIP_ERR_INVALID). */
 #define PBRT_HIP_SCENE_OPTIMIZED_TREE 2u
+/* PBRT_HIP_SCENE_PLAIN_TREE (with PBRT_HIP_SCENE_GPU_BUILD): the device's binned-SAH tree as built, without the re-insertion
+ * passes (A-B measurements; the default device build optimises). */
+#define PBRT_HIP_SCENE_PLAIN_TREE 4u
 int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *desc, int device, uint32_t flags, pbrt_hip_scene **out);
 /* how the accelerator was built: *gpu_built 0 / 1, *build_ms = host build time (wall) or device build time (events) */
 int pbrt_hip_scene_build_info(const pbrt_hip_scene *scene, uint32_t *gpu_built, double *build_ms);
+/* the device build's tree optimisation (parallel re-insertion, pbrt_amd/csrc/reinsert_core.hpp): passes run, nodes moved, and
+ * its share of build_ms; zeros for a host-built scene or PBRT_HIP_SCENE_PLAIN_TREE.  Any pointer may be NULL. */
+int pbrt_hip_scene_optimize_info(const pbrt_hip_scene *scene, uint32_t *passes, uint32_t *moves, double *ms);
 /* the canonical tree behind the counter flags: *ready = it exists (always for a host-built scene; for a device-built one
  * after the first call that counted), *build_ms = the host builder's time for it */
 int pbrt_hip_scene_canonical_info(const pbrt_hip_scene *scene, uint32_t *ready, double *build_ms);
@@ -188,6 +195,7 @@ int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *i
 #define PBRT_HIP_TREE_SAH 0u
 #define PBRT_HIP_TREE_SBVH 1u
 #define PBRT_HIP_TREE_REINSERT 2u
+#define PBRT_HIP_TREE_REINSERT_BATCH 3u
 #define PBRT_HIP_TREE_DEFAULT 0xffffffffu
 int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
                                 uint32_t tree, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need,

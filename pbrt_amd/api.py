@@ -18,6 +18,8 @@ FLAG_COUNTERS = 1
 FLAG_WALK_COUNTERS = 2
 SCENE_GPU_BUILD = 1  # pbrt_hip_scene_create_ex flags
 SCENE_OPTIMIZED_TREE = 2
+SCENE_PLAIN_TREE = 4
+BUILDERS = {"host": 0, "gpu": SCENE_GPU_BUILD, "gpu-plain": SCENE_GPU_BUILD | SCENE_PLAIN_TREE, "host-optimized": SCENE_OPTIMIZED_TREE}
 
 
 def _fp(a):
@@ -203,7 +205,7 @@ def quad_build_host(P, idx, split_leaves=True):
     return quads[:nq.value].copy(), need.value
 
 
-TREES = {"sah": 0, "sbvh": 1, "reinsert": 2, "default": 0xFFFFFFFF}
+TREES = {"sah": 0, "sbvh": 1, "reinsert": 2, "reinsert_batch": 3, "default": 0xFFFFFFFF}
 
 
 def quad_build_host_ex(P, idx, tree="default", split_leaves=True):
@@ -261,7 +263,7 @@ class MultiScene:
         desc = SceneDesc()
         keep = fill_desc(desc, self.sd, Material, Light, Sphere)
         h = C.c_void_p()
-        check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), {"host": 0, "gpu": SCENE_GPU_BUILD, "host-optimized": SCENE_OPTIMIZED_TREE}[builder], C.byref(h)),
+        check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), BUILDERS[builder], C.byref(h)),
               "pbrt_hip_multi_create")
         del keep
         self._h = h
@@ -315,10 +317,10 @@ class Scene:
     """A scene resident in HBM (flattened BVH + leaf-ordered triangles + tables)."""
 
     def __init__(self, sd, device=-1, builder=None):
-        """builder: None (host SAH builder unless PBRT_HIP_BUILDER=gpu), "host", "gpu" (accelerator built on the device:
-        milliseconds; the product's default elsewhere) or "host-optimized" (PBRT_HIP_SCENE_OPTIMIZED_TREE: the host's tree optimised
-        by re-insertion -- about 5 % fewer node fetches per ray for about half a minute per million triangles).  Same film and hit
-        records whichever is used."""
+        """builder: None (host SAH builder unless PBRT_HIP_BUILDER=gpu), "host", "gpu" (accelerator built AND optimised by parallel
+        re-insertion on the device: tens of milliseconds; the product's default elsewhere), "gpu-plain" (the device's tree as built,
+        PBRT_HIP_SCENE_PLAIN_TREE: A-B runs) or "host-optimized" (PBRT_HIP_SCENE_OPTIMIZED_TREE: round 3's sequential re-insertion on
+        one host core, half a minute per million triangles).  Same film and hit records whichever is used."""
         self.sd = sd.normalized()
         desc = SceneDesc()
         keep = fill_desc(desc, self.sd, Material, Light, Sphere)
@@ -326,7 +328,7 @@ class Scene:
         if builder is None:
             check(lib().pbrt_hip_scene_create(C.byref(desc), device, C.byref(h)), "pbrt_hip_scene_create")
         else:
-            flags = {"host": 0, "gpu": SCENE_GPU_BUILD, "host-optimized": SCENE_OPTIMIZED_TREE}[builder]
+            flags = BUILDERS[builder]
             check(lib().pbrt_hip_scene_create_ex(C.byref(desc), device, flags, C.byref(h)), "pbrt_hip_scene_create_ex")
         del keep
         self._h = h
@@ -336,7 +338,10 @@ class Scene:
         check(lib().pbrt_hip_scene_build_info(self._h, C.byref(g), C.byref(ms)), "pbrt_hip_scene_build_info")
         r, cms = C.c_uint32(), C.c_double()
         check(lib().pbrt_hip_scene_canonical_info(self._h, C.byref(r), C.byref(cms)), "pbrt_hip_scene_canonical_info")
-        return {"gpu_built": bool(g.value), "build_ms": ms.value, "canonical_tree_ready": bool(r.value), "canonical_tree_host_build_ms": cms.value}
+        op, om, oms = C.c_uint32(), C.c_uint32(), C.c_double()
+        check(lib().pbrt_hip_scene_optimize_info(self._h, C.byref(op), C.byref(om), C.byref(oms)), "pbrt_hip_scene_optimize_info")
+        return {"gpu_built": bool(g.value), "build_ms": ms.value, "canonical_tree_ready": bool(r.value), "canonical_tree_host_build_ms": cms.value,
+                "reinsert_passes": op.value, "reinsert_moves": om.value, "reinsert_ms": oms.value}
 
     def export_quads(self):
         """(quads[n, 16] uint32, order[n_tris] uint32): the production walk's tree as it sits in HBM."""

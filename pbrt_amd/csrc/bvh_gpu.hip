@@ -23,6 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "device_types.h"
+#include "reinsert_core.hpp"
 
 namespace pbrt_hip {
 namespace {
@@ -490,6 +491,152 @@ __global__ void sah_leaf_boxes_kernel(const uint32_t *ids, int n, const float *t
   order[k] = t;
 }
 
+// ---- parallel re-insertion over the built binary tree (reinsert_core.hpp has the algorithm and what each phase may touch) ----
+// Unified node ids: interior nodes as the builder numbered them, [0, n - 1); the leaf of slot k = (n - 1) + k: the numbering
+// of the box array `bx`.
+__global__ void ri_links_kernel(int n, const uint32_t *child, uint32_t *par, uint32_t *kid) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n - 1) return;
+  for (int k = 0; k < 2; k++) {
+    const uint32_t c = child[2 * (size_t)i + k], id = node_of(c, n);
+    kid[2 * (size_t)i + k] = id;
+    par[id] = (uint32_t)i;
+  }
+  if (i == 0) par[0] = kNone;
+}
+
+// stats: [0] nodes visited by the searches, [1] searches that found a move, [2] moves applied (summed over the passes)
+__global__ void __launch_bounds__(256) ri_search_kernel(reins::Tree t, reins::Search sp, uint32_t pass, uint32_t mu, uint32_t *mv_y, uint32_t *mv_lca,
+                                                        float *mv_gain, unsigned long long *stats) {
+  __shared__ unsigned int s_visits, s_found;
+  if (threadIdx.x == 0) { s_visits = 0u; s_found = 0u; }
+  __syncthreads();
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x, n_nodes = 2u * t.n_int + 1u;
+  if (x < n_nodes) {
+    reins::Move m;
+    m.y = kNone; m.lca = kNone; m.gain = 0.f; m.visits = 0u;
+    if ((x + pass) % mu == 0u) m = reins::find_move(t, x, sp);
+    mv_y[x] = m.y;
+    mv_lca[x] = m.lca;
+    mv_gain[x] = m.gain;
+    atomicAdd(&s_visits, m.visits);
+    if (m.y != kNone) atomicAdd(&s_found, 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_visits) atomicAdd(&stats[0], (unsigned long long)s_visits);
+    if (s_found) atomicAdd(&stats[1], (unsigned long long)s_found);
+  }
+}
+
+__global__ void ri_lock_kernel(reins::Tree t, const uint32_t *mv_y, const float *mv_gain, unsigned long long *lock) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= 2u * t.n_int + 1u || mv_y[x] == kNone) return;
+  const unsigned long long key = reins::move_key(x, mv_gain[x]);
+  reins::for_move_nodes(t, x, mv_y[x], [&](uint32_t q) { atomicMax(&lock[q], key); });
+}
+
+__global__ void ri_hold_kernel(reins::Tree t, const uint32_t *mv_y, const float *mv_gain, const unsigned long long *lock, uint32_t *holds) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= 2u * t.n_int + 1u) return;
+  bool ok = mv_y[x] != kNone;
+  if (ok) {
+    const unsigned long long key = reins::move_key(x, mv_gain[x]);
+    reins::for_move_nodes(t, x, mv_y[x], [&](uint32_t q) { if (lock[q] != key) ok = false; });
+  }
+  holds[x] = ok ? 1u : 0u;
+}
+
+__global__ void ri_free_kernel(reins::Tree t, uint32_t *mv_y, const uint32_t *mv_lca, const uint32_t *holds) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= 2u * t.n_int + 1u || mv_y[x] == kNone) return;
+  if (!(holds[x] && reins::target_path_is_free(t, x, mv_y[x], mv_lca[x], [&](uint32_t q) { return holds[q] != 0u; }))) mv_y[x] = kNone;
+}
+
+__global__ void __launch_bounds__(256) ri_apply_kernel(reins::Tree t, const uint32_t *mv_y, unsigned long long *stats) {
+  __shared__ unsigned int s_applied;
+  if (threadIdx.x == 0) s_applied = 0u;
+  __syncthreads();
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+  if (x < 2u * t.n_int + 1u && mv_y[x] != kNone) {
+    reins::apply_move(t, x, mv_y[x]);
+    atomicAdd(&s_applied, 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_applied) atomicAdd(&stats[2], (unsigned long long)s_applied);
+}
+
+// all boxes bottom-up over the links (one thread per leaf climbs; the second thread to reach a node fits it); COUNT: also the
+// number of leaves below every interior node
+template <bool COUNT>
+__global__ void ri_refit_kernel(reins::Tree t, uint32_t *visits, uint32_t *cnt) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > t.n_int) return;
+  uint32_t node = t.n_int + k, c = 1u;
+  float lo[3], hi[3];
+  box_load<false>(t.bx, node, lo, hi);  // (leaf boxes were written by an earlier launch)
+  uint32_t p = t.par[node];
+  while (p != kNone) {
+    __threadfence();
+    if (atomicAdd(&visits[p], 1u) == 0u) return;  // the sibling subtree is not done yet
+    __threadfence();
+    const uint32_t sib = reins::sibling(t, p, node);
+    float slo[3], shi[3];
+    box_load<true>(t.bx, sib, slo, shi);
+    for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], slo[a]); hi[a] = fmaxf(hi[a], shi[a]); }
+    box_store(t.bx, p, lo, hi);
+    if (COUNT) {
+      c += sib >= t.n_int ? 1u : __hip_atomic_load(&cnt[sib], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cnt[p] = c;
+    }
+    node = p;
+    p = t.par[p];
+  }
+}
+
+__global__ void ri_order_kernel(reins::Tree t) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < t.n_int) reins::order_children(t, i);
+}
+
+// a leaf's position in the depth-first order of the optimised tree = the leaves to its left: the triangle records follow the
+// tree again (a moved triangle would otherwise keep its record where the first tree had it)
+__global__ void ri_leafpos_kernel(reins::Tree t, const uint32_t *cnt, uint32_t *newslot) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > t.n_int) return;
+  uint32_t node = t.n_int + k, pos = 0u;
+  for (uint32_t p = t.par[node]; p != kNone; node = p, p = t.par[p]) {
+    const uint32_t first = t.kid[2 * (size_t)p];
+    if (first != node) pos += first >= t.n_int ? 1u : cnt[first];
+  }
+  newslot[k] = pos;
+}
+
+// back to the builder's own form (child words, parents of interior nodes and of leaf slots) with the new leaf slots
+__global__ void ri_emit_kernel(reins::Tree t, const uint32_t *newslot, uint32_t *child, uint32_t *parent_internal, uint32_t *parent_leaf) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.n_int) return;
+  for (int k = 0; k < 2; k++) {
+    const uint32_t c = t.kid[2 * (size_t)i + k];
+    if (c >= t.n_int) {
+      const uint32_t s = newslot[c - t.n_int];
+      child[2 * (size_t)i + k] = kLeafRef | s;
+      parent_leaf[s] = i;
+    } else {
+      child[2 * (size_t)i + k] = c;
+      parent_internal[c] = i;
+    }
+  }
+  if (i == 0u) parent_internal[0] = kNone;
+}
+__global__ void ri_leaves_kernel(reins::Tree t, const uint32_t *newslot, const uint32_t *order_in, uint32_t *order_out, unsigned long long *leaf_bx_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > t.n_int) return;
+  const uint32_t s = newslot[k];
+  order_out[s] = order_in[k];
+  for (int w = 0; w < 3; w++) leaf_bx_out[3 * (size_t)s + w] = t.bx[3 * (size_t)(t.n_int + k) + w];
+}
+
 // ---- the collapse's dynamic programme (capi.cpp make_quad_nodes_as, after Ylitie, Karras, Laine 2017, section 3.2) ----
 // F(n, k, d) = least expected work inside subtree n when n may occupy up to k child slots of the quad node made of its
 // ancestor at binary distance d; G(n) = the work below n as a quad node of its own.  A child is reached with the probability
@@ -692,7 +839,7 @@ struct Tmp {
 #define GB_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_tris, uint32_t *d_order, uint4 *d_quads,
-                           uint32_t quad_capacity, GpuBuildInfo *info, hipStream_t stream) {
+                           uint32_t quad_capacity, uint32_t flags, GpuBuildInfo *info, hipStream_t stream) {
   const int n = (int)n_tris;
   if (n < 2) return hipErrorInvalidValue;  // (the caller builds trees of fewer than two triangles on the host)
   if (quad_capacity + 1u < n_tris) return hipErrorInvalidValue;  // a quad per interior node of the binary tree at most
@@ -835,6 +982,80 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
       uint32_t *t = cl_in; cl_in = cl_out; cl_out = t;
     }
     root_node = next_node - 1u;  // the last merge made the root (n - 1 internal nodes: ids 0 .. n - 2)
+  }
+
+  // ---- parallel re-insertion: the built tree optimised before it is collapsed (reinsert_core.hpp) ----
+  // Passes of search / lock / check / apply / refit until a pass moves fewer than one node in 1024, `passes` at most, or the
+  // searches have looked at more than kVisitBudget nodes per node of the tree in total (a mesh of coincident boxes, where
+  // nothing prunes a search, costs a bounded amount).  The host reads two numbers per pass.
+  info->reinsert_passes = 0;
+  info->reinsert_moves = 0;
+  info->reinsert_ms = 0.f;
+  {
+    int passes = 12;
+    uint32_t mu = 1;
+    reins::Search sp;
+    if (const char *v = debug_knob("PBRT_HIP_GPU_REINSERT")) passes = std::atoi(v);
+    if (const char *v = debug_knob("PBRT_HIP_REINSERT_MU")) mu = (uint32_t)std::max(1, std::atoi(v));
+    if (const char *v = debug_knob("PBRT_HIP_REINSERT_VISITS")) sp.max_visits = (uint32_t)std::max(1, std::atoi(v));
+    if (const char *v = debug_knob("PBRT_HIP_REINSERT_MIN_REL")) sp.min_rel = (float)std::atof(v);
+    if (const char *v = debug_knob("PBRT_HIP_REINSERT_QK")) sp.qk = (float)std::atof(v);
+    if (const char *v = debug_knob("PBRT_HIP_REINSERT_QW")) sp.qw = (float)std::atof(v);
+    if (!(flags & kGpuBuildReinsert)) passes = 0;
+    if (sah_tree && n >= 8 && passes > 0) {
+      constexpr unsigned long long kVisitBudget = 1024;
+      const uint32_t n_int = (uint32_t)n - 1u, n_nodes = 2u * n_int + 1u;
+      const dim3 grid_n((n_nodes + 255u) / 256u), grid_i((n_int + 255u) / 256u);
+      Tmp par, kid, mv_y, mv_lca, mv_gain, lock, holds, stats, cnt, newslot, order2, leaf_bx;
+      GB_TRY(par.alloc(4 * (size_t)n_nodes)); GB_TRY(kid.alloc(8 * (size_t)n_int));
+      GB_TRY(mv_y.alloc(4 * (size_t)n_nodes)); GB_TRY(mv_lca.alloc(4 * (size_t)n_nodes)); GB_TRY(mv_gain.alloc(4 * (size_t)n_nodes));
+      GB_TRY(lock.alloc(8 * (size_t)n_nodes)); GB_TRY(holds.alloc(4 * (size_t)n_nodes)); GB_TRY(stats.alloc(3 * 8));
+      GB_TRY(cnt.alloc(4 * (size_t)n_int)); GB_TRY(newslot.alloc(4 * (size_t)n)); GB_TRY(order2.alloc(4 * (size_t)n)); GB_TRY(leaf_bx.alloc(24 * (size_t)n));
+      Events rev;
+      GB_TRY(hipEventCreate(&rev.a));
+      GB_TRY(hipEventCreate(&rev.b));
+      GB_TRY(hipEventRecord(rev.a, stream));
+      const reins::Tree t{n_int, par.as<uint32_t>(), kid.as<uint32_t>(), bx.as<unsigned long long>()};
+      hipLaunchKernelGGL(ri_links_kernel, grid_i, block, 0, stream, n, child.as<uint32_t>(), par.as<uint32_t>(), kid.as<uint32_t>());
+      GB_TRY(hipMemsetAsync(stats.p, 0, 3 * 8, stream));
+      unsigned long long h_stats[3] = {0, 0, 0}, applied_before = 0;
+      int done = 0;
+      for (int pass = 0; pass < passes; pass++) {
+        hipLaunchKernelGGL(ri_search_kernel, grid_n, block, 0, stream, t, sp, (uint32_t)pass, mu, mv_y.as<uint32_t>(), mv_lca.as<uint32_t>(), mv_gain.as<float>(),
+                           stats.as<unsigned long long>());
+        GB_TRY(hipMemsetAsync(lock.p, 0, 8 * (size_t)n_nodes, stream));
+        hipLaunchKernelGGL(ri_lock_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_gain.as<float>(), lock.as<unsigned long long>());
+        hipLaunchKernelGGL(ri_hold_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_gain.as<float>(), lock.as<unsigned long long>(), holds.as<uint32_t>());
+        hipLaunchKernelGGL(ri_free_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_lca.as<uint32_t>(), holds.as<uint32_t>());
+        hipLaunchKernelGGL(ri_apply_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), stats.as<unsigned long long>());
+        GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
+        hipLaunchKernelGGL(ri_refit_kernel<false>, grid_t, block, 0, stream, t, visits.as<uint32_t>(), cnt.as<uint32_t>());
+        GB_TRY(hipGetLastError());
+        GB_TRY(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, stream));
+        GB_TRY(hipStreamSynchronize(stream));
+        done = pass + 1;
+        const unsigned long long applied = h_stats[2] - applied_before;
+        applied_before = h_stats[2];
+        if (applied * 1024ull < n_nodes || h_stats[0] > kVisitBudget * n_nodes) break;
+      }
+      // child order, leaf counts, leaves renumbered in depth-first order, and back to the builder's arrays
+      hipLaunchKernelGGL(ri_order_kernel, grid_i, block, 0, stream, t);
+      GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
+      hipLaunchKernelGGL(ri_refit_kernel<true>, grid_t, block, 0, stream, t, visits.as<uint32_t>(), cnt.as<uint32_t>());
+      hipLaunchKernelGGL(ri_leafpos_kernel, grid_t, block, 0, stream, t, cnt.as<uint32_t>(), newslot.as<uint32_t>());
+      hipLaunchKernelGGL(ri_emit_kernel, grid_i, block, 0, stream, t, newslot.as<uint32_t>(), child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>());
+      hipLaunchKernelGGL(ri_leaves_kernel, grid_t, block, 0, stream, t, newslot.as<uint32_t>(), d_order, order2.as<uint32_t>(), leaf_bx.as<unsigned long long>());
+      GB_TRY(hipGetLastError());
+      GB_TRY(hipMemcpyAsync(d_order, order2.p, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream));
+      GB_TRY(hipMemcpyAsync(bx.as<unsigned long long>() + 3 * (size_t)n_int, leaf_bx.p, 24 * (size_t)n, hipMemcpyDeviceToDevice, stream));
+      GB_TRY(hipEventRecord(rev.b, stream));
+      GB_TRY(hipStreamSynchronize(stream));  // (the scratch above is freed when this block ends)
+      float rms = 0.f;
+      GB_TRY(hipEventElapsedTime(&rms, rev.a, rev.b));
+      info->reinsert_passes = (uint32_t)done;
+      info->reinsert_moves = (uint32_t)std::min<unsigned long long>(h_stats[2], 0xffffffffull);
+      info->reinsert_ms = rms;
+    }
   }
 
   // top-down collapse, one launch per level of the quad tree.  The host does not know how many items a level holds

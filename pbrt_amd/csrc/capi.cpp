@@ -20,6 +20,7 @@
 #include "capi_internal.hpp"
 #include "device_types.h"
 #include "host_math.hpp"
+#include "reinsert_batch.hpp"
 #include "sbvh_build.hpp"
 #include "scene_parser.hpp"
 
@@ -311,6 +312,11 @@ void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split
       }
     }
   }
+  if (use_dp && std::getenv("PBRT_HIP_REINSERT_VERBOSE")) {
+    const BvhNode &r = b.nodes[0];
+    const float dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
+    std::fprintf(stderr, "collapse: expected work below the root G = %.4f root areas\n", G[0] / ((dx * dy + dx * dz) + dy * dz));
+  }
   struct Item { uint32_t node, quad, path; bool is_leaf; };  // path = stack entries held above this node
   std::vector<Item> todo = {{0u, 0u, 0u, false}};
   out->q.assign(4, make_uint4(0, 0, 0, 0));
@@ -546,7 +552,7 @@ void make_quad_nodes(const RefBvh &b, const uint32_t *slot_of_ref, bool split_le
 // = the canonical binned-SAH tree `canon` (the oracle's tree), kTreeSbvh = a tree of its own over triangle
 // references with spatial splits (sbvh_build.cpp).  Either way a leaf child's slot refers to the triangle records in
 // `canon`'s leaf order (a triangle reached through several references has ONE record).
-enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeSbvh = 1, kTreeReinsert = 2 };  // (= PBRT_HIP_TREE_*)
+enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeSbvh = 1, kTreeReinsert = 2, kTreeReinsertBatch = 3 };  // (= PBRT_HIP_TREE_*)
 SbvhParams sbvh_params() {
   SbvhParams p;
   if (const char *v = debug_knob("PBRT_HIP_SBVH_ALPHA")) p.alpha = (float)std::atof(v);
@@ -560,19 +566,30 @@ SbvhParams sbvh_params() {
   if (const char *v = debug_knob("PBRT_HIP_SBVH_BIAS")) p.spatial_bias = (float)std::atof(v);
   return p;
 }
+ReinsertBatchParams reinsert_batch_params() {
+  ReinsertBatchParams p;
+  if (const char *v = debug_knob("PBRT_HIP_REINSERT")) p.passes = std::atoi(v);
+  if (const char *v = debug_knob("PBRT_HIP_REINSERT_MU")) p.mu = (uint32_t)std::max(1, std::atoi(v));
+  if (const char *v = debug_knob("PBRT_HIP_REINSERT_VISITS")) p.search.max_visits = (uint32_t)std::max(1, std::atoi(v));
+  if (const char *v = debug_knob("PBRT_HIP_REINSERT_MIN_REL")) p.search.min_rel = (float)std::atof(v);
+  if (const char *v = debug_knob("PBRT_HIP_REINSERT_QK")) p.search.qk = (float)std::atof(v);
+  if (const char *v = debug_knob("PBRT_HIP_REINSERT_QW")) p.search.qw = (float)std::atof(v);
+  return p;
+}
 ProductionTree production_tree_default() {
   const char *v = debug_knob("PBRT_HIP_TREE");
   if (v && std::strcmp(v, "sbvh") == 0) return kTreeSbvh;
   if (v && std::strcmp(v, "reinsert") == 0) return kTreeReinsert;
+  if (v && std::strcmp(v, "reinsert_batch") == 0) return kTreeReinsertBatch;
   if (v && std::strcmp(v, "sah") == 0) return kTreeCanonical;
   return kTreeCanonical;
 }
 void build_production_quads(const Bvh &canon, const float *P, const uint32_t *idx, uint32_t n_tris, ProductionTree tree,
                             bool split_leaves, QuadNodes *out, uint32_t *n_refs = nullptr) {
   RefBvh rb;
-  if ((tree == kTreeSbvh || tree == kTreeReinsert) && n_tris >= 2) {
+  if ((tree == kTreeSbvh || tree == kTreeReinsert || tree == kTreeReinsertBatch) && n_tris >= 2) {
     SbvhParams prm = sbvh_params();
-    if (tree == kTreeReinsert) {  // object splits only (every triangle one reference), then the global optimisation
+    if (tree != kTreeSbvh) {  // object splits only (every triangle one reference), then the global optimisation
       prm.alpha = std::numeric_limits<float>::infinity();
       prm.budget = 0.f;
     }
@@ -580,6 +597,15 @@ void build_production_quads(const Bvh &canon, const float *P, const uint32_t *id
     if (tree == kTreeReinsert) {
       const char *np = debug_knob("PBRT_HIP_REINSERT"), *nf = debug_knob("PBRT_HIP_REINSERT_FRAC");
       reinsert_optimize(&rb, np ? std::atoi(np) : 8, nf ? (float)std::atof(nf) : 1.0f);
+    }
+    if (tree == kTreeReinsertBatch) {  // the device's parallel pass, run on the host (reinsert_batch.cpp)
+      ReinsertBatchParams bp = reinsert_batch_params();
+      reinsert_optimize_batch(&rb, bp);
+    }
+    if (std::getenv("PBRT_HIP_REINSERT_VERBOSE")) {
+      LinkTree lt;
+      link_tree_of(rb, &lt);
+      std::fprintf(stderr, "tree %u: summed interior half-area %.6g, depth %u\n", (unsigned)tree, lt.cost(), rb.depth);
     }
     std::vector<uint32_t> slot_of_tri(n_tris), slot_of_ref(rb.ref_tri.size());
     for (uint32_t s = 0; s < n_tris; s++) slot_of_tri[canon.order[s]] = s;
@@ -677,7 +703,7 @@ int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t
                                 float *root_box, uint32_t *n_refs, float *exact_boxes) {
   try {
     if ((n_tris && (!P || !idx)) || !n_quads || !stack_need) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: null argument");
-    if (tree > PBRT_HIP_TREE_REINSERT && tree != PBRT_HIP_TREE_DEFAULT) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: unknown tree");
+    if (tree > PBRT_HIP_TREE_REINSERT_BATCH && tree != PBRT_HIP_TREE_DEFAULT) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: unknown tree");
     for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
       if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: vertex index out of range");
     if (first_non_finite_vertex(P, idx, n_tris) >= 0) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: a vertex is not finite");
@@ -752,7 +778,9 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
 
     // --- accelerator: the host's binned-SAH builder, or (PBRT_HIP_SCENE_GPU_BUILD) the device builder further down ---
-    if (flags & ~(PBRT_HIP_SCENE_GPU_BUILD | PBRT_HIP_SCENE_OPTIMIZED_TREE)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
+    if (flags & ~(PBRT_HIP_SCENE_GPU_BUILD | PBRT_HIP_SCENE_OPTIMIZED_TREE | PBRT_HIP_SCENE_PLAIN_TREE)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
+    if ((flags & PBRT_HIP_SCENE_PLAIN_TREE) && !(flags & PBRT_HIP_SCENE_GPU_BUILD))
+      return fail(PBRT_HIP_ERR_INVALID, "scene_create: PBRT_HIP_SCENE_PLAIN_TREE qualifies PBRT_HIP_SCENE_GPU_BUILD");
     if ((flags & PBRT_HIP_SCENE_GPU_BUILD) && (flags & PBRT_HIP_SCENE_OPTIMIZED_TREE))
       return fail(PBRT_HIP_ERR_INVALID, "scene_create: PBRT_HIP_SCENE_OPTIMIZED_TREE is a host build, not combined with PBRT_HIP_SCENE_GPU_BUILD");
     s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && d->n_tris >= 2;
@@ -850,10 +878,14 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     HIP_TRY(up(s->d_mat_id.p, d->mat_id, s->d_mat_id.n * 2));
     GpuBuildInfo gb{};
     if (s->gpu_built) {
-      HIP_TRY(gpu_build_quads(s->d_P.p, s->d_idx.p, nt, s->d_order.p, s->d_quads.p, nt, &gb, s->stream));
+      HIP_TRY(gpu_build_quads(s->d_P.p, s->d_idx.p, nt, s->d_order.p, s->d_quads.p, nt, (flags & PBRT_HIP_SCENE_PLAIN_TREE) ? 0u : kGpuBuildReinsert, &gb,
+                              s->stream));
       if (gb.stack_need + 1u > 4096u) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: device-built tree too deep");
       quads.stack_need = gb.stack_need;
       s->build_ms = gb.build_ms;
+      s->reinsert_passes = gb.reinsert_passes;
+      s->reinsert_moves = gb.reinsert_moves;
+      s->reinsert_ms = gb.reinsert_ms;
     } else {
       HIP_TRY(up(s->d_order.p, s->bvh.order.data(), s->d_order.n * 4));
     }
@@ -941,6 +973,14 @@ int pbrt_hip_scene_build_info(const pbrt_hip_scene *s, uint32_t *gpu_built, doub
   if (!s) return fail(PBRT_HIP_ERR_INVALID, "build_info: null scene");
   if (gpu_built) *gpu_built = s->gpu_built ? 1u : 0u;
   if (build_ms) *build_ms = s->build_ms;
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_scene_optimize_info(const pbrt_hip_scene *s, uint32_t *passes, uint32_t *moves, double *ms) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "optimize_info: null scene");
+  if (passes) *passes = s->reinsert_passes;
+  if (moves) *moves = s->reinsert_moves;
+  if (ms) *ms = s->reinsert_ms;
   return PBRT_HIP_OK;
 }
 

@@ -72,6 +72,8 @@ struct pbrt_hip_scene {
   pbrt_hip::DevBuf<uint32_t> d_order_exact;
   double canonical_build_ms = 0.0;
   double build_ms = 0.0;
+  uint32_t reinsert_passes = 0, reinsert_moves = 0;  // the device build's tree optimisation (GpuBuildInfo)
+  double reinsert_ms = 0.0;
   uint64_t pending_samples = 0;
   uint64_t device_bytes = 0;
 

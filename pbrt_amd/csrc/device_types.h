@@ -194,10 +194,13 @@ hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t
 struct GpuBuildInfo {
   uint32_t n_quads, stack_need, levels;
   float root_lo[3], root_hi[3];
-  float build_ms;
+  float build_ms;  // everything, the optimisation included
+  uint32_t reinsert_passes, reinsert_moves;  // the tree's optimisation by parallel re-insertion (reinsert_core.hpp)
+  float reinsert_ms;
 };
+constexpr uint32_t kGpuBuildReinsert = 1u;  // flags of gpu_build_quads: optimise the binary tree by re-insertion before the collapse
 hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_tris, uint32_t *d_order, uint4 *d_quads,
-                           uint32_t quad_capacity, GpuBuildInfo *info, hipStream_t stream);
+                           uint32_t quad_capacity, uint32_t flags, GpuBuildInfo *info, hipStream_t stream);
 hipError_t launch_assemble(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
                            uint32_t n_local_super, hipStream_t stream);
 
