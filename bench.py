@@ -134,6 +134,52 @@ def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0, gpu_film=N
     }
 
 
+class ClockSampler:
+    """The shader clock the GPU holds while the timed region runs, sampled from a host thread with `rocm-smi --showclocks --json`
+    (no HIP call; 80 ms per sample).  roofline.frac prices the kernel against the NOMINAL 2.4 GHz, so the same kernel reads 0.84 on a
+    box that holds 2.32 GHz and 0.86 on one that holds 2.38; frac_at_measured_clock takes the droop out."""
+
+    def __init__(self, device_index, period_s=0.5):
+        import threading
+        self.device_index, self.period_s, self.mhz = device_index, period_s, []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _sample(self):
+        import re
+        import subprocess
+        try:
+            txt = subprocess.run(["rocm-smi", "-d", str(self.device_index), "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            for line in txt.splitlines():
+                if line.startswith("{"):
+                    for card in json.loads(line).values():
+                        m = re.search(r"(\d+)\s*Mhz", str(card.get("sclk clock speed:", "")), re.I)
+                        if m:
+                            return int(m.group(1))
+        except Exception:  # no rocm-smi, no permission, unparsable output: the clock is simply not reported
+            pass
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._sample()
+            if v is not None:
+                self.mhz.append(v)
+            self._stop.wait(self.period_s)
+
+    def start(self):
+        self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=10)
+        busy = sorted(v for v in self.mhz if v >= 1000)  # (samples between launches can catch a sleeping clock)
+        if not busy:
+            return None
+        return {"ghz_median": busy[len(busy) // 2] / 1e3, "ghz_min": busy[0] / 1e3, "ghz_max": busy[-1] / 1e3, "samples": len(busy),
+                "source": "rocm-smi --showclocks (sclk), sampled from a host thread during the timed steps"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,10 +187,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, nargs=2, default=None, help="override strata (diagnostics; invalid as a headline)")
-    ap.add_argument("--builder", default="gpu", choices=["host", "gpu", "host-optimized"],
-                    help="accelerator builder: the device builder (the product's default: milliseconds), the host's binned SAH "
-                         "(one core, about a second for 1M triangles) or the host's tree optimised by re-insertion (about a minute for "
-                         "1M triangles; 5 %% fewer node fetches per ray); same film either way")
+    ap.add_argument("--builder", default="gpu", choices=["host", "gpu", "gpu-plain", "host-optimized"],
+                    help="accelerator builder: the device builder (the product's default: binned SAH + parallel re-insertion, about 0.13 s "
+                         "for 1M triangles), the same without the re-insertion passes (gpu-plain: A-B runs), the host's binned SAH (one core, "
+                         "about a second for 1M triangles) or the host's tree optimised by sequential re-insertion (half a minute for 1M "
+                         "triangles); same film either way")
     ap.add_argument("--sampler", default="stratified", choices=["stratified", "sobol"])
     ap.add_argument("--filter", type=float, nargs=2, default=None, metavar=("XW", "YW"),
                     help="box filter radii (diagnostics; the BASELINE configs use the default 0.5): other radii take the fixed-point film "
@@ -226,7 +273,10 @@ def main():
     for _ in range(args.warmup):
         step()
     per_gpu_ms.clear()
+    clocks = ClockSampler(device_index) if rank == 0 else None
     barrier()
+    if clocks:
+        clocks.start()
     t_start = time.perf_counter()
     kernel_ms, local_samples = [], 0
     film = None
@@ -236,6 +286,18 @@ def main():
         local_samples = st["samples"]
     barrier()
     elapsed = time.perf_counter() - t_start
+    clock = clocks.stop() if clocks else None
+    # what the process group really was (a SCALE record must show that RCCL saw N ranks on N GPUs)
+    dist_info = {"backend": "none (one process, no process group)", "world_size": 1, "ranks_on_distinct_gpus": 1}
+    if in_process:
+        dist_info = {"backend": "rccl inside the library (pbrt_hip_multi_*: ncclCommInitAll, one group call per frame)", "world_size": 1,
+                     "gpus_in_process": scene.n_gpus, "ranks_on_distinct_gpus": scene.n_gpus}
+    if use_pg:
+        ids = [None] * world
+        props = torch.cuda.get_device_properties(device_index)
+        dist.all_gather_object(ids, (os.uname().nodename, getattr(props, "uuid", None) and str(props.uuid), getattr(props, "pci_bus_id", None), device_index))
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_on_distinct_gpus": len(set(ids)),
+                     "nccl_is_rccl": bool(getattr(torch.version, "hip", None))}
     if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -310,6 +372,8 @@ def main():
             roof["peak"] = peak = n_simd * CLOCK_GHZ / 4.0
             roof["achieved"] = pmc["valu_issue_quadcycles_per_ray"] * rays_per_s / 1e9
             roof["frac"] = roof["achieved"] / peak
+            if clock:  # the same against the clock this box held during the timed steps
+                roof["frac_at_measured_clock"] = roof["achieved"] / (n_simd * clock["ghz_median"] / 4.0)
             m = pmc.get("valu_issue_busy_measured")
             roof["valu"] = {k: pmc.get(k) for k in ("valu_issue_busy_measured", "valu_issue_quadcycles_per_ray", "valu_dual_issue_share_of_instructions",
                                                     "valu_instructions_per_ray", "lane_utilisation", "l2_hit_rate", "wave_wait_frac", "wave_issue_wait_frac", "wave_issuing_frac",
@@ -337,6 +401,8 @@ def main():
                                 "incl. Infinity-Cache hits and is uncalibrated for 16-B gathers (x2 if the wide-stream correction applied); "
                                 "hbm_counter_frac = that traffic / that time / 8 TB/s")
 
+    roof["clock_ghz_measured"] = clock["ghz_median"] if clock else None
+    roof["clock"] = clock
     out = {
         "metric": "Msamples/sec (rays/sec) at 1/2/4/8 GPUs; PSNR vs CPU reference",
         "value": value, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -352,6 +418,7 @@ def main():
                    # for the oracle's tree, which only the untimed counting pass uses
                    "accelerator": dict(scene.build_info(), builder=args.builder) if not in_process else {"builder": args.builder}},
         "roofline": roof,
+        "dist": dist_info,
     }
     if in_process and per_gpu_ms:
         import statistics

@@ -26,16 +26,34 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into v_pk_mul / v_pk_add_f32, which issue at half
+# rate on gfx950 (tools/ubench) and need v_mov_b64 copies into aligned register pairs: without it render_kernel has the
+# same instruction count, 13 VGPRs fewer and runs 3 % faster (the packed forms written by hand in the node step stay)
+# -amdgpu-sdwa-peephole=0: SDWA forms are half rate too, and the peephole costs render_kernel 10 VGPRs (106 -> 96: five
+# waves per SIMD without a spill)
+COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sdwa-peephole=0", "-Wall",
+                "-Wno-unused-function", f"--offload-arch={ARCH}"]
+
+
+def compiler_version():
+    try:
+        return subprocess.run([HIPCC, "--version"], capture_output=True, text=True, timeout=60).stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        return "unknown"
+
+
 def source_id(extra_flags=()):
-    """Identity of what a build is made from: a hash of every source under csrc/, the public header and the flags that
-    shape the kernels.  It is compiled into the library (pbrt_hip_build_id()); profiles/pmc_<workload>.json records the id of
-    the library its counters were taken on, and bench.py refuses to price a DIFFERENT library with them."""
+    """Identity of what a build is made from: a hash of every source under csrc/, the public header, EVERY flag the kernels are
+    compiled with (the fixed list above and the extra ones) and the compiler's version -- anything that can change the ISA.  It is
+    compiled into the library (pbrt_hip_build_id()); profiles/pmc_<workload>.json records the id of the library its counters were
+    taken on, and bench.py refuses to price a DIFFERENT library with them."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "pbrt_hip.h")]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
-    h.update(" ".join(extra_flags).encode())
+    h.update(" ".join(COMMON_FLAGS + list(extra_flags)).encode())
+    h.update(compiler_version().encode())
     return h.hexdigest()[:16]
 
 
@@ -50,13 +68,7 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     objs = []
     extra_flags = list(extra_flags) + os.environ.get("PBRT_HIP_EXTRA_FLAGS", "").split()
     build_id = source_id(extra_flags)
-    # -fno-slp-vectorize: the SLP vectoriser turns pairs of f32 operations into v_pk_mul / v_pk_add_f32, which issue at half
-    # rate on gfx950 (tools/ubench) and need v_mov_b64 copies into aligned register pairs: without it render_kernel has the
-    # same instruction count, 13 VGPRs fewer and runs 3 % faster (the packed forms written by hand in the node step stay)
-    # -amdgpu-sdwa-peephole=0: SDWA forms are half rate too, and the peephole costs render_kernel 10 VGPRs (106 -> 96: five
-    # waves per SIMD without a spill)
-    common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sdwa-peephole=0", "-Wall",
-              "-Wno-unused-function", f"--offload-arch={ARCH}", f'-DPBRT_HIP_BUILD_ID="{build_id}"'] + extra_flags
+    common = COMMON_FLAGS + [f'-DPBRT_HIP_BUILD_ID="{build_id}"'] + extra_flags
     def compile_one(src):
         obj = os.path.join(LIB_DIR, src.rsplit(".", 1)[0] + ".o")
         cmd = [HIPCC] + common + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]

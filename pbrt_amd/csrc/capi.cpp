@@ -645,6 +645,8 @@ int ensure_canonical(pbrt_hip_scene *s) {
   if (nt) HIP_TRY(hipMemcpyAsync(s->d_order_exact.p, s->bvh.order.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order_exact.p, nt, s->d_tris_exact.p, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  s->dev.nodes = s->d_nodes.p;  // (the pre-canonical allocation was empty and has just been released: no stale pointer is kept)
+  s->device_bytes += s->d_nodes.n * 16 + s->d_tris_exact.n * 16 + s->d_order_exact.n * 4;
   s->dev_exact = s->dev;
   s->dev_exact.nodes = s->d_nodes.p;
   s->dev_exact.tris = s->d_tris_exact.p;

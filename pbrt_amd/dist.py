@@ -95,10 +95,10 @@ def reduce_accumulators(local_acc, rank, world_size, group=None):
     summed accumulators on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
-        return local_acc
+    if world_size == 1:
+        return local_acc  # one rank: its accumulators ARE the sum (an initialised one-rank group has nothing to add)
     t = local_acc
-    if world_size > 1 and dist.get_backend(group) == "gloo" and t.is_cuda:
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
         t = t.cpu()  # gloo cannot reduce device tensors: stage through the host
     dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=group)
     return t if rank == 0 else None
