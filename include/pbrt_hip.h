@@ -142,11 +142,10 @@ int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_
  * asks for them (vertex / index buffers read back; about a second for 1M triangles, never on the render path).
  * pbrt_hip_scene_create(desc, ...) == pbrt_hip_scene_create_ex(desc, ..., getenv("PBRT_HIP_BUILDER") == "gpu"). */
 #define PBRT_HIP_SCENE_GPU_BUILD 1u
-/* PBRT_HIP_SCENE_OPTIMIZED_TREE: the host builder followed by a global optimisation of its tree -- every interior node is taken out
- * and its two subtrees are put back where they add the least surface area (re-insertion, after Bittner, Hapala, Havran 2013; eight
- * passes).  Rays then visit 4-6 % fewer nodes and triangles (BASELINE C3: 40.2 -> 38.2 node fetches per ray, +4.3 % samples per second)
- * for a build of about a minute per million triangles on one core: for renders long enough to pay for it.  Same film and hit records
- * bit for bit.  Not combined with PBRT_HIP_SCENE_GPU_BUILD (PBRT_HIP_ERR_INVALID). */
+/* PBRT_HIP_SCENE_OPTIMIZED_TREE: the HOST builder followed by the tree optimisation the device builder applies by default -- parallel
+ * re-insertion (pbrt_amd/csrc/reinsert_core.hpp), run on one host core: a few seconds per million triangles, 4-6 % fewer node
+ * fetches per ray than the plain host tree, same film and hit records bit for bit.  For hosts that build on the CPU;
+ * PBRT_HIP_SCENE_GPU_BUILD does the same in a tenth of a second.  Not combined with PBRT_HIP_SCENE_GPU_BUILD (PBRT_HIP_ERR_INVALID). */
 #define PBRT_HIP_SCENE_OPTIMIZED_TREE 2u
 /* PBRT_HIP_SCENE_PLAIN_TREE (with PBRT_HIP_SCENE_GPU_BUILD): the device's binned-SAH tree as built, without the re-insertion
  * passes (A-B measurements; the default device build optimises). */
@@ -186,16 +185,15 @@ int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *id
 int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
                              uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need);
 /* The same with the binary tree the 4-wide nodes are collapsed from chosen explicitly -- PBRT_HIP_TREE_SAH: the canonical
- * binned-SAH tree of DESIGN.md 3.3; PBRT_HIP_TREE_SBVH: SAH over triangle references with spatial splits (a triangle may
- * be reached through several leaves; it still has one record); PBRT_HIP_TREE_REINSERT: SAH over references without spatial
- * splits, then optimised by re-insertion (PBRT_HIP_SCENE_OPTIMIZED_TREE's tree) -- and more outputs, each of which may be NULL: order =
- * leaf slot -> triangle id (n_tris words; what a leaf child's slot refers to), root_box = lo xyz, hi xyz, n_refs =
- * references in the tree (n_tris without spatial splits), exact_boxes = the children's boxes before quantisation (24 floats
- * per node of `quads`: lo xyz, hi xyz of child 0..3; diagnostics). */
+ * binned-SAH tree of DESIGN.md 3.3; PBRT_HIP_TREE_REINSERT: that tree with its leaves opened into single triangles and optimised
+ * by the device builder's parallel re-insertion pass RUN ON THE HOST (the same functions, pbrt_amd/csrc/reinsert_core.hpp: what
+ * lets the CPU tests walk the trees that pass makes; PBRT_HIP_SCENE_OPTIMIZED_TREE's tree) -- and more outputs, each of which may
+ * be NULL: order = leaf slot -> triangle id (n_tris words; what a leaf child's slot refers to), root_box = lo xyz, hi xyz, n_refs
+ * = references in the tree (n_tris), exact_boxes = the children's boxes before quantisation (24 floats per node of `quads`: lo
+ * xyz, hi xyz of child 0..3; diagnostics).  (Round 3's PBRT_HIP_TREE_SBVH = 1, a spatial-split builder measured negative on
+ * BASELINE's meshes, is no longer in the library: tools/experiments/r03_host_tree_builders/.) */
 #define PBRT_HIP_TREE_SAH 0u
-#define PBRT_HIP_TREE_SBVH 1u
 #define PBRT_HIP_TREE_REINSERT 2u
-#define PBRT_HIP_TREE_REINSERT_BATCH 3u
 #define PBRT_HIP_TREE_DEFAULT 0xffffffffu
 int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
                                 uint32_t tree, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need,
@@ -207,6 +205,12 @@ int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t
  * {X, Y, Z, filter_weight_sum} per pixel = Film.pixels after merge_film_tile (film.rs:47-55,313-326).
  * Pixels of super-tiles owned by other ranks are written as zeros. */
 int pbrt_hip_render(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, float *film_xyzw, pbrt_hip_stats *stats);
+/* Allocates (or grows) the device scratch a render of `scene` with this description needs -- the lanes' path-state records, the
+ * partial film sums of the work items, the overflow area of the walk's stack, sampler 2's matrices -- without launching anything.
+ * pbrt_hip_render_device does the same on demand; a host about to launch one frame on SEVERAL GPUs calls this for every GPU first,
+ * so that no allocation (a synchronising call) separates the launches (pbrt_hip_multi_render does).  Stands in for nothing in the
+ * reference (core/api.rs:432-473 renders nothing); part of the boundary's launch plumbing. */
+int pbrt_hip_render_prepare(pbrt_hip_scene *scene, const pbrt_hip_render_desc *r);
 /* Same, but asynchronous on `stream` (a hipStream_t, may be NULL) into a DEVICE slab of
  * pbrt_hip_slab_floats() floats: this rank's super-tiles back to back, 64*64 float4 each.
  * No synchronisation is done; stats->kernel_ms is filled by pbrt_hip_render_wait(). */

@@ -69,6 +69,7 @@ SYMBOLS = {
     "pbrt_hip_quad_build_host_ex": (C.c_int, [_pf, _u32, _pu32, _u32, C.c_int, _u32, _pu32, _u32, _pu32, _pu32, _pu32, _pf, _pu32, _pf]),
     "pbrt_hip_render": (C.c_int, [_vp, C.POINTER(RenderDesc), _pf, C.POINTER(Stats)]),
     "pbrt_hip_render_device": (C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp]),
+    "pbrt_hip_render_prepare": (C.c_int, [_vp, C.POINTER(RenderDesc)]),
     "pbrt_hip_render_wait": (C.c_int, [_vp, C.POINTER(Stats)]),
     "pbrt_hip_film_assemble_device": (C.c_int, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "pbrt_hip_render_buffer_bytes": (_i64, [_vp, C.POINTER(RenderDesc)]),

@@ -205,12 +205,13 @@ def quad_build_host(P, idx, split_leaves=True):
     return quads[:nq.value].copy(), need.value
 
 
-TREES = {"sah": 0, "sbvh": 1, "reinsert": 2, "reinsert_batch": 3, "default": 0xFFFFFFFF}
+TREES = {"sah": 0, "reinsert": 2, "default": 0xFFFFFFFF}
 
 
 def quad_build_host_ex(P, idx, tree="default", split_leaves=True):
     """pbrt_hip_quad_build_host_ex (no device): dict(quads[n, 16] uint32, stack_need, order = leaf slot -> triangle,
-    root_box[6], n_refs) of the production walk's tree collapsed from the binary tree `tree` ("sah" / "sbvh" / "default")."""
+    root_box[6], n_refs) of the production walk's tree collapsed from the binary tree `tree` ("sah": canonical binned SAH; "reinsert": the same
+    optimised by the device builder's re-insertion pass run on the host; "default")."""
     P = np.ascontiguousarray(P, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(idx, np.uint32).reshape(-1, 3)
     nt = idx.shape[0]
@@ -421,6 +422,12 @@ class Scene:
         r = make_render_desc(RenderDesc, flags=FLAG_WALK_COUNTERS if counters == "walk" else (FLAG_COUNTERS if counters else 0), **kw)
         check(lib().pbrt_hip_render_device(self._h, C.byref(r), C.c_void_p(d_slab_ptr), C.c_void_p(stream_ptr or 0)),
               "pbrt_hip_render_device")
+
+    def render_prepare(self, **kw):
+        """pbrt_hip_render_prepare: allocate the scratch a render with these arguments needs, launch nothing."""
+        kw.pop("counters", None)
+        r = make_render_desc(RenderDesc, **kw)
+        check(lib().pbrt_hip_render_prepare(self._h, C.byref(r)), "pbrt_hip_render_prepare")
 
     def render_wait(self):
         st = Stats()

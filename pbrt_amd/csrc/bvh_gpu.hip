@@ -1,13 +1,13 @@
-// BVH construction on the device: the host builder's algorithm --
-// top-down binned SAH (centre bounds -> widest axis -> 16 buckets -> plane of least n_l A_l + n_r A_r) -- run
-// LEVEL-SYNCHRONOUSLY over the Morton-sorted triangles (every segment of a level is split by the same launches), followed
-// by the host's dynamic-programming collapse into the quantised 4-wide nodes the production walk reads (DESIGN.md section
-// 4).  This is the DEFAULT builder (`sah`): 34 ms for 1M triangles against the host's second, a tree within 0.3 % of the
-// host's in walk time.  Two earlier builders stay selectable behind the debug switch for A-B runs
-// (PBRT_HIP_GPU_BUILDER=lbvh|ploc):
-//   * LBVH: the binary radix tree of Karras 2012 + a bottom-up box fit -- faster to build, a tree that walks ~9 % slower on C3;
-//   * PLOC: parallel locally-ordered clustering (Meister & Bittner, IEEE TVCG 2018) -- a better SAH-style cost than the LBVH's
-//     and a WORSE walk in a random soup (bottom-up merging leaves heavily overlapping siblings).
+// BVH construction on the device, three stages:
+//   1. the host builder's algorithm -- top-down binned SAH (centre bounds -> widest axis -> 16 buckets -> plane of
+//      least n_l A_l + n_r A_r) -- run LEVEL-SYNCHRONOUSLY over the Morton-sorted triangles (every segment of a level is split by
+//      the same launches), down to leaves of one triangle;
+//   2. the built tree OPTIMISED by parallel re-insertion (reinsert_core.hpp: every node looks for the position that lowers the
+//      summed surface area most, conflicting moves are dropped, boxes refitted; up to 12 passes): 4.5 % fewer node fetches per ray
+//      on BASELINE C3, 6.5 % on C2;
+//   3. the host's dynamic-programming collapse into the quantised 4-wide nodes the production walk reads.
+// 0.13 s for 1M triangles (34 ms without stage 2: PBRT_HIP_SCENE_PLAIN_TREE) against the host's second.  Round 1's LBVH and PLOC
+// builders are records now (tools/experiments/r01_lbvh_ploc_builders.hip.txt).
 // The reference has no accelerator at all (core/api.rs:237 is a name), so there is nothing to conform to but the RESULT:
 // by the tie rule of DESIGN.md 3.4 a ray's hit does not depend on the shape of the tree, so a scene built here renders
 // the same film, bit for bit, as one built by the host's SAH builder (tests/test_gpu_parity.py::test_gpu_built_scene_*).
@@ -125,146 +125,7 @@ __global__ void morton_kernel(const float *P, const uint32_t *idx, uint32_t n, c
   vals[t] = t;
 }
 
-// length of the common prefix of the keys of sorted positions i and j (ties broken by position), -1 out of range
-__device__ __forceinline__ int delta(const uint32_t *keys, int n, int i, int j) {
-  if (j < 0 || j >= n) return -1;
-  const uint32_t a = keys[i], b = keys[j];
-  if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
-  return __clz(a ^ b);
-}
-
-// Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees", section 4: internal
-// node i of the binary radix tree over n sorted keys.  child[2i], child[2i+1]: internal index, or kLeafRef | leaf.
-__global__ void radix_tree_kernel(const uint32_t *keys, int n, uint32_t *child, uint32_t *parent_internal, uint32_t *parent_leaf) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i >= n - 1) return;
-  const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
-  const int dmin = delta(keys, n, i, i - d);
-  int lmax = 2;
-  while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-  int l = 0;
-  for (int t = lmax / 2; t >= 1; t /= 2)
-    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-  const int j = i + l * d;
-  const int dnode = delta(keys, n, i, j);
-  int s = 0, t = l;
-  do {
-    t = (t + 1) / 2;
-    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-  } while (t > 1);
-  const int gamma = i + s * d + min(d, 0);
-  const int lo = min(i, j), hi = max(i, j);
-  const uint32_t left = lo == gamma ? (kLeafRef | (uint32_t)gamma) : (uint32_t)gamma;
-  const uint32_t right = hi == gamma + 1 ? (kLeafRef | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-  child[2 * i] = left;
-  child[2 * i + 1] = right;
-  if (left & kLeafRef) parent_leaf[gamma] = (uint32_t)i; else parent_internal[gamma] = (uint32_t)i;
-  if (right & kLeafRef) parent_leaf[gamma + 1] = (uint32_t)i; else parent_internal[gamma + 1] = (uint32_t)i;
-  if (i == 0) parent_internal[0] = kNone;
-}
-
-// Boxes bottom-up: node ids are internal 0..n-2, leaf k -> (n-1) + k.  The second thread to reach a node fits it.
-__global__ void fit_kernel(const float *P, const uint32_t *idx, const uint32_t *vals, int n, const uint32_t *child,
-                           const uint32_t *parent_internal, const uint32_t *parent_leaf, uint32_t *visits, unsigned long long *bx) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (k >= n) return;
-  float lo[3], hi[3];
-  tri_box(P, idx, vals[k], lo, hi);
-  box_store(bx, (uint32_t)(n - 1 + k), lo, hi);
-  uint32_t node = parent_leaf[k], from = (uint32_t)(n - 1 + k);
-  while (node != kNone) {
-    __threadfence();
-    if (atomicAdd(&visits[node], 1u) == 0u) return;  // the sibling subtree is not done yet
-    __threadfence();
-    // this thread carries the box of the child it came from; the other child's was written by another thread
-    const uint32_t c0 = child[2 * node], c1 = child[2 * node + 1];
-    const uint32_t i0 = (c0 & kLeafRef) ? (uint32_t)(n - 1) + (c0 & ~kLeafRef) : c0, i1 = (c1 & kLeafRef) ? (uint32_t)(n - 1) + (c1 & ~kLeafRef) : c1;
-    float slo[3], shi[3];
-    box_load<true>(bx, i0 == from ? i1 : i0, slo, shi);
-    for (int a = 0; a < 3; a++) {
-      lo[a] = fminf(lo[a], slo[a]);
-      hi[a] = fmaxf(hi[a], shi[a]);
-    }
-    box_store(bx, node, lo, hi);
-    from = node;
-    node = parent_internal[node];
-  }
-}
-
-// ---- PLOC ----
-constexpr int kPlocRadius = 16;
-
 __device__ __forceinline__ uint32_t node_of(uint32_t ref, int n) { return (ref & kLeafRef) ? (uint32_t)(n - 1) + (ref & ~kLeafRef) : ref; }
-
-// leaf boxes: node id (n - 1) + k for sorted position k; cluster list = the leaves in Morton order
-__global__ void ploc_init_kernel(const float *P, const uint32_t *idx, const uint32_t *order, int n, unsigned long long *bx, uint32_t *clusters) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (k >= n) return;
-  float lo[3], hi[3];
-  tri_box(P, idx, order[k], lo, hi);
-  box_store(bx, (uint32_t)(n - 1 + k), lo, hi);
-  clusters[k] = kLeafRef | (uint32_t)k;
-}
-
-// nearest neighbour of every cluster within kPlocRadius list positions, by the surface area of the union box (ties: the
-// lower position).  The boxes of a block's clusters and of the halo on either side are staged in LDS.
-__global__ void __launch_bounds__(256) ploc_nn_kernel(const uint32_t *clusters, int m, int n, const unsigned long long *bx, uint32_t *nn) {
-  __shared__ float sb[256 + 2 * kPlocRadius][6];
-  const int base = (int)(blockIdx.x * 256) - kPlocRadius;
-  for (int t = (int)threadIdx.x; t < 256 + 2 * kPlocRadius; t += 256) {
-    const int g = base + t;
-    if (g >= 0 && g < m) {
-      float lo[3], hi[3];
-      box_load<false>(bx, node_of(clusters[g], n), lo, hi);
-      for (int a = 0; a < 3; a++) { sb[t][a] = lo[a]; sb[t][3 + a] = hi[a]; }
-    }
-  }
-  __syncthreads();
-  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (i >= m) return;
-  const float *me = sb[threadIdx.x + kPlocRadius];
-  float best = __builtin_huge_valf();
-  int bj = -1;
-  for (int d = -kPlocRadius; d <= kPlocRadius; d++) {
-    const int j = i + d;
-    if (d == 0 || j < 0 || j >= m) continue;
-    const float *o = sb[(int)threadIdx.x + kPlocRadius + d];
-    const float dx = fmaxf(me[3], o[3]) - fminf(me[0], o[0]), dy = fmaxf(me[4], o[4]) - fminf(me[1], o[1]), dz = fmaxf(me[5], o[5]) - fminf(me[2], o[2]);
-    const float area = (dx * dy + dx * dz) + dy * dz;
-    if (area < best) { best = area; bj = j; }
-  }
-  nn[i] = (uint32_t)bj;  // (m >= 2 here, so every cluster has a neighbour)
-}
-
-// flags: low word 1 = the cluster (or the node it merges into) stays in the list, high word 1 = it starts a merge
-__global__ void ploc_flag_kernel(const uint32_t *nn, int m, unsigned long long *flags) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i >= m) return;
-  const uint32_t j = nn[i];
-  const bool mutual = nn[j] == (uint32_t)i;
-  flags[i] = (mutual && (uint32_t)i > j) ? 0ull : (1ull | ((mutual ? 1ull : 0ull) << 32));
-}
-
-// scan = exclusive prefix sums of flags (low word: new list position, high word: number of merges before this one).
-// A merge creates internal node first_node + rank with the two clusters as children and their union box.
-__global__ void ploc_merge_kernel(const uint32_t *clusters, const uint32_t *nn, const unsigned long long *flags, const unsigned long long *scan, int m,
-                                  int n, uint32_t first_node, uint32_t *child, unsigned long long *bx, uint32_t *out) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i >= m) return;
-  const unsigned long long f = flags[i];
-  if (!(f & 1ull)) return;
-  const uint32_t pos = (uint32_t)scan[i];
-  if (!(f >> 32)) { out[pos] = clusters[i]; return; }
-  const uint32_t id = first_node + (uint32_t)(scan[i] >> 32), a = clusters[i], b = clusters[nn[i]];
-  float alo[3], ahi[3], blo[3], bhi[3];
-  box_load<false>(bx, node_of(a, n), alo, ahi);
-  box_load<false>(bx, node_of(b, n), blo, bhi);
-  for (int k = 0; k < 3; k++) { alo[k] = fminf(alo[k], blo[k]); ahi[k] = fmaxf(ahi[k], bhi[k]); }
-  box_store(bx, id, alo, ahi);
-  child[2 * (size_t)id] = a;
-  child[2 * (size_t)id + 1] = b;
-  out[pos] = id;
-}
 
 // ---- top-down binned SAH, level-synchronous (the host builder's split rule, DESIGN.md 3.3, on the device) ----
 // The triangles (in Morton order to start with) form SEGMENTS of the position array; every level every segment of two
@@ -876,16 +737,9 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   hipLaunchKernelGGL(morton_kernel, grid_t, block, 0, stream, d_P, d_idx, n_tris, bounds.as<uint32_t>(), keys.as<uint32_t>(), vals.as<uint32_t>());
   GB_TRY(hipGetLastError());
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
-  uint32_t root_node = 0u;  // internal node the collapse starts from
-  bool sah_tree = false;    // (the SAH path leaves parent pointers: the collapse's dynamic programme needs them)
-  const char *which = debug_knob("PBRT_HIP_GPU_BUILDER");
-  if (which && std::string(which) == "lbvh") {
-    GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
-    hipLaunchKernelGGL(radix_tree_kernel, grid_t, block, 0, stream, keys_out.as<uint32_t>(), n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>());
-    hipLaunchKernelGGL(fit_kernel, grid_t, block, 0, stream, d_P, d_idx, d_order, n, child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>(),
-                       visits.as<uint32_t>(), bx.as<unsigned long long>());
-    GB_TRY(hipGetLastError());
-  } else if (!which || std::string(which) != "ploc") {
+  const uint32_t root_node = 0u;  // internal node the collapse starts from
+  const bool sah_tree = true;
+  {
     // ---- top-down binned SAH ----
     const size_t cap = (size_t)n / 2 + 2;  // segments of >= 2 triangles on one level
     Tmp tlo, thi, ids_b, seg_a, seg_b, cb, bins, split, active, cbase, flags, scan, scan_tmp, segtab;
@@ -946,42 +800,6 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
     if (ids_out != d_order) GB_TRY(hipMemcpyAsync(d_order, ids_out, 4 * (size_t)n, hipMemcpyDeviceToDevice, stream));
     GB_TRY(hipGetLastError());
     GB_TRY(hipStreamSynchronize(stream));  // (the scratch above is freed when this block ends)
-    root_node = 0u;
-    sah_tree = true;
-  } else {
-    // PLOC rounds.  Scratch reuse: keys / keys_out hold the two cluster lists (the Morton keys are no longer needed),
-    // par_i the nearest neighbours; flags / scan are 64-bit per cluster.  The host reads the list length once a round.
-    Tmp flags, scan, scan_tmp, total;
-    GB_TRY(flags.alloc(8 * (size_t)n));
-    GB_TRY(scan.alloc(8 * (size_t)n));
-    GB_TRY(total.alloc(16));
-    size_t scan_bytes = 0;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.as<unsigned long long>(), scan.as<unsigned long long>(), n, stream));
-    GB_TRY(scan_tmp.alloc(scan_bytes));
-    uint32_t *cl_in = keys.as<uint32_t>(), *cl_out = keys_out.as<uint32_t>();
-    hipLaunchKernelGGL(ploc_init_kernel, grid_t, block, 0, stream, d_P, d_idx, d_order, n, bx.as<unsigned long long>(), cl_in);
-    int m = n;
-    uint32_t next_node = 0u;
-    while (m > 1) {
-      const dim3 gm((uint32_t)(m + 255) / 256u);
-      hipLaunchKernelGGL(ploc_nn_kernel, gm, block, 0, stream, cl_in, m, n, bx.as<unsigned long long>(), par_i.as<uint32_t>());
-      hipLaunchKernelGGL(ploc_flag_kernel, gm, block, 0, stream, par_i.as<uint32_t>(), m, flags.as<unsigned long long>());
-      GB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, flags.as<unsigned long long>(), scan.as<unsigned long long>(), m, stream));
-      hipLaunchKernelGGL(ploc_merge_kernel, gm, block, 0, stream, cl_in, par_i.as<uint32_t>(), flags.as<unsigned long long>(), scan.as<unsigned long long>(), m, n,
-                         next_node, child.as<uint32_t>(), bx.as<unsigned long long>(), cl_out);
-      GB_TRY(hipGetLastError());
-      unsigned long long last[2];  // exclusive sum and flag of the last cluster: their sum is the round's total
-      GB_TRY(hipMemcpyAsync(&last[0], scan.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost, stream));
-      GB_TRY(hipMemcpyAsync(&last[1], flags.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost, stream));
-      GB_TRY(hipStreamSynchronize(stream));
-      const unsigned long long tot = last[0] + last[1];
-      const int m_next = (int)(uint32_t)tot;
-      next_node += (uint32_t)(tot >> 32);
-      if (m_next >= m) return hipErrorUnknown;  // (cannot happen: the closest pair of the list is always mutual)
-      m = m_next;
-      uint32_t *t = cl_in; cl_in = cl_out; cl_out = t;
-    }
-    root_node = next_node - 1u;  // the last merge made the root (n - 1 internal nodes: ids 0 .. n - 2)
   }
 
   // ---- parallel re-insertion: the built tree optimised before it is collapsed (reinsert_core.hpp) ----

@@ -20,8 +20,8 @@
 #include "capi_internal.hpp"
 #include "device_types.h"
 #include "host_math.hpp"
+#include "ref_bvh.hpp"
 #include "reinsert_batch.hpp"
-#include "sbvh_build.hpp"
 #include "scene_parser.hpp"
 
 using namespace pbrt_hip;
@@ -220,8 +220,8 @@ struct QuadChild {
   uint32_t leaf_node;  // binary leaf to expand into its own quad node, or 0xffffffff
 };
 enum Collapse { kCollapsePlain = 0, kCollapseGreedy = 1, kCollapseDp = 2 };
-// `b`: the binary tree over triangle references (the canonical tree through refs_of_bvh, or the spatial-split tree of
-// sbvh_build.cpp); slot_of_ref[r] = slot of reference r's triangle in the leaf-ordered triangle records (null: r itself).
+// `b`: the binary tree over triangle references (the canonical tree through refs_of_bvh, or the optimised single-triangle tree of
+// single_ref_tree + reinsert_optimize_batch); slot_of_ref[r] = slot of reference r's triangle in the leaf-ordered triangle records (null: r itself).
 void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split_leaves, Collapse how, QuadNodes *out) {
   const bool greedy = how != kCollapsePlain;
   if (b.nodes.empty() || (b.nodes[0].count_axis & 0xffffu) != 0) return;  // no tree, or the root is a leaf
@@ -548,26 +548,16 @@ void make_quad_nodes(const RefBvh &b, const uint32_t *slot_of_ref, bool split_le
   }
 }
 
-// The production walk's 4-wide tree of a triangle soup.  `tree` picks the binary tree it is collapsed from: kTreeCanonical
-// = the canonical binned-SAH tree `canon` (the oracle's tree), kTreeSbvh = a tree of its own over triangle
-// references with spatial splits (sbvh_build.cpp).  Either way a leaf child's slot refers to the triangle records in
-// `canon`'s leaf order (a triangle reached through several references has ONE record).
-enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeSbvh = 1, kTreeReinsert = 2, kTreeReinsertBatch = 3 };  // (= PBRT_HIP_TREE_*)
-SbvhParams sbvh_params() {
-  SbvhParams p;
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_ALPHA")) p.alpha = (float)std::atof(v);
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_BUDGET")) p.budget = (float)std::atof(v);
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_OBJECT_BINS")) p.object_bins = std::max(2, std::atoi(v));
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_SPATIAL_BINS")) p.spatial_bins = std::max(2, std::atoi(v));
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_SWEEP_BELOW")) p.sweep_below = (uint32_t)std::max(2, std::atoi(v));
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_PAD")) p.pad = (float)std::atof(v);
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_WIDEST")) p.widest_axis_only = std::atoi(v);
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_LOW_FIRST")) p.low_side_first = std::atoi(v);
-  if (const char *v = debug_knob("PBRT_HIP_SBVH_BIAS")) p.spatial_bias = (float)std::atof(v);
-  return p;
-}
+// The production walk's 4-wide tree of a triangle soup, built on the host.  `tree` picks the binary tree it is collapsed from:
+// kTreeCanonical = the canonical binned-SAH tree `canon` (the oracle's tree); kTreeReinsert = that tree with its
+// leaves opened into single triangles and optimised by the DEVICE builder's parallel re-insertion pass run on the host
+// (reinsert_batch.cpp: the same functions, reinsert_core.hpp).  Either way a leaf child's slot refers to the triangle records in
+// `canon`'s leaf order.  (Round 3's host-only builders -- spatial splits, sequential re-insertion -- are records now:
+// tools/experiments/r03_host_tree_builders/.)
+enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeReinsert = 2 };  // (= PBRT_HIP_TREE_*)
 ReinsertBatchParams reinsert_batch_params() {
   ReinsertBatchParams p;
+  p.passes = 12;
   if (const char *v = debug_knob("PBRT_HIP_REINSERT")) p.passes = std::atoi(v);
   if (const char *v = debug_knob("PBRT_HIP_REINSERT_MU")) p.mu = (uint32_t)std::max(1, std::atoi(v));
   if (const char *v = debug_knob("PBRT_HIP_REINSERT_VISITS")) p.search.max_visits = (uint32_t)std::max(1, std::atoi(v));
@@ -578,30 +568,15 @@ ReinsertBatchParams reinsert_batch_params() {
 }
 ProductionTree production_tree_default() {
   const char *v = debug_knob("PBRT_HIP_TREE");
-  if (v && std::strcmp(v, "sbvh") == 0) return kTreeSbvh;
   if (v && std::strcmp(v, "reinsert") == 0) return kTreeReinsert;
-  if (v && std::strcmp(v, "reinsert_batch") == 0) return kTreeReinsertBatch;
-  if (v && std::strcmp(v, "sah") == 0) return kTreeCanonical;
   return kTreeCanonical;
 }
 void build_production_quads(const Bvh &canon, const float *P, const uint32_t *idx, uint32_t n_tris, ProductionTree tree,
                             bool split_leaves, QuadNodes *out, uint32_t *n_refs = nullptr) {
   RefBvh rb;
-  if ((tree == kTreeSbvh || tree == kTreeReinsert || tree == kTreeReinsertBatch) && n_tris >= 2) {
-    SbvhParams prm = sbvh_params();
-    if (tree != kTreeSbvh) {  // object splits only (every triangle one reference), then the global optimisation
-      prm.alpha = std::numeric_limits<float>::infinity();
-      prm.budget = 0.f;
-    }
-    build_sbvh(P, idx, n_tris, prm, &rb);
-    if (tree == kTreeReinsert) {
-      const char *np = debug_knob("PBRT_HIP_REINSERT"), *nf = debug_knob("PBRT_HIP_REINSERT_FRAC");
-      reinsert_optimize(&rb, np ? std::atoi(np) : 8, nf ? (float)std::atof(nf) : 1.0f);
-    }
-    if (tree == kTreeReinsertBatch) {  // the device's parallel pass, run on the host (reinsert_batch.cpp)
-      ReinsertBatchParams bp = reinsert_batch_params();
-      reinsert_optimize_batch(&rb, bp);
-    }
+  if (tree == kTreeReinsert && n_tris >= 2) {
+    single_ref_tree(canon, P, idx, &rb);
+    reinsert_optimize_batch(&rb, reinsert_batch_params());
     if (std::getenv("PBRT_HIP_REINSERT_VERBOSE")) {
       LinkTree lt;
       link_tree_of(rb, &lt);
@@ -705,7 +680,7 @@ int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t
                                 float *root_box, uint32_t *n_refs, float *exact_boxes) {
   try {
     if ((n_tris && (!P || !idx)) || !n_quads || !stack_need) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: null argument");
-    if (tree > PBRT_HIP_TREE_REINSERT_BATCH && tree != PBRT_HIP_TREE_DEFAULT) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: unknown tree");
+    if (tree != PBRT_HIP_TREE_SAH && tree != PBRT_HIP_TREE_REINSERT && tree != PBRT_HIP_TREE_DEFAULT) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: unknown tree");
     for (size_t i = 0; i < 3 * (size_t)n_tris; i++)
       if (idx[i] >= n_verts) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: vertex index out of range");
     if (first_non_finite_vertex(P, idx, n_tris) >= 0) return fail(PBRT_HIP_ERR_INVALID, "quad_build_host: a vertex is not finite");
@@ -1043,7 +1018,76 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if ((fx != 0.5f || fy != 0.5f) && r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND)
     return fail(PBRT_HIP_ERR_LIMIT, "render: the Sobol' sampler (sampler 2) with a box filter radius other than 0.5 is not instantiated");
   if (!(r->max_sample_luminance >= 0.f)) return fail(PBRT_HIP_ERR_INVALID, "render: max_sample_luminance must be >= 0 (0 = none)");
+  if (fx != 0.5f || fy != 0.5f) {
+    // the fixed-point film: a sample adds at most 2^39 units to a pixel's int64 accumulator, and a pixel receives
+    // at most spp x footprint samples (from every rank together: the N-rank reduce adds the same samples) -- 2^24 of them fit
+    const uint64_t foot = (uint64_t)(2 * (int)std::ceil(fx) + 1) * (uint64_t)(2 * (int)std::ceil(fy) + 1);
+    if ((uint64_t)r->spp_x * (uint64_t)r->spp_y * foot > (1ull << 24))
+      return fail(PBRT_HIP_ERR_LIMIT, "render: samples per pixel x filter footprint above 2^24 (the fixed-point film's accumulators could wrap)");
+  }
   return PBRT_HIP_OK;
+}
+
+namespace {
+// The scratch one render of `s` needs beyond the caller's slab, sized for THIS description and (re)allocated here when what the
+// scene holds is too small: the lanes' path-state records, the partial film sums of the work items, the overflow area of the
+// walk's stack, the generator matrices of sampler 2.  pbrt_hip_render_device calls it; a host that is about to launch on several
+// GPUs calls it for every GPU FIRST (pbrt_hip_render_prepare), so that no hipMalloc -- a synchronising call -- sits between
+// the launches of a frame.
+struct RenderScratch {
+  uint32_t n_workgroups = 0, chunk_shift = 0;
+  RenderStackPlan plan{};
+};
+int ensure_render_scratch(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, const FilmGeom &fg, const Shard &sh, RenderScratch *out) {
+  const uint32_t spp = r->spp_x * r->spp_y;
+  out->chunk_shift = sample_chunk_shift(spp);
+  const uint32_t n_chunks = 1u << out->chunk_shift;  // K: DESIGN.md 3.1
+  if ((uint64_t)sh.n_local * 4096u * n_chunks >= (1ull << 32)) return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for 32-bit item numbers");
+  // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
+  out->plan = render_stack_plan(s->dev.quad_stack_need, render_force_overflow(), render_prefer_lds());
+  // (the instantiations for another filter radius and for the Sobol' sampler fit the 96 VGPRs of 5 waves per SIMD like the default one)
+  const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, out->plan.waves_per_cu) : out->plan.waves_per_cu;
+  out->n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
+  if (r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND && s->d_sobol.n == 0) {
+    uint32_t mat[kSobolNdDims * 32];
+    sobol_nd_matrices(mat);
+    HIP_TRY(s->d_sobol.alloc(kSobolNdDims * 32));
+    HIP_TRY(hipMemcpy(s->d_sobol.p, mat, sizeof(mat), hipMemcpyHostToDevice));
+  }
+  {
+    // float4 records: 5 x 64 per one-wave workgroup (kernels.hip LaneRecords); with another box filter radius 16 x 2 x 64 more
+    // behind them (kWideSlotFloat4: a chunk's sums per footprint)
+    const size_t path = (size_t)out->n_workgroups * 320, need = path + (fg.wide ? (size_t)out->n_workgroups * 2048 : 0);
+    if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
+  }
+  if (!fg.wide) {
+    const size_t need = (size_t)sh.n_local * 4096u * n_chunks;  // one float4 per item
+    // (one float4 per item = 16 K bytes per pixel of the rank's share: C3 1.07 GB, C4's 4096^2 x 16 chunks 4.3 GB on one
+    // GPU; the buffer follows the frame: released when a later render needs less than a quarter of it)
+    if (s->d_partials.n < need || s->d_partials.n / 4 > need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
+  }
+  {
+    // the overflow variant keeps kQuadLdsStackOvf rows per lane in LDS; deeper entries (rare) go here
+    const size_t need = (size_t)out->n_workgroups * 64 * out->plan.extra_entries;
+    if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); HIP_TRY(s->d_stack_overflow.alloc(need)); }
+  }
+  return PBRT_HIP_OK;
+}
+}  // namespace
+
+int pbrt_hip_render_prepare(pbrt_hip_scene *s, const pbrt_hip_render_desc *r) {
+  int rc = check_render_desc(s, r);
+  if (rc) return rc;
+  try {
+    if (s->pending) return fail(PBRT_HIP_ERR_INVALID, "render_prepare: a render of this scene is still in flight (call pbrt_hip_render_wait first)");
+    HIP_TRY(hipSetDevice(s->device));
+    const FilmGeom fg = film_geom(s->desc, *r);
+    const Shard sh = make_shard_bounds(fg.sb, r->rank, r->world_size);
+    RenderScratch rs;
+    return ensure_render_scratch(s, r, fg, sh, &rs);
+  } catch (const std::exception &e) {
+    return fail(PBRT_HIP_ERR_INTERNAL, e.what());
+  }
 }
 
 int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, void *d_slab, void *stream) {
@@ -1064,17 +1108,11 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.max_lum = r->max_sample_luminance > 0.f ? r->max_sample_luminance : std::numeric_limits<float>::infinity();
     R.filter_rx = fg.rx; R.filter_ry = fg.ry;
     R.acc = fg.wide ? (unsigned long long *)d_slab : nullptr;
-    R.sobol_mat = nullptr;
     const bool sobol_nd = r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND;
-    if (sobol_nd) {
-      if (s->d_sobol.n == 0) {
-        uint32_t mat[kSobolNdDims * 32];
-        sobol_nd_matrices(mat);
-        HIP_TRY(s->d_sobol.alloc(kSobolNdDims * 32));
-        HIP_TRY(hipMemcpy(s->d_sobol.p, mat, sizeof(mat), hipMemcpyHostToDevice));
-      }
-      R.sobol_mat = s->d_sobol.p;
-    }
+    RenderScratch rs;
+    rc = ensure_render_scratch(s, r, fg, sh, &rs);  // (no allocation when pbrt_hip_render_prepare ran for this description, or an earlier frame did)
+    if (rc) return rc;
+    R.sobol_mat = sobol_nd ? s->d_sobol.p : nullptr;
     R.integrator = r->integrator;
     R.max_depth = r->max_depth;
     R.spp_x = r->spp_x;
@@ -1100,41 +1138,17 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     // LDS stack -- render_stack_plan -- and the register budget both allow 5 per SIMD), each lane drawing item after item
     // from the rank's list.
     // An item is one CHUNK (a K-th of the samples, K <= 16 with at least 32 samples per chunk) of one pixel: DESIGN.md 3.1.
-    R.chunk_shift = sample_chunk_shift(spp);
+    R.chunk_shift = rs.chunk_shift;
     const uint32_t n_chunks = 1u << R.chunk_shift;  // K: DESIGN.md 3.1
-    if ((uint64_t)sh.n_local * 4096u * n_chunks >= (1ull << 32)) return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for 32-bit item numbers");
     R.n_items = sh.n_local * 4096u * n_chunks;
-    // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
-    const RenderStackPlan plan = render_stack_plan(s->dev.quad_stack_need, render_force_overflow(), render_prefer_lds());
-    // (the instantiations for another filter radius and for the Sobol' sampler fit the 96 VGPRs of 5 waves per SIMD like the default one)
-    const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, plan.waves_per_cu) : plan.waves_per_cu;
-    R.n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
+    R.n_workgroups = rs.n_workgroups;
     R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
-    {
-      // float4 records: 5 x 64 per one-wave workgroup (kernels.hip LaneRecords); with another box filter radius 16 x 2 x 64 more
-      // behind them (kWideSlotFloat4: a chunk's sums per footprint)
-      const size_t path = (size_t)R.n_workgroups * 320, need = path + (fg.wide ? (size_t)R.n_workgroups * 2048 : 0);
-      if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
-      R.lane_state = s->d_lane_state.p;
-      R.wide_slots = s->d_lane_state.p + path;
-    }
-    R.partials = nullptr;
-    if (!fg.wide) {
-      const size_t need = (size_t)sh.n_local * 4096u * n_chunks;  // one float4 per item
-      // (one float4 per item = 16 K bytes per pixel of the rank's share: C3 1.07 GB, C4's 4096^2 x 16 chunks 4.3 GB on one
-      // GPU; the buffer follows the frame: released when a later render needs less than a quarter of it)
-      if (s->d_partials.n < need || s->d_partials.n / 4 > need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
-      R.partials = s->d_partials.p;
-    }
-    {
-      // the overflow variant keeps kQuadLdsStackOvf rows per lane in LDS; deeper entries (rare) go here
-      const uint32_t extra = plan.extra_entries;
-      const size_t need = (size_t)R.n_workgroups * 64 * extra;
-      if (s->d_stack_overflow.n < need) { s->d_stack_overflow.release(); HIP_TRY(s->d_stack_overflow.alloc(need)); }
-      R.stack_overflow = s->d_stack_overflow.p;
-      R.stack_overflow_entries = extra;
-    }
+    R.lane_state = s->d_lane_state.p;
+    R.wide_slots = s->d_lane_state.p + (size_t)R.n_workgroups * 320;
+    R.partials = fg.wide ? nullptr : s->d_partials.p;
+    R.stack_overflow = s->d_stack_overflow.p;
+    R.stack_overflow_entries = rs.plan.extra_entries;
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", s->dev.quad_stack_need <= kShallowStackNeed ? kMinWalkersShallow : kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);

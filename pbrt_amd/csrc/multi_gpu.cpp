@@ -133,6 +133,9 @@ int clone_scene(const pbrt_hip_scene *src, int device, pbrt_hip_scene **out) {
   s->gpu_built = src->gpu_built;
   s->n_quads_gpu = src->n_quads_gpu;
   s->build_ms = src->build_ms;
+  s->reinsert_passes = src->reinsert_passes;
+  s->reinsert_moves = src->reinsert_moves;
+  s->reinsert_ms = src->reinsert_ms;
   s->device_bytes = src->device_bytes;
   HIP_TRY(hipStreamCreate(&s->stream));
   HIP_TRY(hipEventCreate(&s->ev0));
@@ -239,6 +242,14 @@ int multi_render(pbrt_hip_multi *m, const pbrt_hip_render_desc *r, float *film, 
   const size_t per_gpu_f4 = wide ? 2 * m->n_px : m->max_slab;
   int code = ensure_buffers(m, per_gpu_f4, !wide);
   if (code) return code;
+  // ---- every GPU's scratch first (hipMalloc synchronises: none may sit between the launches below; no-ops from the second frame on) ----
+  for (int g = 0; g < n; g++) {
+    pbrt_hip_render_desc rd = *r;
+    rd.rank = (uint32_t)g;
+    rd.world_size = (uint32_t)n;
+    code = pbrt_hip_render_prepare(m->scenes[g], &rd);
+    if (code) return fail(code, "multi_render: GPU " + std::to_string(g) + ": " + pbrt_hip_last_error());
+  }
   // ---- every GPU's shard, asynchronously on its own stream ----
   std::vector<bool> started(n, false);
   std::string err;

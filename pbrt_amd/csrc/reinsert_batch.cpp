@@ -15,6 +15,76 @@ namespace pbrt_hip {
 
 using reins::kNone;
 
+void refs_of_bvh(const Bvh &bv, const float *P, const uint32_t *idx, RefBvh *out) {
+  out->nodes = bv.nodes;
+  out->depth = bv.depth;
+  const size_t n = bv.order.size();
+  out->ref_tri = bv.order;
+  out->ref_lo.resize(3 * n);
+  out->ref_hi.resize(3 * n);
+  for (size_t r = 0; r < n; r++) {
+    const uint32_t t = bv.order[r];
+    for (int a = 0; a < 3; a++) {
+      const float v0 = P[3 * (size_t)idx[3 * (size_t)t] + a], v1 = P[3 * (size_t)idx[3 * (size_t)t + 1] + a], v2 = P[3 * (size_t)idx[3 * (size_t)t + 2] + a];
+      out->ref_lo[3 * r + a] = std::min(v0, std::min(v1, v2));
+      out->ref_hi[3 * r + a] = std::max(v0, std::max(v1, v2));
+    }
+  }
+}
+
+void single_ref_tree(const Bvh &bv, const float *P, const uint32_t *idx, RefBvh *out) {
+  RefBvh flat;
+  refs_of_bvh(bv, P, idx, &flat);
+  RefBvh o;
+  o.ref_tri = flat.ref_tri;
+  o.ref_lo = flat.ref_lo;
+  o.ref_hi = flat.ref_hi;
+  o.nodes.reserve(2 * flat.ref_tri.size());
+  // (iterative: the canonical tree can be 64 levels deep, a leaf adds at most 6)
+  struct It { uint32_t node, first, count; int patch; uint32_t level; };  // node: canonical node, or 0xffffffff for a run of references
+  std::vector<It> st;
+  if (!flat.nodes.empty()) st.push_back({0u, 0u, 0u, -1, 1u});
+  while (!st.empty()) {
+    const It it = st.back();
+    st.pop_back();
+    const int me = (int)o.nodes.size();
+    if (it.patch >= 0) o.nodes[it.patch].offset = (uint32_t)me;
+    if (it.level > o.depth) o.depth = it.level;
+    BvhNode b{};
+    uint32_t first = it.first, count = it.count;
+    if (it.node != 0xffffffffu) {
+      const BvhNode &c = flat.nodes[it.node];
+      b = c;
+      if ((c.count_axis & 0xffffu) == 0) {
+        o.nodes.push_back(b);
+        st.push_back({c.offset, 0u, 0u, me, it.level + 1});
+        st.push_back({it.node + 1u, 0u, 0u, -1, it.level + 1});
+        continue;
+      }
+      first = c.offset;
+      count = c.count_axis & 0xffffu;
+    }
+    if (it.node == 0xffffffffu || count == 1u) {  // the box of a run: its references' boxes
+      for (int a = 0; a < 3; a++) { b.lo[a] = flat.ref_lo[3 * (size_t)first + a]; b.hi[a] = flat.ref_hi[3 * (size_t)first + a]; }
+      for (uint32_t r = first + 1; r < first + count; r++)
+        for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], flat.ref_lo[3 * (size_t)r + a]); b.hi[a] = std::max(b.hi[a], flat.ref_hi[3 * (size_t)r + a]); }
+    }
+    if (count == 1u) {
+      b.offset = first;
+      b.count_axis = 1u;
+      o.nodes.push_back(b);
+    } else {
+      b.offset = 0;
+      b.count_axis &= 0xffff0000u;
+      o.nodes.push_back(b);
+      const uint32_t half = count / 2;
+      st.push_back({0xffffffffu, first + half, count - half, me, it.level + 1});
+      st.push_back({0xffffffffu, first, half, -1, it.level + 1});
+    }
+  }
+  *out = std::move(o);
+}
+
 bool LinkTree::valid(std::string *why) const {
   const uint32_t n_nodes = 2 * n_int + 1;
   auto bad = [&](const char *m) { if (why) *why = m; return false; };

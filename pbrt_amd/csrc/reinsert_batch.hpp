@@ -6,7 +6,7 @@
 #include <vector>
 
 #include "reinsert_core.hpp"
-#include "sbvh_build.hpp"
+#include "ref_bvh.hpp"
 
 namespace pbrt_hip {
 

@@ -236,6 +236,29 @@ def test_multi_gpu_render_in_one_process(gpu, oracle, n_gpus):
         gpu.MultiScene(sd, gpu.device_count() + 1)
 
 
+def test_render_prepare_leaves_nothing_to_allocate(gpu, oracle):
+    """pbrt_hip_render_prepare (what pbrt_hip_multi_render calls for every GPU before the first launch of a frame, so that no
+    hipMalloc separates the launches): the scene's device footprint does not change between a prepared render's launch and its
+    end, the film is the oracle's, and a description the render would refuse is refused here too."""
+    import torch
+    sd = SMALL_SCENES["mesh1k"]()
+    ref, _ = oracle.OracleScene(sd).render(max_depth=4, spp=(3, 2), seed=5)
+    with gpu.Scene(sd, builder="gpu") as sc:
+        kw = dict(max_depth=4, spp=(3, 2), seed=5)
+        sc.render_prepare(**kw)
+        free0 = torch.cuda.mem_get_info()[0]
+        slab = torch.empty(max(sc.slab_floats() // 4, 1), 4, device="cuda")
+        free1 = torch.cuda.mem_get_info()[0]
+        sc.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, **kw)
+        sc.render_wait()
+        assert torch.cuda.mem_get_info()[0] == free1, "render_device allocated after render_prepare"
+        film, _ = sc.render(**kw)
+        with pytest.raises(RuntimeError):
+            sc.render_prepare(max_depth=4, spp=(2048, 1024), seed=5)  # 2^21 samples per pixel
+        del free0
+    assert_bit_equal(film, ref, "film after a prepared render")
+
+
 def test_rank_without_tiles(gpu, oracle):
     """A frame of one 64x64 super-tile split over three ranks: ranks 1 and 2 own nothing and must return an empty
     (all-zero) film (found by the randomised tests of round 1: a division by the zero workgroups of such a rank)."""
@@ -523,6 +546,44 @@ def test_c4_window_at_full_spp(gpu, oracle):
     assert_bit_equal(film, ref, "C4 window")
     for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
         assert st[k] == rst[k]
+
+
+# ---- closed forms on the HIP path itself: anchors of the path loop that do not route through the oracle ----
+
+def _hip_rgb(gpu, sd, max_depth, spp, seed):
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(max_depth=max_depth, spp=spp, seed=seed)
+    return pbrt_amd.film_to_rgb(film)
+
+
+@pytest.mark.parametrize("rho", [0.5, 0.8])
+@pytest.mark.parametrize("max_depth", [1, 3, 8, 40])
+def test_furnace_with_reflecting_walls_sums_the_bounce_series_on_the_gpu(gpu, rho, max_depth):
+    """The kernel against Le x sum_{i <= maxdepth} rho^i inside a closed emitting, reflecting icosphere (tests/util.py furnace_scene;
+    the same check runs on the oracle in tests/test_oracle_selfcheck.py): multi-bounce throughput, Russian-roulette reweighting and
+    the maxdepth accounting of render_kernel pinned WITHOUT the oracle.  8 seeds x 48 x 48 x 256 spp."""
+    from util import check_furnace
+    mean, se, want = check_furnace(lambda sd, d, spp, seed: _hip_rgb(gpu, sd, d, spp, seed), rho, max_depth, seeds=range(40, 48), spp=(16, 16), res=48)
+    assert abs(mean - want) < 3.5 * se + 3e-4 * want, (rho, max_depth, mean, se, want)
+    assert se < 0.002 * want
+
+
+@pytest.mark.parametrize("rho,max_depth", [(0.5, 8), (0.8, 3)])
+def test_furnace_in_a_box_on_the_gpu(gpu, rho, max_depth):
+    """The cube (heavy-tailed light estimate along its edges: tests/util.py furnace_scene): 8 seeds x 64 x 64 x 1024 spp, from above
+    with the standard error, from below with a 1 % allowance."""
+    from util import check_furnace
+    mean, se, want = check_furnace(lambda sd, d, spp, seed: _hip_rgb(gpu, sd, d, spp, seed), rho, max_depth, seeds=range(40, 48), spp=(32, 32), res=64, shape="box")
+    assert want * 0.99 - 3.5 * se < mean < want + 3.5 * se, (rho, max_depth, mean, se, want)
+
+
+@pytest.mark.parametrize("kind", ["distant", "infinite"])
+@pytest.mark.parametrize("max_depth", [1, 5])
+def test_lit_plane_closed_forms_on_the_gpu(gpu, kind, max_depth):
+    from util import lit_plane_scene
+    sd, want = lit_plane_scene(kind, res=64)
+    rgb = _hip_rgb(gpu, sd, max_depth, (4, 4), 9)
+    assert np.allclose(rgb, want, rtol=3e-6, atol=1e-7), (rgb.min((0, 1)), rgb.max((0, 1)), want)
 
 
 # ---- accelerator built on the device (SURVEY.md 8 row f3): a different tree, the same answers ----

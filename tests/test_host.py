@@ -438,15 +438,14 @@ def test_image_readers_refuse_hostile_headers(tmp_path):
 
 
 # ---- the production walk's trees checked on the CPU with the kernel's step restated (oracle/quad_walk.cpp) ----
-@pytest.mark.parametrize("tree", ["sah", "sbvh", "reinsert", "reinsert_batch"])
+@pytest.mark.parametrize("tree", ["sah", "reinsert"])
 @pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "ties", "deep"])
 def test_production_tree_finds_the_oracles_hits(oracle, name, tree):
     """A hit does not depend on the tree (tie rule): the 4-wide quantised tree collapsed from the canonical
-    binned-SAH tree, the one from the spatial-split builder (sbvh_build.cpp: a triangle is reached through several
-    references with CLIPPED boxes), the one optimised by sequential re-insertion (PBRT_HIP_SCENE_OPTIMIZED_TREE) and the one optimised by
-    the DEVICE builder's parallel re-insertion pass run on the host (reinsert_batch: the same functions, reinsert_core.hpp, that
-    bvh_gpu.hip's kernels call) must give the oracle's hit records and occlusion flags ray for ray -- any difference is
-    a box that does not enclose what lies below it, or a triangle a move lost.  Also: no walk exceeds the builder's stack bound."""
+    binned-SAH tree and the one optimised by the DEVICE builder's parallel re-insertion pass run on the host (the same functions,
+    reinsert_core.hpp, that bvh_gpu.hip's kernels call) must give the oracle's hit records and occlusion flags ray for ray -- any
+    difference is a box that does not enclose what lies below it, or a triangle a move lost.  Also: no walk exceeds the builder's
+    stack bound."""
     from pbrt_amd.api import quad_build_host_ex
     from util import SMALL_SCENES, random_rays
     sd = SMALL_SCENES[name]().normalized()
@@ -463,31 +462,28 @@ def test_production_tree_finds_the_oracles_hits(oracle, name, tree):
         occ = oracle.quad_walk(q["quads"], q["root_box"], sd.P, sd.idx, q["order"], o, d, tmax, any_hit=True)
         assert np.array_equal(occ["occluded"], ref.occluded(o, d, tmax))
         assert max(got["max_stack"], occ["max_stack"]) <= q["stack_need"]
-    assert q["n_refs"] >= sd.idx.shape[0] and (tree == "sah") == (q["n_refs"] == sd.idx.shape[0]) or sd.idx.shape[0] < 2 or tree != "sah"
-    if tree in ("reinsert", "reinsert_batch"):
-        assert q["n_refs"] == sd.idx.shape[0]  # no spatial splits: every triangle is one reference
-        _check_quads(q["quads"], q["stack_need"], sd.P, sd.idx, q["order"])
+    assert q["n_refs"] == sd.idx.shape[0]  # every triangle is one reference
+    _check_quads(q["quads"], q["stack_need"], sd.P, sd.idx, q["order"])
 
 
 def test_reinsertion_cuts_the_walks_work(oracle):
-    """PBRT_HIP_SCENE_OPTIMIZED_TREE / PBRT_HIP_TREE_REINSERT: on a mesh of BASELINE's kind the optimised tree costs a walk less
-    work than the binned-SAH tree for the same hits -- here (20 k triangles, uniformly random rays) 16 % fewer node steps for 18 %
-    more triangle tests, 10 % less in all with a triangle test priced at 0.7 node steps (their instruction counts); on the
-    path-traced ray mix of the 1 M-triangle scene both fall (tools/walk_sim.py: 35.2 -> 33.8 steps, 4.33 -> 4.17 tests)."""
+    """PBRT_HIP_SCENE_OPTIMIZED_TREE / PBRT_HIP_TREE_REINSERT (the device builder's parallel re-insertion pass, run here on the host):
+    on a mesh of BASELINE's kind the optimised tree costs a walk less work than the binned-SAH tree for the same hits -- here (20 k
+    triangles, uniformly random rays) at least 4 % fewer node steps, and less in all with a triangle test priced at 0.7 node steps
+    (their instruction counts); on the path-traced ray mix of the 1 M-triangle scene both fall (tools/walk_sim.py: 35.2 -> 33.9
+    steps, 4.33 -> 4.18 tests; on the GPU 40.2 -> 38.4 node fetches per ray)."""
     from pbrt_amd.api import quad_build_host_ex
     from util import SMALL_SCENES, random_rays
     sd = SMALL_SCENES["mesh20k"]().normalized()
     o, d, tmax = random_rays(40_000, 7)
     work = {}
-    for tree in ("sah", "reinsert", "reinsert_batch"):
+    for tree in ("sah", "reinsert"):
         q = quad_build_host_ex(sd.P, sd.idx, tree=tree)
         got = oracle.quad_walk(q["quads"], q["root_box"], sd.P, sd.idx, q["order"], o, d, tmax)
         work[tree] = (got["steps"].sum(), got["tris"].sum(), got["prim"])
-    assert np.array_equal(work["sah"][2], work["reinsert"][2]) and np.array_equal(work["sah"][2], work["reinsert_batch"][2])
+    assert np.array_equal(work["sah"][2], work["reinsert"][2])
     cost = {k: float(v[0]) + 0.7 * float(v[1]) for k, v in work.items()}
-    assert work["reinsert"][0] < 0.95 * work["sah"][0] and cost["reinsert"] < 0.97 * cost["sah"], (work["sah"][:2], work["reinsert"][:2])
-    # the parallel pass (the device builder's, run here on the host) must deliver most of that
-    assert work["reinsert_batch"][0] < 0.96 * work["sah"][0] and cost["reinsert_batch"] < 0.98 * cost["sah"], (work["sah"][:2], work["reinsert_batch"][:2])
+    assert work["reinsert"][0] < 0.96 * work["sah"][0] and cost["reinsert"] < 0.98 * cost["sah"], (work["sah"][:2], work["reinsert"][:2])
 
 
 def test_sobol_nd_generator_matrices(oracle):

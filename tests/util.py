@@ -95,3 +95,84 @@ def deep_tree_scene(xres=32, yres=32, k=400):
 
 
 SMALL_SCENES["deep"] = deep_tree_scene
+
+
+# ---- closed forms that do not pass through the oracle (tests/test_oracle_selfcheck.py on the oracle, tests/test_gpu_parity.py on
+# the HIP path): the anchors of the path loop (A9) that are independent of the kernel's twin ----
+def _icosphere(levels):
+    """unit icosphere, triangles wound so that their normals point INWARDS"""
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    v = [tuple(np.array(p) / np.linalg.norm(p)) for p in v]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(levels):
+        mid, nf = {}, []
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = (np.array(v[a]) + np.array(v[b])) / 2
+                v.append(tuple(p / np.linalg.norm(p)))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, np.float32), np.array([(a, c, b) for a, b, c in f], np.uint32)  # (outward-wound faces, flipped)
+
+
+def furnace_scene(rho, le=1.0, res=24, shape="sphere"):
+    """A closed surface every point of which emits `le` and reflects `rho` (matte), seen from inside.  Every camera ray meets it; the
+    one-light estimate at a surface point gathers rho x le on average (the form factors of a closed enclosure sum to one), so with the
+    spec's accounting (emission at the camera vertex, one direct estimate per vertex while bounces < maxdepth,
+    Russian roulette after the fourth bounce reweighted by 1 / (1 - q)) the expected pixel value is  le x sum_{i = 0 .. maxdepth} rho^i
+    whatever the shape.  shape "sphere": an icosphere of 1280 triangles -- between two points of a sphere cos cos / d^2 is CONSTANT, so
+    the estimate has almost no variance and the series can be pinned tightly; "box": a cube -- cos cos / d^2 is unbounded along its
+    edges, the estimator's tail falls off like w^(-3/2) and a finite run sits BELOW the expectation by about N^(-1/3) (measured:
+    -1.1 % at 2.4 M vertices), so the box is checked with that allowance."""
+    from pbrt_amd.api import MATTE, SceneData, look_at
+    if shape == "sphere":
+        P, idx = _icosphere(3)
+    else:
+        b = 1.0
+        c = [(-b, -b, -b), (b, -b, -b), (b, b, -b), (-b, b, -b), (-b, -b, b), (b, -b, b), (b, b, b), (-b, b, b)]
+        faces = [(0, 1, 2, 3), (4, 7, 6, 5), (0, 4, 5, 1), (3, 2, 6, 7), (0, 3, 7, 4), (1, 5, 6, 2)]  # wound to face inwards
+        P = np.array(c, np.float32)
+        idx = np.array([t for f in faces for t in ((f[0], f[1], f[2]), (f[0], f[2], f[3]))], np.uint32)
+    return SceneData(P=P, idx=idx, mat_id=np.zeros(len(idx), np.uint16), materials=np.array([[MATTE, rho, rho, rho, le, le, le]], np.float32),
+                     cam_to_world=look_at((0.1, -0.2, 0.05), (0.4, 1.0, 0.3), (0, 0, 1))[1], fov=70.0, xres=res, yres=res).normalized()
+
+
+def furnace_expectation(rho, max_depth, le=1.0):
+    return le * sum(rho ** i for i in range(max_depth + 1))
+
+
+def check_furnace(render, rho, max_depth, seeds, spp, res, shape="sphere"):
+    """render(scene_data, max_depth, spp, seed) -> linear RGB image.  The statistic is the mean of the per-seed image means, its
+    standard error comes from their spread.  Seeds are fixed and both sides are deterministic, so the test cannot flake.
+    Returns (mean, standard error, expectation)."""
+    sd = furnace_scene(rho, res=res, shape=shape)
+    means = np.array([float(render(sd, max_depth, spp, seed)[..., 0].astype(np.float64).mean()) for seed in seeds])
+    return means.mean(), means.std(ddof=1) / np.sqrt(len(means)), furnace_expectation(rho, max_depth)
+
+
+def lit_plane_scene(kind, res=16):
+    """A large matte plane z = 0 (rho = 0.6, 0.5, 0.4) seen from above, lit by ONE light: `distant` -- radiance (3, 2, 1) arriving from
+    direction (0.6, 0, 0.8) above the plane, so every pixel is rho / pi x L x 0.8 (the delta light leaves no sampling noise) -- or
+    `infinite` -- a constant environment (0.5, 0.25, 1.0): the cosine-sampled estimate is rho x Le for every sample, exactly.  Nothing
+    else is in the scene, so deeper paths add nothing (a bounce ray escapes; escaped rays add the environment only at the camera
+    vertex or after a mirror).  Returns (scene_data, expected rgb)."""
+    from pbrt_amd.api import LIGHT_DISTANT, LIGHT_INFINITE, MATTE, SceneData, look_at
+    rho = np.array([0.6, 0.5, 0.4], np.float32)
+    P = np.array([(-50, -50, 0), (50, -50, 0), (50, 50, 0), (-50, 50, 0)], np.float32)
+    idx = np.array([(0, 1, 2), (0, 2, 3)], np.uint32)  # normal +z
+    if kind == "distant":
+        lights = np.array([[LIGHT_DISTANT, 0.6, 0.0, 0.8, 3.0, 2.0, 1.0]], np.float32)
+        want = rho / np.pi * np.array([3.0, 2.0, 1.0]) * 0.8
+    else:
+        lights = np.array([[LIGHT_INFINITE, 0, 0, 0, 0.5, 0.25, 1.0]], np.float32)
+        want = rho * np.array([0.5, 0.25, 1.0])
+    sd = SceneData(P=P, idx=idx, mat_id=np.zeros(2, np.uint16), materials=np.array([[MATTE, *rho, 0, 0, 0]], np.float32), lights=lights,
+                   cam_to_world=look_at((1.0, -2.0, 3.0), (0.2, 0.3, 0.0), (0, 0, 1))[1], fov=40.0, xres=res, yres=res).normalized()
+    return sd, want.astype(np.float64)

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Node steps / triangle tests per ray of the production walk's tree, on the CPU (no GPU needed): builds the 4-wide tree of
-a BASELINE mesh scene with each binary-tree builder (`sah` = canonical binned SAH, `sbvh` = SAH over references with
-spatial splits, `reinsert` = SAH over references optimised by re-insertion: PBRT_HIP_SCENE_OPTIMIZED_TREE's tree), walks a path-tracing-like set of rays through it with oracle/quad_walk.cpp (the kernel's step restated),
+a BASELINE mesh scene with each binary-tree builder (`sah` = canonical binned SAH, `reinsert` = the same optimised by the device
+builder's parallel re-insertion pass run on the host: PBRT_HIP_SCENE_OPTIMIZED_TREE's tree; PBRT_HIP_REINSERT_VERBOSE=1 prints the
+passes and the collapse's expected-work figure G, which tracks steps per ray), walks a path-tracing-like set of rays through it with oracle/quad_walk.cpp (the kernel's step restated),
 checks every hit against the oracle's own BVH, and prints the per-ray work.
 
-usage: walk_sim.py [n_tris] [trees...]      e.g.  PBRT_HIP_DEBUG_KNOBS=1 PBRT_HIP_SBVH_BUDGET=0.3 walk_sim.py 100000 sah sbvh
+usage: walk_sim.py [n_tris] [trees...]      e.g.  PBRT_HIP_DEBUG_KNOBS=1 PBRT_HIP_REINSERT=4 walk_sim.py 100000 sah reinsert
 """
 import os
 import sys
@@ -66,7 +67,7 @@ def path_rays(sd, osc, res=96, bounces=5, seed=1):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
-    trees = sys.argv[2:] or ["sah", "sbvh"]
+    trees = sys.argv[2:] or ["sah", "reinsert"]
     sd = scenes.random_mesh_scene(n, 256, 256).normalized()
     osc = ob.OracleScene(sd)
     (co, cd, ct), (so, sdd, stm) = path_rays(sd, osc)
