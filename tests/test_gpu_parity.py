@@ -240,22 +240,40 @@ def test_render_prepare_leaves_nothing_to_allocate(gpu, oracle):
     """pbrt_hip_render_prepare (what pbrt_hip_multi_render calls for every GPU before the first launch of a frame, so that no
     hipMalloc separates the launches): the scene's device footprint does not change between a prepared render's launch and its
     end, the film is the oracle's, and a description the render would refuse is refused here too."""
-    import torch
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # (the runtime the library itself is linked against: no second one is brought in)
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    sd = scenes.random_mesh_scene(1000, 512, 512)
+    small, big = dict(max_depth=2, spp=(2, 2), seed=5), dict(max_depth=2, spp=(16, 8), seed=5)  # 1 and 4 chunks per pixel: 4 / 17 MB of partial sums
+    grew = {}
+    for prepared in (False, True):
+        with gpu.Scene(sd, builder="gpu") as sc:
+            slab = C.c_void_p()
+            assert hip.hipMalloc(C.byref(slab), C.c_size_t(max(sc.slab_floats() * 4, 16))) == 0
+            sc.render_device(slab.value, None, **small)  # (the kernel's code object, the runtime's own pools: everything a first launch brings)
+            sc.render_wait()
+            if prepared:
+                sc.render_prepare(**big)
+            before = free_bytes()
+            sc.render_device(slab.value, None, **big)
+            sc.render_wait()
+            grew[prepared] = before - free_bytes()
+            assert hip.hipFree(slab) == 0
+            if prepared:
+                with pytest.raises(RuntimeError):
+                    sc.render_prepare(max_depth=4, spp=(2048, 1024), seed=5)  # 2^21 samples per pixel
+    assert grew[False] > 8 << 20, grew  # (the measurement sees an unprepared render allocate)
+    assert grew[True] == 0, f"render_device allocated {grew[True]} bytes after render_prepare"
     sd = SMALL_SCENES["mesh1k"]()
     ref, _ = oracle.OracleScene(sd).render(max_depth=4, spp=(3, 2), seed=5)
     with gpu.Scene(sd, builder="gpu") as sc:
-        kw = dict(max_depth=4, spp=(3, 2), seed=5)
-        sc.render_prepare(**kw)
-        free0 = torch.cuda.mem_get_info()[0]
-        slab = torch.empty(max(sc.slab_floats() // 4, 1), 4, device="cuda")
-        free1 = torch.cuda.mem_get_info()[0]
-        sc.render_device(slab.data_ptr(), torch.cuda.current_stream().cuda_stream, **kw)
-        sc.render_wait()
-        assert torch.cuda.mem_get_info()[0] == free1, "render_device allocated after render_prepare"
-        film, _ = sc.render(**kw)
-        with pytest.raises(RuntimeError):
-            sc.render_prepare(max_depth=4, spp=(2048, 1024), seed=5)  # 2^21 samples per pixel
-        del free0
+        sc.render_prepare(max_depth=4, spp=(3, 2), seed=5)
+        film, _ = sc.render(max_depth=4, spp=(3, 2), seed=5)
     assert_bit_equal(film, ref, "film after a prepared render")
 
 
