@@ -321,11 +321,11 @@ def main():
     # them is withheld ("frac is silently stale").
     lib_id = pbrt_amd.build_id()
     pmc_stale = pmc is not None and pmc.get("build_id") != lib_id
-    if pmc is not None and not pmc_stale and args.builder == "host-optimized":
-        # the committed counters are those of the DEFAULT tree's walk (178 L1 accesses, 145.6 issue quad-cycles per ray); the optimised
-        # tree's rays do less of both, so pricing its rays with them would overstate every fraction: withheld
-        roof["profile_note"] = (f"{os.path.relpath(pmc_path, ROOT)} was taken with the default tree: roofline.frac / valu / l1 / traffic are "
-                                "withheld for --builder host-optimized (fewer node fetches per ray)")
+    if pmc is not None and not pmc_stale and pmc.get("builder", "gpu") != args.builder:
+        # the committed per-ray counters (L1 accesses, issue quad-cycles) are those of ONE tree's walk; another builder's rays do a
+        # different amount of both, so pricing them with these counters would misstate every fraction: withheld
+        roof["profile_note"] = (f"{os.path.relpath(pmc_path, ROOT)} was taken with --builder {pmc.get('builder', 'gpu')}: roofline.frac / valu / l1 / traffic "
+                                f"are withheld for --builder {args.builder} (a different tree: different work per ray)")
         pmc = None
     if pmc_stale:
         roof["stale_profile"] = (f"{os.path.relpath(pmc_path, ROOT)} was taken on library build {pmc.get('build_id', '(none recorded)')}, "

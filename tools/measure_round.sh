@@ -37,6 +37,8 @@ kill $CL
 for w in c2 c1 c4 big; do
   timeout 1200 python3 bench.py --workload $w --steps 2 --warmup 1 > $O/bench_${w}_${TAG}.json 2> $O/bench_${w}_${TAG}.err
 done
-timeout 900 python3 bench.py --workload c3 --steps 2 --warmup 1 --builder host --no-cpu-baseline > $O/bench_c3_hostbuilder_${TAG}.json 2> $O/bench_c3_hostbuilder_${TAG}.err
+# the device builder's tree as built (no re-insertion passes) on this same box: what the optimisation is worth here
+timeout 900 python3 bench.py --workload c3 --steps 3 --warmup 1 --builder gpu-plain --no-cpu-baseline --no-counters > $O/bench_c3_plaintree_${TAG}.json 2> $O/bench_c3_plaintree_${TAG}.err
+timeout 900 python3 bench.py --workload big --steps 2 --warmup 1 --builder gpu-plain --no-cpu-baseline --no-counters > $O/bench_big_plaintree_${TAG}.json 2> $O/bench_big_plaintree_${TAG}.err
 bash tools/rank_shares.sh > $O/rank_shares_${TAG}.txt 2>&1
 tail -n 2 $O/${TAG}_pytest_gpu.log; cat $O/bench_c3_${TAG}.json

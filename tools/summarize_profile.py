@@ -74,7 +74,10 @@ def main():
         # the library the counters were taken on (bench.py withholds figures priced with another build's profile)
         for line_file in (os.path.join(G, f"prof_{tag}_{wl}_trace.json"), os.path.join(G, f"bench_{wl}_{tag}.json")):
             try:
-                summary["build_id"] = json.load(open(line_file))["config"]["library_build_id"]
+                cfg = json.load(open(line_file))["config"]
+                summary["build_id"] = cfg["library_build_id"]
+                # the tree the per-ray counters belong to (tools/measure_round.sh: PROBE_BUILDER = bench.py's default builder)
+                summary["builder"] = cfg.get("accelerator", {}).get("builder", "gpu")
                 break
             except (OSError, ValueError, KeyError):
                 continue
