@@ -293,11 +293,15 @@ def main():
         dist_info = {"backend": "rccl inside the library (pbrt_hip_multi_*: ncclCommInitAll, one group call per frame)", "world_size": 1,
                      "gpus_in_process": scene.n_gpus, "ranks_on_distinct_gpus": scene.n_gpus}
     if use_pg:
-        ids = [None] * world
-        props = torch.cuda.get_device_properties(device_index)
-        dist.all_gather_object(ids, (os.uname().nodename, getattr(props, "uuid", None) and str(props.uuid), getattr(props, "pci_bus_id", None), device_index))
-        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_on_distinct_gpus": len(set(ids)),
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_on_distinct_gpus": None,
                      "nccl_is_rccl": bool(getattr(torch.version, "hip", None))}
+        try:  # (reporting only: whatever goes wrong here must not cost the bench line)
+            ids = [None] * world
+            props = torch.cuda.get_device_properties(device_index)
+            dist.all_gather_object(ids, (os.uname().nodename, getattr(props, "uuid", None) and str(props.uuid), getattr(props, "pci_bus_id", None), device_index))
+            dist_info["ranks_on_distinct_gpus"] = len(set(ids))
+        except Exception as e:  # noqa: BLE001
+            dist_info["ranks_on_distinct_gpus_error"] = repr(e)[:200]
     if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
