@@ -135,20 +135,42 @@ def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0, gpu_film=N
 
 
 class ClockSampler:
-    """The shader clock the GPU holds while the timed region runs, sampled from a host thread with `rocm-smi --showclocks --json`
-    (no HIP call; 80 ms per sample).  roofline.frac prices the kernel against the NOMINAL 2.4 GHz, so the same kernel reads 0.84 on a
-    box that holds 2.32 GHz and 0.86 on one that holds 2.38; frac_at_measured_clock takes the droop out."""
+    """The shader clock the GPU holds while the timed region runs, sampled from a host thread: the `*` line of the device's
+    /sys/class/drm/card*/device/pp_dpm_sclk (found through its PCI address; no process is started), else `rocm-smi --showclocks
+    --json` (80 ms per sample; never under rocprofv3, whose preloaded library makes every child's exec an exec after GPU start-up).
+    roofline.frac prices the kernel against the NOMINAL 2.4 GHz, so the same kernel reads 0.84 on a box that holds 2.32 GHz and 0.86
+    on one that holds 2.38; frac_at_measured_clock takes the droop out."""
 
-    def __init__(self, device_index, period_s=0.5):
+    def __init__(self, device_index, period_s=0.25):
+        import glob
         import threading
-        self.device_index, self.period_s, self.mhz = device_index, period_s, []
+        self.device_index, self.period_s, self.mhz, self.sysfs = device_index, period_s, [], None
+        try:
+            import torch
+            p = torch.cuda.get_device_properties(device_index)
+            addr = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            for dev in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(dev)) == addr and os.access(os.path.join(dev, "pp_dpm_sclk"), os.R_OK):
+                    self.sysfs = os.path.join(dev, "pp_dpm_sclk")
+        except Exception:  # no such attributes, no sysfs: fall back to rocm-smi
+            pass
+        self.use_smi = self.sysfs is None and not any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY"))
+        self.source = (f"{self.sysfs} (the level marked *)" if self.sysfs else "rocm-smi --showclocks (sclk)") + ", sampled from a host thread during the timed steps"
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _sample(self):
         import re
-        import subprocess
         try:
+            if self.sysfs:
+                for line in open(self.sysfs):
+                    if "*" in line:
+                        m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                        return int(m.group(1)) if m else None
+                return None
+            if not self.use_smi:
+                return None
+            import subprocess
             txt = subprocess.run(["rocm-smi", "-d", str(self.device_index), "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
             for line in txt.splitlines():
                 if line.startswith("{"):
@@ -176,8 +198,7 @@ class ClockSampler:
         busy = sorted(v for v in self.mhz if v >= 1000)  # (samples between launches can catch a sleeping clock)
         if not busy:
             return None
-        return {"ghz_median": busy[len(busy) // 2] / 1e3, "ghz_min": busy[0] / 1e3, "ghz_max": busy[-1] / 1e3, "samples": len(busy),
-                "source": "rocm-smi --showclocks (sclk), sampled from a host thread during the timed steps"}
+        return {"ghz_median": busy[len(busy) // 2] / 1e3, "ghz_min": busy[0] / 1e3, "ghz_max": busy[-1] / 1e3, "samples": len(busy), "source": self.source}
 
 
 def main():
@@ -274,9 +295,9 @@ def main():
         step()
     per_gpu_ms.clear()
     clocks = ClockSampler(device_index) if rank == 0 else None
-    barrier()
     if clocks:
-        clocks.start()
+        clocks.start()  # (before the barrier: nothing of the sampler's start-up falls into the timed region)
+    barrier()
     t_start = time.perf_counter()
     kernel_ms, local_samples = [], 0
     film = None
