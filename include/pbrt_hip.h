@@ -236,9 +236,9 @@ int64_t pbrt_hip_render_buffer_bytes(const pbrt_hip_scene *scene, const pbrt_hip
 int pbrt_hip_render_acc(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, int64_t *acc, pbrt_hip_stats *stats);
 int pbrt_hip_film_from_acc_device(const pbrt_hip_scene *scene, const void *d_acc, void *d_film_xyzw, void *stream);
 void pbrt_hip_film_from_acc(const int64_t *acc, int64_t n_pixels, float *film_xyzw);
-/* host only: the generator matrices sampler 2 uses -- 10 dimensions x 32 columns, rows 0 .. 9 of the reference's
+/* host only: the generator matrices sampler 2 uses -- 32 dimensions x 32 columns, rows 0 .. 31 of the reference's
  * SOBOL_MATRICES32 (sobolmatrices.rs:81) -- for tests of that claim */
-void pbrt_hip_sobol_matrices(uint32_t *out_320_words);
+void pbrt_hip_sobol_matrices(uint32_t *out_1024_words);
 /* host-side geometry of the sharding (no device needed) */
 int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world_size);
 /* for every float4 slot of a rank's slab the row-major pixel index inside the cropped film, or -1 */

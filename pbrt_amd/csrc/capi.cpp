@@ -1049,6 +1049,7 @@ int ensure_render_scratch(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, cons
   const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, out->plan.waves_per_cu) : out->plan.waves_per_cu;
   out->n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
   if (r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND && s->d_sobol.n == 0) {
+    static_assert(kSobolNdDims == 2 * (int)kSobolNdRequests, "sampler 2: two dimensions per request");
     uint32_t mat[kSobolNdDims * 32];
     sobol_nd_matrices(mat);
     HIP_TRY(s->d_sobol.alloc(kSobolNdDims * 32));

@@ -730,7 +730,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t v) {  // lowbias32
 // One 2-D request of the sample in flight.  Sobol: point (s ^ mask_j) of the first two Sobol' dimensions -- the
 // van der Corput sequence (bit reversal) and the dimension whose generator matrix has the columns v, v ^ v >> 1, ...
 // (Joe-Kuo s = 1, a = 0, m = 1) -- XOR-scrambled with keys hashed from the pixel and the request number j.
-// SND (sampler 2): requests 0 .. 4 of a sample take their own Sobol' dimensions (2j, 2j + 1) from the
+// SND (sampler 2): requests 0 .. 15 of a sample take their own Sobol' dimensions (2j, 2j + 1) from the
 // generator matrices in `mat` at point index s, XOR-scrambled per dimension; later requests are the padded ones below.
 template <bool SND = false>
 __device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const uint32_t spp_mask, float &u1, float &u2, const uint32_t *mat = nullptr) {
@@ -739,7 +739,7 @@ __device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const 
     u2 = pcg_float(P.rng);
     return;
   }
-  if (SND && (uint32_t)(P.rng.state >> 32) < 5u) {
+  if (SND && (uint32_t)(P.rng.state >> 32) < kSobolNdRequests) {
     const uint32_t key = (uint32_t)P.rng.state, d0 = 2u * (uint32_t)(P.rng.state >> 32);
     P.rng.state += 1ull << 32;  // next request
     // x = XOR of the columns of dimension d0's matrix at the set bits of the sample index, y likewise for d0 + 1.  Branch-free
