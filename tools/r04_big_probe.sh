@@ -2,7 +2,7 @@
 # round 4: the out-of-cache workload (12 M triangles) with and without the device builder's re-insertion pass
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-out=gpurun_out/r04d_big_probe.txt
+out=gpurun_out/r04p3_big_probe.txt
 : > $out
 for b in gpu-plain gpu; do
   echo "== big builder=$b" >> $out

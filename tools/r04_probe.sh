@@ -2,7 +2,7 @@
 # round 4: the device builder's re-insertion pass against the plain device tree (walk counters, probe frame times)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-out=gpurun_out/r04a_reinsert_probe.txt
+out=gpurun_out/r04p1_reinsert_probe.txt
 : > $out
 for wl in c3 c2; do
   for b in gpu-plain gpu; do

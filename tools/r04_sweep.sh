@@ -2,7 +2,7 @@
 # round 4: sweep of the device re-insertion's knobs on the C3 probe frame (16 spp)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-out=gpurun_out/r04b_reinsert_sweep.txt
+out=gpurun_out/r04p2_reinsert_sweep.txt
 : > $out
 export PBRT_HIP_DEBUG_KNOBS=1
 run() {  # label, env...
