@@ -134,7 +134,7 @@ const char *pbrt_hip_build_id(void);
  * positive, 0 < fov < 180 (PBRT_HIP_ERR_INVALID otherwise). ---- */
 int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_scene **out);
 /* The same with options.  PBRT_HIP_SCENE_GPU_BUILD: build the accelerator on the device (Morton order, level-synchronous
- * binned SAH, the tree optimised by parallel re-insertion, collapse into the quantised 4-wide nodes; SURVEY.md 8 row f3;
+ * binned SAH, the tree -- from 1024 triangles on -- optimised by parallel re-insertion, collapse into the quantised 4-wide nodes; SURVEY.md 8 row f3;
  * stands in for what core/api.rs:237 names "bvh" and api.rs:446-453 would have built) instead of the host's binned-SAH
  * builder: tens of milliseconds instead of a second for 1M triangles, a tree rays cross in fewer steps, the SAME film and
  * hit records bit for bit (a hit does not depend on the tree).  The counter flags of render / intersect

@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the library reads its tuning / A-B knobs (PBRT_HIP_MIN_WALKERS, PBRT_HIP_COLLAPSE, ...) only behind this switch
 os.environ.setdefault("PBRT_HIP_DEBUG_KNOBS", "1")
+# the device builder optimises trees of >= 1024 triangles by re-insertion (smaller ones gain nothing); the suite lowers that to 8 so that
+# its small scenes (36 .. 1014 triangles, the random ones of 0 .. 300) exercise the pass too -- "gpu-plain" covers the tree as built
+os.environ.setdefault("PBRT_HIP_REINSERT_MIN_TRIS", "8")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
