@@ -236,6 +236,21 @@ def test_furnace_in_a_box(oracle, rho, max_depth):
     assert want * 0.98 - 3.5 * se < mean < want + 3.5 * se, (rho, max_depth, mean, se, want)
 
 
+@pytest.mark.parametrize("max_depth", [0, 1, 2, 3])
+def test_mirror_furnace_is_exact_up_to_three_bounces(oracle, max_depth):
+    """A closed box of emitting mirrors (tests/util.py mirror_furnace_scene): Le x sum_{i <= maxdepth} Kr^i in every pixel, with no
+    random number involved -- the specular chain, emission after a specular bounce and the depth limit's "one more ray after a mirror"
+    pinned exactly, not statistically."""
+    from util import mirror_furnace_scene
+    kr, le = 0.75, 2.0
+    rgb = oracle.film_write_rgb(oracle.OracleScene(mirror_furnace_scene(kr, le)).render(max_depth=max_depth, spp=(2, 2), seed=3)[0])
+    want = le * sum(kr ** i for i in range(max_depth + 1))
+    # (Moeller-Trumbore is not watertight: one reflected ray in a thousand slips through an edge of the box and brings nothing back --
+    # the same ray on both sides; such a pixel is low by a quarter of a term, none may be high)
+    exact = np.isclose(rgb, want, rtol=3e-6, atol=0).all(-1)
+    assert exact.mean() >= 0.99 and (rgb <= want * (1 + 3e-6)).all(), (max_depth, exact.mean(), rgb.min(), rgb.max(), want)
+
+
 @pytest.mark.parametrize("kind", ["distant", "infinite"])
 @pytest.mark.parametrize("max_depth", [1, 5])
 def test_lit_plane_closed_forms(oracle, kind, max_depth):

@@ -157,6 +157,17 @@ def check_furnace(render, rho, max_depth, seeds, spp, res, shape="sphere"):
     return means.mean(), means.std(ddof=1) / np.sqrt(len(means)), furnace_expectation(rho, max_depth)
 
 
+def mirror_furnace_scene(kr, le=1.0, res=16):
+    """A closed cube of MIRRORS that emit `le` and reflect `kr`: the camera ray sees le, every mirror bounce adds the next wall's
+    emission (emission counts after a specular bounce; a ray at the depth limit is still traced after a mirror, for its
+    emission, 3.9), no light is sampled at a mirror and no random number is drawn while bounces <= 3: every pixel is EXACTLY
+    le x sum_{i = 0 .. maxdepth} kr^i for maxdepth <= 3, and that on average beyond (Russian roulette)."""
+    from pbrt_amd.api import MIRROR
+    sd = furnace_scene(0.0, le=le, res=res, shape="box")
+    sd.materials = np.array([[MIRROR, kr, kr, kr, le, le, le]], np.float32)
+    return sd.normalized()
+
+
 def lit_plane_scene(kind, res=16):
     """A large matte plane z = 0 (rho = 0.6, 0.5, 0.4) seen from above, lit by ONE light: `distant` -- radiance (3, 2, 1) arriving from
     direction (0.6, 0, 0.8) above the plane, so every pixel is rho / pi x L x 0.8 (the delta light leaves no sampling noise) -- or
