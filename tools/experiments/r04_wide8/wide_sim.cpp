@@ -119,10 +119,13 @@ static void collapse(const RefBvh &b, int W, bool quantise, WTree *out) {
 
 struct Stat { double steps = 0, tris = 0, stack = 0; uint64_t bad = 0; };
 
+// events: per ray the sequence of its walk -- 0 = a node step, 1 = a triangle test -- for the scheduling model below
 static void walk_all(const WTree &T, const RefBvh &rb, const float *P, const uint32_t *idx, size_t n, const float *o, const float *d, const float *tmax,
-                     bool any, bool sorted, const float *rt, const uint32_t *rprim, const uint8_t *rocc, Stat *st) {
+                     bool any, bool sorted, const float *rt, const uint32_t *rprim, const uint8_t *rocc, Stat *st,
+                     std::vector<std::vector<uint8_t>> *events = nullptr) {
   std::vector<uint32_t> stack;
   for (size_t i = 0; i < n; i++) {
+    if (events) events->emplace_back();
     const float ox = o[3 * i], oy = o[3 * i + 1], oz = o[3 * i + 2], dx = d[3 * i], dy = d[3 * i + 1], dz = d[3 * i + 2];
     const float ix = 1.f / dx, iy = 1.f / dy, iz = 1.f / dz;
     const bool nx = ix < 0.f, ny = iy < 0.f, nz = iz < 0.f;
@@ -136,6 +139,7 @@ static void walk_all(const WTree &T, const RefBvh &rb, const float *P, const uin
       if (!(cur & kLeaf)) {
         const WNode &w = T.nodes[cur];
         st->steps++;
+        if (events) events->back().push_back(0);
         const float tfar = std::fmin(best, tmax[i]);
         float key[8];
         int hit[8], nh = 0;
@@ -163,6 +167,7 @@ static void walk_all(const WTree &T, const RefBvh &rb, const float *P, const uin
       }
       const uint32_t r = cur & ~kLeaf, id = rb.ref_tri[r];
       st->tris++;
+      if (events) events->back().push_back(1);
       const float *a = P + 3 * (size_t)idx[3 * (size_t)id], *b = P + 3 * (size_t)idx[3 * (size_t)id + 1], *c = P + 3 * (size_t)idx[3 * (size_t)id + 2];
       const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
       const float pv[3] = {(dy * e2[2]) - (dz * e2[1]), (dz * e2[0]) - (dx * e2[2]), (dx * e2[1]) - (dy * e2[0])};
@@ -182,6 +187,99 @@ static void walk_all(const WTree &T, const RefBvh &rb, const float *P, const uin
     }
     st->stack += (double)max_stack;
     if (any ? (occ != (rocc[i] != 0)) : (prim != rprim[i] || std::memcmp(&best, &rt[i], 4) != 0)) st->bad++;
+  }
+}
+
+
+// ---- scheduling model: how full are a wave's passes? -------------------------------------------------------------------------
+// A wave works through `rays` (their event sequences) the way intersect_kernel / render_kernel's traversal loop does -- every lane
+// owns one ray, node-step passes (three per scheduling check) run while at least `min_walkers` lanes still walk or nobody waits to be
+// served, a leaf pass runs when `min_parked` lanes are parked or the parked lanes are at least half the steppers, a lane whose ray is
+// over gets the next one in a service pass -- or, POOLED, keeps `pool` rays in LDS and deals up to 64 rays of ONE state to its lanes per
+// pass (the fullest state first; a pass on fewer than `min_pool` rays only when nothing fuller exists).  Counts passes and lanes.
+struct Sched { double step_passes = 0, step_lanes = 0, leaf_passes = 0, leaf_lanes = 0, service_passes = 0, service_lanes = 0, rays = 0; };
+
+static void sched_lanes(const std::vector<std::vector<uint8_t>> &ev, size_t first, size_t count, Sched *out) {
+  const int kMinWalkers = 36, kMinParked = 16, kSteps = 3;
+  struct Lane { long ray = -1; size_t pos = 0; };
+  Lane L[64];
+  size_t next = first, end = first + count;
+  auto done = [&](const Lane &l) { return l.ray < 0 || l.pos >= ev[(size_t)l.ray].size(); };
+  for (;;) {
+    // service: lanes whose ray is over take the next one
+    int finished = 0, walking = 0;
+    for (auto &l : L) { if (done(l)) finished++; else walking++; }
+    if (walking == 0 && next >= end) break;
+    if ((walking < kMinWalkers || walking == 0) && finished > 0 && next < end) {
+      int served = 0;
+      for (auto &l : L) if (done(l) && next < end) { l.ray = (long)next++; l.pos = 0; served++; out->rays++; }
+      out->service_passes++; out->service_lanes += served;
+      continue;
+    }
+    for (int rep = 0; rep < kSteps; rep++) {
+      int act = 0;
+      for (auto &l : L) if (!done(l) && ev[(size_t)l.ray][l.pos] == 0) { l.pos++; act++; }
+      if (act) { out->step_passes++; out->step_lanes += act; }
+    }
+    int parked = 0, steppers = 0;
+    for (auto &l : L) if (!done(l)) { if (ev[(size_t)l.ray][l.pos] == 1) parked++; else steppers++; }
+    if (parked && (parked >= kMinParked || parked * 2 >= steppers)) {
+      for (auto &l : L) if (!done(l) && ev[(size_t)l.ray][l.pos] == 1) l.pos++;
+      out->leaf_passes++; out->leaf_lanes += parked;
+    }
+  }
+}
+
+static void sched_pool(const std::vector<std::vector<uint8_t>> &ev, size_t first, size_t count, int pool, int min_pool, Sched *out) {
+  struct Slot { long ray = -1; size_t pos = 0; };
+  std::vector<Slot> S((size_t)pool);
+  size_t next = first, end = first + count;
+  auto done = [&](const Slot &l) { return l.ray < 0 || l.pos >= ev[(size_t)l.ray].size(); };
+  for (;;) {
+    int ns = 0, nl = 0, nf = 0;
+    for (auto &l : S) { if (done(l)) nf++; else if (ev[(size_t)l.ray][l.pos] == 0) ns++; else nl++; }
+    const bool refill = nf > 0 && next < end;
+    if (ns == 0 && nl == 0 && !refill) break;
+    // the fullest pass first; service counts as full when 64 slots can be refilled
+    const int cs = std::min(ns, 64), cl = std::min(nl, 64), cf = refill ? std::min<int>(nf, 64) : 0;
+    int pick = 0;  // 0 step, 1 leaf, 2 service
+    if (cl > cs) pick = 1;
+    if (cf > std::max(cs, cl)) pick = 2;
+    (void)min_pool;
+    if (pick == 0) {
+      int k = 0;
+      for (auto &l : S) if (k < 64 && !done(l) && ev[(size_t)l.ray][l.pos] == 0) { l.pos++; k++; }
+      out->step_passes++; out->step_lanes += k;
+    } else if (pick == 1) {
+      int k = 0;
+      for (auto &l : S) if (k < 64 && !done(l) && ev[(size_t)l.ray][l.pos] == 1) { l.pos++; k++; }
+      out->leaf_passes++; out->leaf_lanes += k;
+    } else {
+      int k = 0;
+      for (auto &l : S) if (k < 64 && done(l) && next < end) { l.ray = (long)next++; l.pos = 0; k++; out->rays++; }
+      out->service_passes++; out->service_lanes += k;
+    }
+  }
+}
+
+static void sched_report(const char *what, const std::vector<std::vector<uint8_t>> &ev, int W) {
+  // waves of a launch each take a contiguous run of 4096 rays (neighbouring rays of the frame: what a wave of the kernel sees)
+  const size_t per_wave = 4096;
+  const double step_cost = W == 4 ? 88.0 : 88.0 * 1.8, leaf_cost = 70.0, service_cost = 40.0;
+  for (int mode = 0; mode < 4; mode++) {
+    const int pool = mode == 0 ? 0 : (mode == 1 ? 96 : (mode == 2 ? 128 : 256));
+    Sched s;
+    for (size_t f = 0; f + per_wave <= ev.size(); f += per_wave) {
+      if (pool) sched_pool(ev, f, per_wave, pool, 32, &s); else sched_lanes(ev, f, per_wave, &s);
+    }
+    if (s.rays == 0) continue;
+    // a pooled pass pays for dealing rays to lanes and for reading / writing their state in LDS: + 20 instructions on ~ 100
+    const double ovh = pool ? 1.2 : 1.0;
+    const double qc = (s.step_passes * step_cost * ovh + s.leaf_passes * leaf_cost * ovh + s.service_passes * service_cost) / s.rays;
+    std::printf("  %s, %s: per ray %.3f step passes (%.1f lanes), %.3f leaf passes (%.1f lanes), %.3f refills (%.1f lanes) => %.1f issue quad-cycles per ray (model)\n", what,
+                pool ? (pool == 96 ? "pool of  96 rays per wave" : pool == 128 ? "pool of 128 rays per wave" : "pool of 256 rays per wave") : "one ray per lane (today)  ",
+                s.step_passes / s.rays, s.step_lanes / std::max(1.0, s.step_passes), s.leaf_passes / s.rays, s.leaf_lanes / std::max(1.0, s.leaf_passes),
+                s.service_passes / s.rays, s.service_lanes / std::max(1.0, s.service_passes), qc);
   }
 }
 
@@ -210,13 +308,19 @@ int main(int argc, char **argv) {
         WTree T;
         collapse(rb, W, true, &T);
         Stat c, s;
-        walk_all(T, rb, P, idx, nc, co, cd, ct, false, sorted != 0, crt, cprim, nullptr, &c);
-        walk_all(T, rb, P, idx, ns, so, sd, stm, true, sorted != 0, nullptr, nullptr, socc, &s);
+        std::vector<std::vector<uint8_t>> evc, evs;
+        const bool model = optimise && !sorted;
+        walk_all(T, rb, P, idx, nc, co, cd, ct, false, sorted != 0, crt, cprim, nullptr, &c, model ? &evc : nullptr);
+        walk_all(T, rb, P, idx, ns, so, sd, stm, true, sorted != 0, nullptr, nullptr, socc, &s, model ? &evs : nullptr);
         const double rays = (double)(nc + ns), steps = (c.steps + s.steps) / rays, tris = (c.tris + s.tris) / rays;
         const int pieces = W == 4 ? 4 : 5;
         std::printf("%s W=%d %s: nodes %8zu (%.2f children per node, %.1f MB) | steps/ray %6.2f tris/ray %5.2f mean deepest stack %.1f | 16-byte L1 accesses/ray %6.1f | hits %s\n",
                     optimise ? "optimised tree" : "binned SAH    ", W, sorted ? "others by distance" : "others in slot order", T.nodes.size(), T.children / T.nodes.size(),
                     T.nodes.size() * (W == 4 ? 64.0 : 80.0) / 1e6, steps, tris, (c.stack + s.stack) / rays, steps * pieces + tris * 3, (c.bad + s.bad) ? "DIFFER" : "equal to the oracle's");
+        if (model) {
+          sched_report(W == 4 ? "closest-hit rays, W=4" : "closest-hit rays, W=8", evc, W);
+          sched_report(W == 4 ? "shadow rays,      W=4" : "shadow rays,      W=8", evs, W);
+        }
       }
     }
   }
