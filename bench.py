@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--builder", default="gpu", choices=["host", "gpu", "gpu-plain", "host-optimized"],
                     help="accelerator builder: the device builder (the product's default: binned SAH + parallel re-insertion, about 0.13 s "
                          "for 1M triangles), the same without the re-insertion passes (gpu-plain: A-B runs), the host's binned SAH (one core, "
-                         "about a second for 1M triangles) or the host's tree optimised by sequential re-insertion (half a minute for 1M "
+                         "about a second for 1M triangles) or the host's tree optimised by the same pass run on one host core (seconds for 1M "
                          "triangles); same film either way")
     ap.add_argument("--sampler", default="stratified", choices=["stratified", "sobol"])
     ap.add_argument("--filter", type=float, nargs=2, default=None, metavar=("XW", "YW"),

@@ -320,8 +320,9 @@ class Scene:
     def __init__(self, sd, device=-1, builder=None):
         """builder: None (host SAH builder unless PBRT_HIP_BUILDER=gpu), "host", "gpu" (accelerator built AND optimised by parallel
         re-insertion on the device: tens of milliseconds; the product's default elsewhere), "gpu-plain" (the device's tree as built,
-        PBRT_HIP_SCENE_PLAIN_TREE: A-B runs) or "host-optimized" (PBRT_HIP_SCENE_OPTIMIZED_TREE: round 3's sequential re-insertion on
-        one host core, half a minute per million triangles).  Same film and hit records whichever is used."""
+        PBRT_HIP_SCENE_PLAIN_TREE: A-B runs) or "host-optimized" (PBRT_HIP_SCENE_OPTIMIZED_TREE: the host builder
+        followed by the same re-insertion pass run on one host core, seconds per million triangles).  Same film and hit records whichever
+        is used."""
         self.sd = sd.normalized()
         desc = SceneDesc()
         keep = fill_desc(desc, self.sd, Material, Light, Sphere)
