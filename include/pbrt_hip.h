@@ -129,27 +129,35 @@ const char *pbrt_hip_version(void);
  * profile taken on one build must not price another: bench.py compares this with the id stored beside the counters */
 const char *pbrt_hip_build_id(void);
 
-/* ---- scene: flatten + BVH build on the host, upload to HBM.  device < 0: current device.
+/* ---- scene: upload to HBM, accelerator build.  device < 0: current device.
  * Input is validated before any device work: indices in range, vertices / spheres / camera matrix finite, sphere radii
- * positive, 0 < fov < 180 (PBRT_HIP_ERR_INVALID otherwise). ---- */
+ * positive, 0 < fov < 180 (PBRT_HIP_ERR_INVALID otherwise).
+ * ONE default, whoever builds (this call, pbrt_hip_scene_create_ex with flags 0, pbrt_hip_multi_create, pbrt_hip_render_multi,
+ * the command line): the accelerator is built ON THE DEVICE from the uploaded vertex / index buffers -- Morton order,
+ * level-synchronous binned SAH, the tree (from 1024 triangles on) optimised by parallel re-insertion, collapse into the
+ * quantised 4-wide nodes; stands in for what core/api.rs:237 names "bvh" and api.rs:446-453 would have
+ * built: 0.1 s for 1M triangles.  So a `world_end` that calls pbrt_hip_scene_create + pbrt_hip_render gets the same tree as
+ * one that calls pbrt_hip_render_multi.  PBRT_HIP_BUILDER=host in the environment turns the default into
+ * PBRT_HIP_SCENE_HOST_BUILD for callers that left the choice open (flags 0). ---- */
 int pbrt_hip_scene_create(const pbrt_hip_scene_desc *desc, int device, pbrt_hip_scene **out);
-/* The same with options.  PBRT_HIP_SCENE_GPU_BUILD: build the accelerator on the device (Morton order, level-synchronous
- * binned SAH, the tree -- from 1024 triangles on -- optimised by parallel re-insertion, collapse into the quantised 4-wide nodes; SURVEY.md 8 row f3;
- * stands in for what core/api.rs:237 names "bvh" and api.rs:446-453 would have built) instead of the host's binned-SAH
- * builder: tens of milliseconds instead of a second for 1M triangles, a tree rays cross in fewer steps, the SAME film and
- * hit records bit for bit (a hit does not depend on the tree).  The counter flags of render / intersect
- * count the oracle's canonical walk: for such a scene the canonical tree is built on the host at the first call that
- * asks for them (vertex / index buffers read back; about a second for 1M triangles, never on the render path).
- * pbrt_hip_scene_create(desc, ...) == pbrt_hip_scene_create_ex(desc, ..., getenv("PBRT_HIP_BUILDER") == "gpu"). */
+/* The same with options (0 = the default above).
+ * PBRT_HIP_SCENE_GPU_BUILD: the default, said explicitly (PBRT_HIP_BUILDER is then not consulted).  The SAME film and hit
+ * records bit for bit whichever builder is used (a hit does not depend on the tree).  The counter flags of
+ * render / intersect count the oracle's canonical walk: for a device-built scene the canonical tree is built on the host at
+ * the first call that asks for them (vertex / index buffers read back; about a second for 1M triangles, never on the
+ * render path). */
 #define PBRT_HIP_SCENE_GPU_BUILD 1u
-/* PBRT_HIP_SCENE_OPTIMIZED_TREE: the HOST builder followed by the tree optimisation the device builder applies by default -- parallel
+/* PBRT_HIP_SCENE_OPTIMIZED_TREE: the HOST builder followed by the tree optimisation the device builder applies -- parallel
  * re-insertion (pbrt_amd/csrc/reinsert_core.hpp), run on one host core: a few seconds per million triangles, 4-6 % fewer node
- * fetches per ray than the plain host tree, same film and hit records bit for bit.  For hosts that build on the CPU;
- * PBRT_HIP_SCENE_GPU_BUILD does the same in a tenth of a second.  Not combined with PBRT_HIP_SCENE_GPU_BUILD (PBRT_HIP_ERR_INVALID). */
+ * fetches per ray than the plain host tree.  For hosts that must build on the CPU.  Not combined with PBRT_HIP_SCENE_GPU_BUILD /
+ * PBRT_HIP_SCENE_PLAIN_TREE (PBRT_HIP_ERR_INVALID). */
 #define PBRT_HIP_SCENE_OPTIMIZED_TREE 2u
-/* PBRT_HIP_SCENE_PLAIN_TREE (with PBRT_HIP_SCENE_GPU_BUILD): the device's binned-SAH tree as built, without the re-insertion
- * passes (A-B measurements; the default device build optimises). */
+/* PBRT_HIP_SCENE_PLAIN_TREE: the device's binned-SAH tree as built, without the re-insertion passes (A-B measurements). */
 #define PBRT_HIP_SCENE_PLAIN_TREE 4u
+/* PBRT_HIP_SCENE_HOST_BUILD: the host's binned-SAH builder (the canonical tree of the oracle and of the counter
+ * flags, collapsed into the 4-wide nodes as it is): 0.7 s per million triangles on one core and a tree rays cross in ~4.5 % more
+ * steps -- kept for A-B runs and for tests of that builder.  Not combined with PBRT_HIP_SCENE_GPU_BUILD / _PLAIN_TREE. */
+#define PBRT_HIP_SCENE_HOST_BUILD 8u
 int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *desc, int device, uint32_t flags, pbrt_hip_scene **out);
 /* how the accelerator was built: *gpu_built 0 / 1, *build_ms = host build time (wall) or device build time (events) */
 int pbrt_hip_scene_build_info(const pbrt_hip_scene *scene, uint32_t *gpu_built, double *build_ms);

@@ -19,7 +19,8 @@ FLAG_WALK_COUNTERS = 2
 SCENE_GPU_BUILD = 1  # pbrt_hip_scene_create_ex flags
 SCENE_OPTIMIZED_TREE = 2
 SCENE_PLAIN_TREE = 4
-BUILDERS = {"host": 0, "gpu": SCENE_GPU_BUILD, "gpu-plain": SCENE_GPU_BUILD | SCENE_PLAIN_TREE, "host-optimized": SCENE_OPTIMIZED_TREE}
+SCENE_HOST_BUILD = 8
+BUILDERS = {"host": SCENE_HOST_BUILD, "gpu": SCENE_GPU_BUILD, "gpu-plain": SCENE_GPU_BUILD | SCENE_PLAIN_TREE, "host-optimized": SCENE_OPTIMIZED_TREE}
 
 
 def _fp(a):
@@ -258,13 +259,14 @@ class MultiScene:
     """A scene replicated on n GPUs of this node inside ONE process (pbrt_hip_multi_*): GPU g renders the super-tiles
     t % n == g from its own host thread and stream, one RCCL gather assembles the film on GPU 0."""
 
-    def __init__(self, sd, n_gpus=0, builder="host"):
+    def __init__(self, sd, n_gpus=0, builder=None):
+        """builder: as Scene (None = the library's default, the device builder)."""
         self._h = None
         self.sd = sd.normalized()
         desc = SceneDesc()
         keep = fill_desc(desc, self.sd, Material, Light, Sphere)
         h = C.c_void_p()
-        check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), BUILDERS[builder], C.byref(h)),
+        check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), BUILDERS[builder] if builder else 0, C.byref(h)),
               "pbrt_hip_multi_create")
         del keep
         self._h = h
@@ -318,8 +320,9 @@ class Scene:
     """A scene resident in HBM (flattened BVH + leaf-ordered triangles + tables)."""
 
     def __init__(self, sd, device=-1, builder=None):
-        """builder: None (host SAH builder unless PBRT_HIP_BUILDER=gpu), "host", "gpu" (accelerator built AND optimised by parallel
-        re-insertion on the device: tens of milliseconds; the product's default elsewhere), "gpu-plain" (the device's tree as built,
+        """builder: None (the library's one default: pbrt_hip_scene_create = "gpu" unless PBRT_HIP_BUILDER=host), "host" (the host's
+        binned-SAH builder, the canonical tree), "gpu" (accelerator built AND optimised by parallel
+        re-insertion on the device: tens of milliseconds), "gpu-plain" (the device's tree as built,
         PBRT_HIP_SCENE_PLAIN_TREE: A-B runs) or "host-optimized" (PBRT_HIP_SCENE_OPTIMIZED_TREE: the host builder
         followed by the same re-insertion pass run on one host core, seconds per million triangles).  Same film and hit records whichever
         is used."""

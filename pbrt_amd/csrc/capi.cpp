@@ -706,8 +706,7 @@ int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t
 }
 
 int pbrt_hip_scene_create(const pbrt_hip_scene_desc *d, int device, pbrt_hip_scene **out) {
-  const char *b = std::getenv("PBRT_HIP_BUILDER");
-  return pbrt_hip_scene_create_ex(d, device, (b && std::strcmp(b, "gpu") == 0) ? PBRT_HIP_SCENE_GPU_BUILD : 0u, out);
+  return pbrt_hip_scene_create_ex(d, device, 0u, out);  // the default: built and optimised on the device
 }
 
 int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t flags, pbrt_hip_scene **out) {
@@ -754,12 +753,23 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     s->desc.P = nullptr; s->desc.idx = nullptr; s->desc.mat_id = nullptr;
     s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
 
-    // --- accelerator: the host's binned-SAH builder, or (PBRT_HIP_SCENE_GPU_BUILD) the device builder further down ---
-    if (flags & ~(PBRT_HIP_SCENE_GPU_BUILD | PBRT_HIP_SCENE_OPTIMIZED_TREE | PBRT_HIP_SCENE_PLAIN_TREE)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
-    if ((flags & PBRT_HIP_SCENE_PLAIN_TREE) && !(flags & PBRT_HIP_SCENE_GPU_BUILD))
-      return fail(PBRT_HIP_ERR_INVALID, "scene_create: PBRT_HIP_SCENE_PLAIN_TREE qualifies PBRT_HIP_SCENE_GPU_BUILD");
-    if ((flags & PBRT_HIP_SCENE_GPU_BUILD) && (flags & PBRT_HIP_SCENE_OPTIMIZED_TREE))
-      return fail(PBRT_HIP_ERR_INVALID, "scene_create: PBRT_HIP_SCENE_OPTIMIZED_TREE is a host build, not combined with PBRT_HIP_SCENE_GPU_BUILD");
+    // --- accelerator: ONE default -- the device builder further down (binned SAH + parallel re-insertion + collapse), whoever asks
+    // and however (pbrt_hip_scene_create, flags 0, pbrt_hip_render_multi, the command line, bench.py); the host's binned-SAH
+    // builder only on request (PBRT_HIP_SCENE_HOST_BUILD / _OPTIMIZED_TREE, or PBRT_HIP_BUILDER=host in the environment when the
+    // caller left the choice open) ---
+    if (flags & ~(PBRT_HIP_SCENE_GPU_BUILD | PBRT_HIP_SCENE_OPTIMIZED_TREE | PBRT_HIP_SCENE_PLAIN_TREE | PBRT_HIP_SCENE_HOST_BUILD))
+      return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown flag");
+    const bool want_host = (flags & (PBRT_HIP_SCENE_HOST_BUILD | PBRT_HIP_SCENE_OPTIMIZED_TREE)) != 0u;
+    const bool want_gpu = (flags & (PBRT_HIP_SCENE_GPU_BUILD | PBRT_HIP_SCENE_PLAIN_TREE)) != 0u;
+    if (want_host && want_gpu)
+      return fail(PBRT_HIP_ERR_INVALID, "scene_create: PBRT_HIP_SCENE_HOST_BUILD / _OPTIMIZED_TREE are host builds, not combined with PBRT_HIP_SCENE_GPU_BUILD / _PLAIN_TREE");
+    if (!want_host && !want_gpu) {
+      const char *b = std::getenv("PBRT_HIP_BUILDER");
+      if (b && std::strcmp(b, "host") == 0) flags |= PBRT_HIP_SCENE_HOST_BUILD;
+      else flags |= PBRT_HIP_SCENE_GPU_BUILD;
+    } else if (want_gpu) {
+      flags |= PBRT_HIP_SCENE_GPU_BUILD;  // (PBRT_HIP_SCENE_PLAIN_TREE alone qualifies the default)
+    }
     s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && d->n_tris >= 2;
     if (d->n_tris > (1u << 24)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 2^24 triangles (leaf references hold a 24-bit slot)");
     PairNodes pairs;

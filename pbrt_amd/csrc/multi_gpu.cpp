@@ -351,7 +351,7 @@ int pbrt_hip_multi_film_device(pbrt_hip_multi *m, void **d_film) {
 int pbrt_hip_render_multi(const pbrt_hip_scene_desc *d, const pbrt_hip_render_desc *r, int n_gpus, float *film, pbrt_hip_stats *per_gpu) {
   pbrt_hip_multi *m = nullptr;
   // world_end has one frame to render: the accelerator is built on the device (milliseconds)
-  int rc = pbrt_hip_multi_create(d, n_gpus, PBRT_HIP_SCENE_GPU_BUILD, &m);
+  int rc = pbrt_hip_multi_create(d, n_gpus, 0u /* the one default: built and optimised on the device */, &m);
   if (rc) return rc;
   rc = pbrt_hip_multi_render(m, r, film, per_gpu);
   const std::string keep = rc ? pbrt_hip_last_error() : "";

@@ -22,6 +22,20 @@ def psnr(a, b):
     return np.inf if mse == 0 else 10 * np.log10(1.0 / mse)
 
 
+# The BASELINE-size cases run on BOTH builders -- "gpu" is what every default path of the library ships (pbrt_hip_scene_create,
+# pbrt_hip_render_multi, the command line, bench.py: built and optimised on the device), "host" the canonical binned-SAH tree -- and
+# the oracle's answer for a case is computed once.
+BUILDERS = [pytest.param(None, id="default"), "host"]  # None = pbrt_hip_scene_create, the §8(b) entry point: must be the device build
+_oracle_cache = {}
+
+
+def oracle_render(oracle, key, make_sd, **kw):
+    k = (key, tuple(sorted((a, str(b)) for a, b in kw.items())))
+    if k not in _oracle_cache:
+        _oracle_cache[k] = oracle.OracleScene(make_sd()).render(**kw)
+    return _oracle_cache[k]
+
+
 def test_native_library_is_the_one_loaded(gpu):
     """The GPU tests run on the in-tree HIP library, not on a fallback."""
     maps = open("/proc/self/maps").read()
@@ -31,15 +45,17 @@ def test_native_library_is_the_one_loaded(gpu):
     assert os.path.realpath(_lib.LIB_PATH) in maps and "/pbrt_amd/lib" in _lib.LIB_PATH  # (lib_<variant>/ for A-B builds)
 
 
+@pytest.mark.parametrize("builder", [None, "host"])  # None: the library's default (pbrt_hip_scene_create: built and optimised on the device)
 @pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere", "ties", "deep"])
-def test_intersect_matches_oracle(gpu, oracle, name):
+def test_intersect_matches_oracle(gpu, oracle, name, builder):
     sd = SMALL_SCENES[name]()
     o, d, tmax = random_rays(200_000 if name != "mesh20k" else 400_000, 21)
     ref = oracle.OracleScene(sd)
     rt, rp, rb1, rb2, rc = ref.intersect(o, d, tmax)
-    with gpu.Scene(sd) as sc:
-        sc_depth, sc_need = sc.info()["depth"], sc.info()["quad_stack_need"]
+    with gpu.Scene(sd, builder=builder) as sc:  # (device-built: the canonical tree behind the counters is made lazily)
+        assert sc.build_info()["gpu_built"] == (builder is None and sc.sd.idx.shape[0] >= 2)
         t, prim, b1, b2, cnt = sc.intersect(o, d, tmax, counters=True)
+        sc_depth, sc_need = sc.info()["depth"], sc.info()["quad_stack_need"]
         occ = sc.occluded(o, d, tmax)
         t2 = sc.intersect(o, d, tmax)[0]  # the non-counting instantiation
     assert_bit_equal(prim, rp, "prim")
@@ -51,7 +67,8 @@ def test_intersect_matches_oracle(gpu, oracle, name):
     assert_bit_equal(occ, ref.occluded(o, d, tmax), "occluded")
     assert (prim != 0xFFFFFFFF).mean() > (0.05 if name != "deep" else 0.0005)
     if name == "deep":
-        assert sc_depth >= 39 and sc_need > 40  # more than the 40 LDS entries -> the overflow variant runs
+        assert sc_depth >= 39  # (the canonical tree; the host's 4-wide collapse of it needs more than the 40 LDS entries: overflow variant)
+        assert sc_need > 40 or builder is None
 
 
 def test_intersect_edge_cases(gpu, oracle):
@@ -90,11 +107,12 @@ RENDER_CASES = [
 ]
 
 
+@pytest.mark.parametrize("builder", [None, "host"])
 @pytest.mark.parametrize("name,integrator,depth,spp,seed", RENDER_CASES)
-def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
+def test_render_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed, builder):
     sd = SMALL_SCENES[name]()
-    ref, rst = oracle.OracleScene(sd).render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
-    with gpu.Scene(sd) as sc:
+    ref, rst = oracle_render(oracle, ("small", name), lambda: sd, integrator=integrator, max_depth=depth, spp=spp, seed=seed)
+    with gpu.Scene(sd, builder=builder) as sc:
         film, st = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed, counters=True)
         film2, st2 = sc.render(integrator=integrator, max_depth=depth, spp=spp, seed=seed)
     assert_bit_equal(film, ref, f"{name} film")
@@ -351,34 +369,40 @@ def test_device_slab_path_with_torch(gpu, oracle):
         assert_bit_equal(f1.cpu().numpy(), ref, "render_sharded world 1")
 
 
-def test_c2_crop_windows_at_full_spp(gpu, oracle):
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_c2_crop_windows_at_full_spp(gpu, oracle, builder):
     """BASELINE config C2 (100k triangles, 1024x1024, 256 spp, maxdepth 8): two 32x32 windows of
-    the frame at the full sample count against the oracle, bit for bit."""
+    the frame at the full sample count against the oracle, bit for bit -- films from the production walk of the builder's tree,
+    canonical counters (for the device-built tree: through the lazily built canonical tree)."""
     for crop in [(0.5, 0.53125, 0.5, 0.53125), (0.125, 0.15625, 0.8125, 0.84375)]:
         sd = scenes.random_mesh_scene(100_000, 1024, 1024, crop=crop)
-        ref, rst = oracle.OracleScene(sd).render(max_depth=8, spp=(16, 16), seed=0)
-        with gpu.Scene(sd) as sc:
+        ref, rst = oracle_render(oracle, ("c2", crop), lambda: sd, max_depth=8, spp=(16, 16), seed=0)
+        with gpu.Scene(sd, builder=builder) as sc:
+            assert sc.build_info()["gpu_built"] == (builder is None)
+            plain, _ = sc.render(max_depth=8, spp=(16, 16), seed=0)
             film, st = sc.render(max_depth=8, spp=(16, 16), seed=0, counters=True)
         assert film.shape == (32, 32, 4)
-        assert_bit_equal(film, ref, f"C2 window {crop}")
+        assert_bit_equal(plain, ref, f"C2 window {crop} ({builder} tree, production walk)")
+        assert_bit_equal(film, ref, f"C2 window {crop} ({builder}, canonical walk)")
         assert st["nodes_visited"] == rst["nodes_visited"] and st["tris_tested"] == rst["tris_tested"]
 
 
-def test_full_size_properties_c2(gpu, oracle):
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_full_size_properties_c2(gpu, oracle, builder):
     """The whole C2 frame at reduced spp: size-independent properties + a window against the oracle."""
     sd = scenes.random_mesh_scene(100_000, 1024, 1024)
-    with gpu.Scene(sd) as sc:
+    with gpu.Scene(sd, builder=builder) as sc:
         info = sc.info()
         film, st = sc.render(max_depth=8, spp=(2, 2), seed=0)
         again, _ = sc.render(max_depth=8, spp=(2, 2), seed=0)
-    assert info["depth"] <= 64
+    assert info["depth"] <= 64 and (info["depth"] > 0) == (builder == "host")  # (a device-built scene has no canonical tree yet)
     assert film.shape == (1024, 1024, 4)
     assert (film[..., 3] == 4).all()                      # every pixel got exactly spp samples
     assert np.isfinite(film).all() and (film[..., 1] >= 0).all()
     assert_bit_equal(film, again, "idempotence")           # no run-to-run nondeterminism
     assert st["samples"] == 1024 * 1024 * 4
-    win = scenes.random_mesh_scene(100_000, 1024, 1024, crop=(0.25, 0.3125, 0.25, 0.3125))
-    ref, _ = oracle.OracleScene(win).render(max_depth=8, spp=(2, 2), seed=0)
+    ref, _ = oracle_render(oracle, "c2-full-window", lambda: scenes.random_mesh_scene(100_000, 1024, 1024, crop=(0.25, 0.3125, 0.25, 0.3125)),
+                           max_depth=8, spp=(2, 2), seed=0)
     assert_bit_equal(film[256:320, 256:320], ref, "window of the full frame")
 
 
@@ -412,11 +436,13 @@ def test_full_size_wide_filter_c2_and_c3(gpu, oracle):
             assert_bit_equal(nd[sl], o.render(**dict(kw, sampler="sobol_nd"))[0], "window of the full frame, sampler 2")
 
 
-def test_c2_full_frame_eight_rank_shares_add_up(gpu):
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_c2_full_frame_eight_rank_shares_add_up(gpu, oracle, builder):
     """BASELINE config C2 at its full size and sample count: the frame rendered by one rank equals, bit for bit, the sum
-    of the eight shares of an 8-GPU job: sharding and the dynamic, XCD-aware hand-out of work items change no sample."""
+    of the eight shares of an 8-GPU job: sharding and the dynamic, XCD-aware hand-out of work items change no sample.  And a
+    window of that full frame equals the oracle's render of the window."""
     sd = scenes.random_mesh_scene(100_000, 1024, 1024)
-    with gpu.Scene(sd) as sc:
+    with gpu.Scene(sd, builder=builder) as sc:
         full, st = sc.render(max_depth=8, spp=(16, 16), seed=0)
         acc = np.zeros_like(full)
         n = 0
@@ -428,18 +454,34 @@ def test_c2_full_frame_eight_rank_shares_add_up(gpu):
     assert n == st["samples"] == 1024 * 1024 * 256
     assert (full[..., 3] == 256).all()
     assert_bit_equal(acc, full, "sum of 8 rank shares vs the single-rank frame")
+    crop = (0.5, 0.53125, 0.5, 0.53125)  # (the first window of test_c2_crop_windows_at_full_spp: the oracle's film is shared)
+    ref, _ = oracle_render(oracle, ("c2", crop), lambda: scenes.random_mesh_scene(100_000, 1024, 1024, crop=crop), max_depth=8, spp=(16, 16), seed=0)
+    assert_bit_equal(full[512:544, 512:544], ref, f"window of the full C2 frame at 256 spp ({builder} tree)")
 
 
-def test_c3_scene_window(gpu, oracle):
-    """BASELINE config C3's scene (1M triangles, 2048x2048): a 16x16 window at 32x16 = 512 spp."""
+_c3_window_fetches = {}
+
+
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_c3_scene_window(gpu, oracle, builder):
+    """BASELINE config C3's scene (1M triangles, 2048x2048): a 16x16 window at 32x16 = 512 spp, on the tree that ships (built and
+    optimised on the device: 12 re-insertion passes over 2M nodes) and on the host's."""
     crop = (0.5, 0.5 + 16 / 2048, 0.5, 0.5 + 16 / 2048)
     sd = scenes.random_mesh_scene(1_000_000, 2048, 2048, crop=crop)
-    ref, rst = oracle.OracleScene(sd).render(max_depth=8, spp=(32, 16), seed=0)
-    with gpu.Scene(sd) as sc:
-        assert sc.info()["depth"] <= 64
+    ref, rst = oracle_render(oracle, "c3-window", lambda: sd, max_depth=8, spp=(32, 16), seed=0)
+    with gpu.Scene(sd, builder=builder) as sc:
+        bi = sc.build_info()
+        assert bi["gpu_built"] == (builder is None) and (bi["reinsert_moves"] > 100_000) == (builder is None)
+        plain, wst = sc.render(max_depth=8, spp=(32, 16), seed=0, counters="walk")
         film, st = sc.render(max_depth=8, spp=(32, 16), seed=0, counters=True)
-    assert_bit_equal(film, ref, "C3 window")
-    assert st["nodes_visited"] == rst["nodes_visited"]
+        assert 0 < sc.info()["depth"] <= 64
+    assert_bit_equal(plain, ref, f"C3 window ({builder} tree, production walk)")
+    assert_bit_equal(film, ref, f"C3 window ({builder}, canonical walk)")
+    assert st["nodes_visited"] == rst["nodes_visited"] and st["tris_tested"] == rst["tris_tested"]
+    rays = wst["camera_rays"] + wst["bounce_rays"] + wst["shadow_rays"]
+    _c3_window_fetches[builder] = wst["nodes_visited"] / rays  # 64-byte fetches per ray of the production walk (this window's ray mix)
+    if len(_c3_window_fetches) == 2:  # the optimised device tree is the cheaper one to walk (full frame: 38.4 against 40.2)
+        assert _c3_window_fetches[None] < _c3_window_fetches["host"], _c3_window_fetches
 
 
 def test_c0_scene_file_renders_like_the_oracle(gpu, oracle):
@@ -457,6 +499,25 @@ def test_c0_scene_file_renders_like_the_oracle(gpu, oracle):
     assert_bit_equal(film, ref, "C0 film")
     rgb = gpu.film_to_rgb(film)
     assert rgb[5, 5].mean() > 0.3 and np.isfinite(rgb).all()  # the sky is visible and lit
+
+
+def test_c0_as_baseline_states_it(gpu, oracle):
+    """BASELINE configs[0] AS WRITTEN: the check-sphere scene (scenes/c0_check_sphere.pbrt = the reference's
+    scenes/check-sphere.pbrt:1-37) at 256x256, 4 samples per pixel (2x2 strata, stratified sampler), whole frame, through the C++
+    parser on both sides: HIP film == oracle film bit for bit, with the file's own default sampler name ("halton") as well."""
+    import os
+    from pbrt_amd import loader
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "c0_check_sphere.pbrt")).read()
+    text = text.replace("[400]", "[256]").replace('"integer pixelsamples" 128', '"integer pixelsamples" 4')
+    for sampler in ("stratified", "halton"):
+        ls = loader.load_string(text.replace('Sampler "halton"', f'Sampler "{sampler}"'))
+        assert (ls.scene.xres, ls.scene.yres) == (256, 256) and ls.spp == (2, 2) and ls.integrator == INTEGRATOR_PATH
+        assert (ls.sampler == 0) == (sampler == "stratified")
+        ref, _ = oracle.OracleScene(ls.scene).render(seed=0, **ls.render_kwargs())
+        with gpu.Scene(ls.scene) as sc:
+            film, st = sc.render(seed=0, **ls.render_kwargs())
+        assert film.shape == (256, 256, 4) and st["samples"] == 256 * 256 * 4 and (film[..., 3] == 4).all()
+        assert_bit_equal(film, ref, f"C0 film at 256x256, 4 spp, Sampler \"{sampler}\"")
 
 
 def test_cli_renders_c0(gpu, tmp_path):
@@ -500,20 +561,26 @@ def test_native_cli_renders_c0(gpu, tmp_path):
     assert subprocess.run([CLI_PATH, "-q", str(tmp_path / "missing.pbrt")], capture_output=True).returncode == 1
 
 
-def test_full_size_properties_c3(gpu, oracle):
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_full_size_properties_c3(gpu, oracle, builder):
     """BASELINE config C3's full frame (1M triangles, 2048x2048) at 2 spp: every pixel gets exactly spp
     samples, finite, idempotent; three 16x16 windows of that frame against the oracle."""
     sd = scenes.random_mesh_scene(1_000_000, 2048, 2048)
-    with gpu.Scene(sd) as sc:
+    with gpu.Scene(sd, builder=builder) as sc:
         film, st = sc.render(max_depth=8, spp=(2, 1), seed=0)
-        again, _ = sc.render(max_depth=8, spp=(2, 1), seed=0)
+        again, wst = sc.render(max_depth=8, spp=(2, 1), seed=0, counters="walk")
+        bi = sc.build_info()
+    rays = wst["camera_rays"] + wst["bounce_rays"] + wst["shadow_rays"]
+    if builder is None:  # pbrt_hip_scene_create + pbrt_hip_render = the documented pair: the optimised device tree, <= 38.5 64-byte fetches per ray
+        assert bi["gpu_built"] and bi["reinsert_passes"] > 0 and wst["nodes_visited"] / rays <= 38.5, (bi, wst["nodes_visited"] / rays)
+    else:
+        assert not bi["gpu_built"] and wst["nodes_visited"] / rays > 38.5
     assert film.shape == (2048, 2048, 4) and (film[..., 3] == 2).all() and np.isfinite(film).all()
     assert_bit_equal(film, again, "idempotence")
     assert st["samples"] == 2048 * 2048 * 2
     for (x0, y0) in [(0, 0), (1024, 1024), (2032, 2032)]:
         crop = (x0 / 2048, (x0 + 16) / 2048, y0 / 2048, (y0 + 16) / 2048)
-        win = scenes.random_mesh_scene(1_000_000, 2048, 2048, crop=crop)
-        ref, _ = oracle.OracleScene(win).render(max_depth=8, spp=(2, 1), seed=0)
+        ref, _ = oracle_render(oracle, ("c3-full", x0, y0), lambda: scenes.random_mesh_scene(1_000_000, 2048, 2048, crop=crop), max_depth=8, spp=(2, 1), seed=0)
         assert_bit_equal(film[y0:y0 + 16, x0:x0 + 16], ref, f"window at {x0},{y0}")
 
 
@@ -535,12 +602,13 @@ def test_full_size_properties_c1(gpu, oracle):
         assert_bit_equal(film[y0:y0 + 32, x0:x0 + 32], ref, f"C1 window at {x0},{y0}")
 
 
-def test_full_size_properties_c4(gpu, oracle):
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_full_size_properties_c4(gpu, oracle, builder):
     """BASELINE config C4's full 4096x4096 frame (Cornell-style box, path, maxdepth 16) at 2x2 spp: weight == spp,
     finite, idempotent; three 32x32 windows of the frame against the oracle."""
     sd = scenes.cornell_scene(4096, 4096)
     kw = dict(max_depth=16, spp=(2, 2), seed=0)
-    with gpu.Scene(sd) as sc:
+    with gpu.Scene(sd, builder=builder) as sc:
         film, st = sc.render(**kw)
         again, _ = sc.render(**kw)
     assert film.shape == (4096, 4096, 4) and (film[..., 3] == 4).all() and np.isfinite(film).all() and (film[..., 1] >= 0).all()
@@ -548,19 +616,22 @@ def test_full_size_properties_c4(gpu, oracle):
     assert st["samples"] == 4096 * 4096 * 4
     for (x0, y0) in [(0, 0), (2048, 1024), (4064, 4064)]:
         crop = (x0 / 4096, (x0 + 32) / 4096, y0 / 4096, (y0 + 32) / 4096)
-        ref, _ = oracle.OracleScene(scenes.cornell_scene(4096, 4096, crop=crop)).render(**kw)
+        ref, _ = oracle_render(oracle, ("c4-full", x0, y0), lambda: scenes.cornell_scene(4096, 4096, crop=crop), **kw)
         assert_bit_equal(film[y0:y0 + 32, x0:x0 + 32], ref, f"C4 window at {x0},{y0}")
 
 
-def test_c4_window_at_full_spp(gpu, oracle):
+@pytest.mark.parametrize("builder", BUILDERS)
+def test_c4_window_at_full_spp(gpu, oracle, builder):
     """BASELINE config C4 (Cornell-style box, 4096x4096, 64x64 = 4096 spp, maxdepth 16): an 8x8 window at the
     full sample count, bit for bit (262k paths of depth up to 16 through the longest RNG streams of any config)."""
     crop = (0.5, 0.5 + 8 / 4096, 0.25, 0.25 + 8 / 4096)
     sd = scenes.cornell_scene(4096, 4096, crop=crop)
-    ref, rst = oracle.OracleScene(sd).render(max_depth=16, spp=(64, 64), seed=0)
-    with gpu.Scene(sd) as sc:
+    ref, rst = oracle_render(oracle, "c4-window", lambda: sd, max_depth=16, spp=(64, 64), seed=0)
+    with gpu.Scene(sd, builder=builder) as sc:
+        plain, _ = sc.render(max_depth=16, spp=(64, 64), seed=0)
         film, st = sc.render(max_depth=16, spp=(64, 64), seed=0, counters=True)
     assert film.shape == (8, 8, 4) and (film[..., 3] == 4096).all()
+    assert_bit_equal(plain, ref, f"C4 window ({builder} tree, production walk)")
     assert_bit_equal(film, ref, "C4 window")
     for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
         assert st[k] == rst[k]
