@@ -13,14 +13,31 @@ timing starts.  N>1: one process per GPU under torch.distributed.run (the driver
 `--single-process`: all N GPUs from this one process through pbrt_hip_multi_* (one host thread per GPU,
 ncclGather inside the library).
 
-Rank 0 prints ONE JSON line.  `roofline` (dominant kernel = render_kernel):
-  bound "valu"  the resource the counters show binding: vector-instruction issue.  achieved = the
-                quad-cycles in which the SIMDs issued vector instructions (MEASURED by the SQ: SQ_ACTIVE_INST_VALU -
-                SQ_ACTIVE_INST_VALU2 per ray, from the committed PMC profile of this very build, x the rays of this launch,
-                counted live) / the kernel's HIP-event time; peak = SIMDs x clock / 4.  frac <= 1 by construction.
-  hbm           SURVEY 8(d)'s contract figure kept beside it: algorithmic bytes of the CANONICAL walk / kernel time
-                against 8 TB/s (can exceed 1: the scene is cache-resident and the production walk moves fewer bytes),
-                and what the memory-side counters saw (`traffic`, hbm_counter_frac).
+`python bench.py --gpus N` with N > 1 and NO torch.distributed environment (no WORLD_SIZE) takes the in-library path by
+itself -- decided from argv and the environment before anything touches a GPU, no re-exec -- so the command produces a line
+however it is launched.
+
+Rank 0 prints ONE JSON line.  Every figure of `roofline` (dominant kernel = render_kernel) follows from three inputs --
+P = profiles/pmc_<workload>.json (the committed rocprofv3 --pmc passes of THIS kernel's ISA and builder), R = rays_per_launch
+(counted live by the exact-counter instantiation) and T = kernel_ms (HIP events on the launch stream, average of the timed
+steps) -- by one formula each:
+  achieved          = P.valu_issue_quadcycles_per_ray x R / T                     [G vector-issue quad-cycles/s]
+  peak              = CUs x 4 SIMDs x 2.4 GHz / 4                                  (614.4 G for 256 CUs)
+  frac              = achieved / peak             the share of all SIMD quad-cycles in which a vector instruction issued: a BUSY
+                                                  fraction (utilisation of the issue port), not useful work
+  frac_at_measured_clock = achieved / (CUs x 4 x clock_ghz_measured / 4)
+  lane_utilisation  = P.lane_utilisation          active lanes per issued vector instruction / 64
+  frac_useful       = frac x lane_utilisation     the share of the chip's lane-issue slots that did work for a ray
+  l1.frac           = P.l1_accesses_per_ray x R / T / 693.6 G   (16-byte gathers against tools/ubench/gather_wide.hip's roof)
+  l2_miss.requests_per_s = (hbm.kernel_fetches_per_ray + hbm.kernel_tris_per_ray) x R / T x (1 - P.l2_hit_rate)
+                                                  64-byte records that miss the XCD's L2, against l2_miss.peak = 58.1 G records/s
+                                                  (the same microbenchmark on a 112 MB table: past L2, inside the Infinity Cache)
+  hbm.frac          = (32 x nodes_visited + 48 x tris_tested of the CANONICAL walk + 28 + 16/spp per sample) x samples / T / 8 TB/s
+                                                  SURVEY 8(d)'s contract figure (exceeds 1 when hbm.cache_resident: the hot working
+                                                  set -- quad nodes + triangle records -- then fits the 256 MiB Infinity Cache and
+                                                  the production walk moves fewer bytes, kernel_*)
+  hbm_counter_frac  = P.traffic_bytes_raw / P.avg_ms / 8 TB/s                      north_star's "rocprof achieved HBM GB/s":
+                                                  (FETCH_SIZE + WRITE_SIZE) x 1024 of the dedicated --pmc passes
 `cpu_baseline` (N=1): the CPU oracle timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
@@ -38,6 +55,26 @@ SIMDS_PER_CU = 4
 # what the CUs' vector L1s deliver to random 16-byte-per-lane gathers of 64-byte records that hit in L2: 173.4 G records/s x 4 accesses,
 # measured with tools/ubench/gather_wide.hip (profiles/r03end_gather_wide_48B.txt); 1.13 accesses per CU and clock at 2.4 GHz
 L1_GATHER_ROOF_G_ACCESSES = 173.4 * 4
+# 64-byte records gathered at random from a 112 MB table (past the 4 MiB L2s, inside the Infinity Cache), same file
+L2_MISS_ROOF_G_RECORDS = 58.08
+INFINITY_CACHE_BYTES = 256 * 2 ** 20
+
+
+def launch_mode(gpus, single_process, env):
+    """How `--gpus N` is driven, decided from the arguments and the environment alone (before any GPU call; nothing is re-executed):
+    -> ("ranks", world) one process per GPU under torch.distributed.run (the driver's contract for N > 1), ("in-process", 1) all N
+    GPUs from this one process through pbrt_hip_multi_* (RCCL inside the library) -- also what a bare `python bench.py --gpus N`
+    gets --, ("single", 1) one GPU; or raises SystemExit for a contradictory launch."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    if gpus < 1:
+        raise SystemExit(f"--gpus {gpus}")
+    if single_process and gpus > 1:
+        return "in-process", 1
+    if world == gpus:
+        return ("ranks", world) if ("RANK" in env or world > 1) else ("single", 1)
+    if world == 1 and "RANK" not in env and gpus > 1:
+        return "in-process", 1  # a bare `python bench.py --gpus N`: no launcher, so the library drives the N GPUs itself
+    raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}")
 
 WORKLOADS = {
     # name: (scene factory args, integrator, maxdepth, (spp_x, spp_y), description)
@@ -136,8 +173,9 @@ def cpu_baseline(kind, n, res, integrator, depth, spp, target_s=15.0, gpu_film=N
 
 class ClockSampler:
     """The shader clock the GPU holds while the timed region runs, sampled from a host thread: the `*` line of the device's
-    /sys/class/drm/card*/device/pp_dpm_sclk (found through its PCI address; no process is started), else `rocm-smi --showclocks
-    --json` (80 ms per sample; never under rocprofv3, whose preloaded library makes every child's exec an exec after GPU start-up).
+    /sys/class/drm/card*/device/pp_dpm_sclk (found through its PCI address).  Reading sysfs starts no process and costs
+    microseconds; where it cannot be read the clock is simply not reported (an earlier version fell back to spawning
+    `rocm-smi` every 0.25 s INSIDE the timed region: 80 ms per sample, and a child exec'd from a GPU-initialised process).
     roofline.frac prices the kernel against the NOMINAL 2.4 GHz, so the same kernel reads 0.84 on a box that holds 2.32 GHz and 0.86
     on one that holds 2.38; frac_at_measured_clock takes the droop out."""
 
@@ -152,33 +190,22 @@ class ClockSampler:
             for dev in glob.glob("/sys/class/drm/card*/device"):
                 if os.path.basename(os.path.realpath(dev)) == addr and os.access(os.path.join(dev, "pp_dpm_sclk"), os.R_OK):
                     self.sysfs = os.path.join(dev, "pp_dpm_sclk")
-        except Exception:  # no such attributes, no sysfs: fall back to rocm-smi
+        except Exception:  # no such attributes, no sysfs: no clock in the line
             pass
-        self.use_smi = self.sysfs is None and not any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY"))
-        self.source = (f"{self.sysfs} (the level marked *)" if self.sysfs else "rocm-smi --showclocks (sclk)") + ", sampled from a host thread during the timed steps"
+        self.source = f"{self.sysfs} (the level marked *), sampled from a host thread during the timed steps" if self.sysfs else None
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _sample(self):
         import re
+        if not self.sysfs:
+            return None
         try:
-            if self.sysfs:
-                for line in open(self.sysfs):
-                    if "*" in line:
-                        m = re.search(r"(\d+)\s*Mhz", line, re.I)
-                        return int(m.group(1)) if m else None
-                return None
-            if not self.use_smi:
-                return None
-            import subprocess
-            txt = subprocess.run(["rocm-smi", "-d", str(self.device_index), "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
-            for line in txt.splitlines():
-                if line.startswith("{"):
-                    for card in json.loads(line).values():
-                        m = re.search(r"(\d+)\s*Mhz", str(card.get("sclk clock speed:", "")), re.I)
-                        if m:
-                            return int(m.group(1))
-        except Exception:  # no rocm-smi, no permission, unparsable output: the clock is simply not reported
+            for line in open(self.sysfs):
+                if "*" in line:
+                    m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                    return int(m.group(1)) if m else None
+        except OSError:
             pass
         return None
 
@@ -190,11 +217,13 @@ class ClockSampler:
             self._stop.wait(self.period_s)
 
     def start(self):
-        self._thread.start()
+        if self.sysfs:
+            self._thread.start()
 
     def stop(self):
         self._stop.set()
-        self._thread.join(timeout=10)
+        if self.sysfs:
+            self._thread.join(timeout=10)
         busy = sorted(v for v in self.mhz if v >= 1000)  # (samples between launches can catch a sleeping clock)
         if not busy:
             return None
@@ -224,20 +253,17 @@ def main():
     ap.add_argument("--profiles", default=os.path.join(ROOT, "profiles"), help="directory of pmc_<workload>.json (tests point it at a copy)")
     args = ap.parse_args()
 
+    mode, world = launch_mode(args.gpus, args.single_process, os.environ)  # (before torch / HIP are even imported)
+    in_process = mode == "in-process"
+
     import torch
     import torch.distributed as dist
 
     import pbrt_amd
     from pbrt_amd import dist as pdist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    in_process = args.single_process and args.gpus > 1
-    if world != args.gpus and not in_process:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...  (or --single-process)")
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank = int(os.environ.get("RANK", "0")) if mode == "ranks" else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if mode == "ranks" else 0
     if not torch.cuda.is_available() or pbrt_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: pbrt_amd has no CPU fallback")
     # one rank per GPU; PBRT_DIST_BACKEND=gloo lets several ranks share one GPU (test boxes with a single device)
@@ -248,7 +274,7 @@ def main():
     torch.cuda.set_device(device_index)
     # under torch.distributed.run the process group is ALWAYS initialised, also for one rank: the RCCL path
     # (init with device_id, barrier, all_reduce, gather) then runs on single-GPU boxes as well
-    use_pg = "RANK" in os.environ and not in_process
+    use_pg = mode == "ranks"
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -263,6 +289,8 @@ def main():
     t0 = time.time()
     sd = make_scene_data(kind, n, res)
     if in_process:
+        if pbrt_amd.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but {pbrt_amd.device_count()} HIP device(s) visible")
         scene = pbrt_amd.MultiScene(sd, args.gpus, builder=args.builder)
         args.no_counters = True
         info = {"n_nodes": None, "depth": None, "device_bytes": None}
@@ -377,12 +405,15 @@ def main():
         wst = scene.render_wait()
         # (64-byte quad nodes, 64-byte triangle records: 16 x kTriStride since r02j)
         kbytes = (64.0 * wst["nodes_visited"] + 64.0 * wst["tris_tested"] + 112.0 * rays) / wst["samples"] + 28.0 + 128.0 / (spp[0] * spp[1])
+        # the hot loop's working set: the production walk's quad nodes + the triangle records (64 B each).  device_bytes also counts
+        # the uploaded vertex / index buffers and, after the counting pass above, the canonical arrays -- none of which a timed step reads
+        hot_bytes = 64 * (info["quad_nodes"] + int(sd.idx.shape[0]))
         roof["hbm"] = {
             "note": "SURVEY 8(d) contract figure: algorithmic bytes of the CANONICAL binary-BVH walk (exact counters, equal to the "
                     "oracle's) / HIP-event kernel time, against the 8 TB/s HBM spec.  It is not a roof of this workload when "
-                    f"cache_resident: the scene ({info['device_bytes'] / 1e6:.0f} MB) then sits in the 256 MiB Infinity Cache and the "
-                    "production kernel walks a quantised 4-wide form of the tree that moves fewer bytes (kernel_*)",
-            "cache_resident": bool(info["device_bytes"] < 256 * 2 ** 20),
+                    f"cache_resident: the hot working set ({hot_bytes / 1e6:.0f} MB of quad nodes + triangle records) then sits in the 256 MiB "
+                    "Infinity Cache and the production kernel walks a quantised 4-wide form of the tree that moves fewer bytes (kernel_*)",
+            "cache_resident": bool(hot_bytes < INFINITY_CACHE_BYTES), "hot_working_set_bytes": hot_bytes,
             "achieved_gbps": ach, "peak_gbps": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS, "bytes_per_sample": bps,
             "algorithmic_bytes_per_launch": alg_bytes, "nodes_per_ray": cst["nodes_visited"] / rays, "tris_per_ray": cst["tris_tested"] / rays,
             "kernel_bytes_per_sample": kbytes, "kernel_fetches_per_ray": wst["nodes_visited"] / rays,
@@ -399,6 +430,19 @@ def main():
             roof["frac"] = roof["achieved"] / peak
             if clock:  # the same against the clock this box held during the timed steps
                 roof["frac_at_measured_clock"] = roof["achieved"] / (n_simd * clock["ghz_median"] / 4.0)
+            # frac is a BUSY fraction of the issue port; the lanes that were active when it issued make it useful work
+            if pmc.get("lane_utilisation") is not None:
+                roof["lane_utilisation"] = pmc["lane_utilisation"]
+                roof["frac_useful"] = roof["frac"] * pmc["lane_utilisation"]
+            if pmc.get("l2_hit_rate") is not None:
+                # the third roof the kernel sits under: 64-byte records (quad nodes, triangle records) that miss the XCD's L2
+                recs = (wst["nodes_visited"] + wst["tris_tested"]) / rays * rays_per_s / 1e9
+                roof["l2_miss"] = {"requests_per_s_G": recs * (1.0 - pmc["l2_hit_rate"]), "records_per_s_G": recs, "l2_hit_rate": pmc["l2_hit_rate"],
+                                   "peak_G": L2_MISS_ROOF_G_RECORDS, "frac": recs * (1.0 - pmc["l2_hit_rate"]) / L2_MISS_ROOF_G_RECORDS,
+                                   "peak_source": "tools/ubench/gather_wide.hip, 112 MB table (past L2, inside the Infinity Cache), 64-byte records: "
+                                                  "58.08 G records/s (profiles/r03end_gather_wide_48B.txt)"}
+                if pmc.get("FETCH_SIZE_KB_per_launch") and pmc.get("avg_ms"):
+                    roof["l2_miss"]["fetch_size_64B_requests_per_s_G"] = pmc["FETCH_SIZE_KB_per_launch"] * 1024 / 64 / (pmc["avg_ms"] * 1e-3) / 1e9
             m = pmc.get("valu_issue_busy_measured")
             roof["valu"] = {k: pmc.get(k) for k in ("valu_issue_busy_measured", "valu_issue_quadcycles_per_ray", "valu_dual_issue_share_of_instructions",
                                                     "valu_instructions_per_ray", "lane_utilisation", "l2_hit_rate", "wave_wait_frac", "wave_issue_wait_frac", "wave_issuing_frac",

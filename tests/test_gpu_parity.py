@@ -508,9 +508,10 @@ def test_c0_as_baseline_states_it(gpu, oracle):
     import os
     from pbrt_amd import loader
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "c0_check_sphere.pbrt")).read()
-    text = text.replace("[400]", "[256]").replace('"integer pixelsamples" 128', '"integer pixelsamples" 4')
-    for sampler in ("stratified", "halton"):
-        ls = loader.load_string(text.replace('Sampler "halton"', f'Sampler "{sampler}"'))
+    text = text.replace("[400]", "[256]")
+    assert 'Sampler "halton" "integer pixelsamples" 128' in text
+    for sampler, line in (("stratified", 'Sampler "stratified" "integer xsamples" 2 "integer ysamples" 2'), ("halton", 'Sampler "halton" "integer pixelsamples" 4')):
+        ls = loader.load_string(text.replace('Sampler "halton" "integer pixelsamples" 128', line))
         assert (ls.scene.xres, ls.scene.yres) == (256, 256) and ls.spp == (2, 2) and ls.integrator == INTEGRATOR_PATH
         assert (ls.sampler == 0) == (sampler == "stratified")
         ref, _ = oracle.OracleScene(ls.scene).render(seed=0, **ls.render_kwargs())

@@ -35,6 +35,29 @@ def test_build_id_is_the_hash_of_the_sources():
     assert build.source_id(["-DX"]) != build.source_id([])  # the flags are part of the identity
 
 
+def test_bench_gpus_n_picks_a_launch_path_however_it_is_started():
+    """`python bench.py --gpus N` must produce a line however it is launched: under torch.distributed.run one
+    rank per GPU; bare, with no WORLD_SIZE, all N GPUs from the one process through pbrt_hip_multi_* (RCCL inside the library).  The
+    choice is a pure function of argv and the environment, taken before torch or HIP are imported -- nothing is re-executed."""
+    import subprocess
+    import sys
+    import bench
+    assert bench.launch_mode(1, False, {}) == ("single", 1)
+    assert bench.launch_mode(1, False, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}) == ("ranks", 1)  # torchrun with one rank: RCCL group of one
+    for n in (2, 4, 8):
+        assert bench.launch_mode(n, False, {}) == ("in-process", 1)                       # bare: the in-library path
+        assert bench.launch_mode(n, True, {}) == ("in-process", 1)                        # --single-process
+        assert bench.launch_mode(n, False, {"WORLD_SIZE": str(n), "RANK": "1"}) == ("ranks", n)  # the driver's launch
+        assert bench.launch_mode(n, True, {"WORLD_SIZE": str(n), "RANK": "1"}) == ("in-process", 1)
+    for env in ({"WORLD_SIZE": "4", "RANK": "0"}, {"WORLD_SIZE": "1", "RANK": "0"}):  # a launcher that disagrees with --gpus
+        with pytest.raises(SystemExit):
+            bench.launch_mode(8, False, env)
+    if pbrt_amd.device_count() == 0:  # here: the bare N > 1 command gets as far as "no device", not "use another launcher"
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "needs a HIP device" in r.stderr and "torch.distributed.run" not in r.stderr
+
+
 def test_library_holds_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"render_kernel" in blob
