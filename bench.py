@@ -369,11 +369,20 @@ def main():
     roof["kernel_ms"] = avg_kernel_ms
     pmc_path = os.path.join(args.profiles, f"pmc_{args.workload}.json")
     pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
-    # A profile prices the library it was taken on and no other: the committed counters carry the build id (hash of the
-    # sources and kernel flags, pbrt_hip_build_id) of that library; with a different one loaded every figure that rests on
-    # them is withheld ("frac is silently stale").
+    # A profile prices the KERNEL it was taken on and no other: the committed counters carry the id of that kernel's machine code
+    # (pbrt_amd/isa_id.py: a hash of the production instantiation's .text bytes and kernel descriptor in the gfx950 code object);
+    # when the loaded library's kernel of that name hashes differently -- a changed source line, flag or compiler that reaches
+    # its ISA -- every figure that rests on the counters is withheld ("frac is silently stale").  Edits that do not
+    # reach that kernel (the parser, another instantiation, the builder's host code) leave the profile valid (VERDICT r04 item 7;
+    # the tree the rays walk is checked separately, by builder).  A profile without an ISA id falls back to the source hash.
     lib_id = pbrt_amd.build_id()
-    pmc_stale = pmc is not None and pmc.get("build_id") != lib_id
+    from pbrt_amd import isa_id
+    from pbrt_amd._lib import LIB_PATH
+    kernel_id_loaded = isa_id.kernel_id(LIB_PATH, pmc["kernel"]) if pmc is not None and pmc.get("kernel") else None
+    if pmc is not None and pmc.get("kernel_isa_id"):
+        pmc_stale = pmc["kernel_isa_id"] != kernel_id_loaded
+    else:
+        pmc_stale = pmc is not None and pmc.get("build_id") != lib_id
     if pmc is not None and not pmc_stale and pmc.get("builder", "gpu") != args.builder:
         # the committed per-ray counters (L1 accesses, issue quad-cycles) are those of ONE tree's walk; another builder's rays do a
         # different amount of both, so pricing them with these counters would misstate every fraction: withheld
@@ -381,9 +390,12 @@ def main():
                                 f"are withheld for --builder {args.builder} (a different tree: different work per ray)")
         pmc = None
     if pmc_stale:
-        roof["stale_profile"] = (f"{os.path.relpath(pmc_path, ROOT)} was taken on library build {pmc.get('build_id', '(none recorded)')}, "
-                                 f"this is {lib_id}: roofline.frac / valu / traffic withheld -- rerun tools/measure_round.sh")
+        roof["stale_profile"] = (f"{os.path.relpath(pmc_path, ROOT)} was taken on kernel {pmc.get('kernel_isa_id') or 'of library build ' + str(pmc.get('build_id', '(none recorded)'))} "
+                                 f"({isa_id.normalise(pmc.get('kernel', '?'))}), the loaded library's is {kernel_id_loaded or lib_id}: "
+                                 "roofline.frac / valu / traffic withheld -- rerun tools/measure_round.sh")
         pmc = None
+    elif pmc is not None:
+        roof["profile_kernel"] = {"name": isa_id.normalise(pmc.get("kernel", "?")), "isa_id": kernel_id_loaded, "round": pmc.get("round")}
     if not args.no_counters:
         # untimed counting pass: exact nodes-visited / triangles-tested of THIS rank's share (the counting instantiation
         # of the same kernel; equal to the oracle's counters, tests/test_gpu_parity.py) and the rays of the launch

@@ -9,6 +9,9 @@
  * plus the geometry the reference never stores (api.rs:220-223 TODO).  INTEGRATION.md shows the
  * `extern "C"` block and the `world_end` body a maintainer of the Rust crate would add.
  *
+ * This header is what a host binds.  The hooks of tests and measurements (tree exports, walk / stack-plan introspection, the
+ * host-only builders, the tokenizer alone, parser state) live in pbrt_hip_debug.h: same library, not part of the stable ABI.
+ *
  * Conventions
  *  - plain pointers and sizes only; the caller owns every HOST pointer it passes, the library
  *    copies what it needs during the call and keeps nothing;
@@ -164,49 +167,11 @@ int pbrt_hip_scene_build_info(const pbrt_hip_scene *scene, uint32_t *gpu_built, 
 /* the device build's tree optimisation (parallel re-insertion, pbrt_amd/csrc/reinsert_core.hpp): passes run, nodes moved, and
  * its share of build_ms; zeros for a host-built scene or PBRT_HIP_SCENE_PLAIN_TREE.  Any pointer may be NULL. */
 int pbrt_hip_scene_optimize_info(const pbrt_hip_scene *scene, uint32_t *passes, uint32_t *moves, double *ms);
-/* the canonical tree behind the counter flags: *ready = it exists (always for a host-built scene; for a device-built one
- * after the first call that counted), *build_ms = the host builder's time for it */
-int pbrt_hip_scene_canonical_info(const pbrt_hip_scene *scene, uint32_t *ready, double *build_ms);
-/* the production walk's tree as it sits in HBM: quads = 16 words per node (cap_nodes of them), order = leaf slot ->
- * triangle id (n_tris words); either may be NULL */
-int pbrt_hip_scene_export_quads(const pbrt_hip_scene *scene, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads,
-                                uint32_t *order);
 void pbrt_hip_scene_destroy(pbrt_hip_scene *scene);
-/* BVH introspection (host copies; order maps leaf slot -> triangle id) */
+/* scene introspection: nodes / depth of the canonical tree (0 for a device-built scene until a counter flag built it), lights
+ * (explicit + emissive triangles), bytes held in HBM */
 int pbrt_hip_scene_info(const pbrt_hip_scene *scene, uint32_t *n_nodes, uint32_t *depth, uint32_t *n_lights,
                         uint64_t *device_bytes);
-int pbrt_hip_scene_export_bvh(const pbrt_hip_scene *scene, uint32_t *nodes /* 8 words each */, uint32_t *order);
-/* the production walk's own structure: number of 64-byte quantised 4-wide nodes, and the most stack entries a
- * walk can hold (see pbrt_hip_render_stack_plan for where they live) */
-int pbrt_hip_scene_walk_info(const pbrt_hip_scene *scene, uint32_t *quad_nodes, uint32_t *stack_need);
-/* How the render kernel is launched for a tree with that stack bound (pure function, no device touched): LDS rows of
- * 64 x 4 bytes per wave, one-wave workgroups a CU holds at once with them (the grid is this x the CU count), and the
- * entries per lane kept in an HBM overflow area (non-zero = the overflow variant of the kernel). */
-int pbrt_hip_render_stack_plan(uint32_t stack_need, uint32_t *lds_rows, uint32_t *waves_per_cu, uint32_t *overflow_entries);
-/* host-only variant for CPU-side tests of the builder: no device is touched */
-int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
-                            uint32_t *nodes /* 8*(2*n_tris) words cap */, uint32_t *order, uint32_t *n_nodes,
-                            uint32_t *depth);
-
-/* host-only: the production walk's quantised 4-wide tree from a triangle soup, for CPU-side
- * tests of its invariants.  quads: 16 words per node (cap_nodes nodes of room); split_leaves as the library default. */
-int pbrt_hip_quad_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
-                             uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need);
-/* The same with the binary tree the 4-wide nodes are collapsed from chosen explicitly -- PBRT_HIP_TREE_SAH: the canonical
- * binned-SAH tree of DESIGN.md 3.3; PBRT_HIP_TREE_REINSERT: that tree with its leaves opened into single triangles and optimised
- * by the device builder's parallel re-insertion pass RUN ON THE HOST (the same functions, pbrt_amd/csrc/reinsert_core.hpp: what
- * lets the CPU tests walk the trees that pass makes; PBRT_HIP_SCENE_OPTIMIZED_TREE's tree) -- and more outputs, each of which may
- * be NULL: order = leaf slot -> triangle id (n_tris words; what a leaf child's slot refers to), root_box = lo xyz, hi xyz, n_refs
- * = references in the tree (n_tris), exact_boxes = the children's boxes before quantisation (24 floats per node of `quads`: lo
- * xyz, hi xyz of child 0..3; diagnostics).  (Round 3's PBRT_HIP_TREE_SBVH = 1, a spatial-split builder measured negative on
- * BASELINE's meshes, is no longer in the library: tools/experiments/r03_host_tree_builders/.) */
-#define PBRT_HIP_TREE_SAH 0u
-#define PBRT_HIP_TREE_REINSERT 2u
-#define PBRT_HIP_TREE_DEFAULT 0xffffffffu
-int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris, int split_leaves,
-                                uint32_t tree, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads, uint32_t *stack_need,
-                                uint32_t *order, float *root_box, uint32_t *n_refs, float *exact_boxes);
-
 /* ---- the hot path ---- */
 /* Render this rank's super-tiles and return the assembled film in HOST memory:
  * film_xyzw = (crop_w * crop_h * 4) floats, row-major over the cropped pixel bounds,
@@ -244,9 +209,6 @@ int64_t pbrt_hip_render_buffer_bytes(const pbrt_hip_scene *scene, const pbrt_hip
 int pbrt_hip_render_acc(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, int64_t *acc, pbrt_hip_stats *stats);
 int pbrt_hip_film_from_acc_device(const pbrt_hip_scene *scene, const void *d_acc, void *d_film_xyzw, void *stream);
 void pbrt_hip_film_from_acc(const int64_t *acc, int64_t n_pixels, float *film_xyzw);
-/* host only: the generator matrices sampler 2 uses -- 32 dimensions x 32 columns, rows 0 .. 31 of the reference's
- * SOBOL_MATRICES32 (sobolmatrices.rs:81) -- for tests of that claim */
-void pbrt_hip_sobol_matrices(uint32_t *out_1024_words);
 /* host-side geometry of the sharding (no device needed) */
 int64_t pbrt_hip_slab_floats(int32_t xres, int32_t yres, const float crop[4], uint32_t rank, uint32_t world_size);
 /* for every float4 slot of a rank's slab the row-major pixel index inside the cropped film, or -1 */
@@ -311,13 +273,6 @@ int pbrt_hip_loaded_get(const pbrt_hip_loaded *loaded, pbrt_hip_scene_desc *desc
 float pbrt_hip_loaded_film_scale(const pbrt_hip_loaded *loaded);
 /* warnings (ignored directives / parameters, api.rs:291-332 "log and continue"), '\n'-separated; returns their count */
 int pbrt_hip_loaded_warnings(const pbrt_hip_loaded *loaded, char *buf, size_t cap);
-/* CTM (current_transform[0].m) when parsing stopped, and the directive names stored by the option setters
- * (api.rs:778-820) as "camera sampler integrator filter accelerator film" */
-int pbrt_hip_loaded_state(const pbrt_hip_loaded *loaded, float ctm[16], char *names, size_t names_cap);
-/* the tokenizer alone (parser.rs:61-170): tokens '\n'-separated into buf; returns the token count, or
- * -(1 + count) when the stream ends in an error (EOF / newline inside a quoted string) after `count` tokens */
-int pbrt_hip_tokenize(const char *text, size_t len, char *buf, size_t cap);
-
 #ifdef __cplusplus
 }
 #endif

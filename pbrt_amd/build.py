@@ -43,13 +43,13 @@ def compiler_version():
 
 
 def source_id(extra_flags=()):
-    """Identity of what a build is made from: a hash of every source under csrc/, the public header, EVERY flag the kernels are
-    compiled with (the fixed list above and the extra ones) and the compiler's version -- anything that can change the ISA.  It is
-    compiled into the library (pbrt_hip_build_id()); profiles/pmc_<workload>.json records the id of the library its counters were
-    taken on, and bench.py refuses to price a DIFFERENT library with them."""
+    """Identity of what a build is made from: a hash of every source under csrc/, the public headers, EVERY flag the kernels are
+    compiled with (the fixed list above and the extra ones) and the compiler's version.  It is compiled into the library
+    (pbrt_hip_build_id()) and printed in every bench line.  (Until round 4 it also keyed the counter profiles; they are keyed by the
+    measured kernel's machine code now, pbrt_amd/isa_id.py: an edit that does not reach that kernel leaves a profile valid.)"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "pbrt_hip.h")]:
+    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "pbrt_hip.h"), os.path.join("..", "..", "include", "pbrt_hip_debug.h")]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     h.update(" ".join(COMMON_FLAGS + list(extra_flags)).encode())
@@ -62,6 +62,7 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     os.makedirs(LIB_DIR, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(HERE, "..", "include", "pbrt_hip.h"))
+    deps.append(os.path.join(HERE, "..", "include", "pbrt_hip_debug.h"))
     deps.append(os.path.abspath(__file__))
     if not force and _newer(LIB_PATH, deps):
         return LIB_PATH

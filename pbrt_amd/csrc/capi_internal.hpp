@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/pbrt_hip.h"
+#include "../../include/pbrt_hip_debug.h"
 #include "bvh_build.hpp"
 #include "device_types.h"
 

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/pbrt_hip.h"
+#include "../../include/pbrt_hip_debug.h"
 
 namespace pbrt_hip {
 

@@ -911,29 +911,44 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
 
 @pytest.mark.timeout(900)
 def test_bench_withholds_a_stale_profile(gpu, tmp_path):
-    """VERDICT r02 item 2b / ADVICE: a committed profile prices only the library it was taken on.  bench.py run against a
-    copy of profiles/pmc_c2.json whose build id is not the loaded library's must say so and withhold the figures that rest
-    on it; with the right id it must not complain."""
+    """a committed profile prices only the KERNEL it was taken on -- identified by a hash of its
+    machine code (pbrt_amd/isa_id.py).  bench.py run against a copy of profiles/pmc_c2.json whose kernel id is not that of the
+    loaded library's kernel must say so and withhold the figures that rest on it; with the right id it must not complain,
+    whatever the library's source hash is (an edit elsewhere in csrc/ does not invalidate it)."""
     import json
     import subprocess
     import sys
+    from pbrt_amd import isa_id
+    from pbrt_amd._lib import LIB_PATH
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pmc = {"build_id": "0123456789abcdef", "valu_issue_quadcycles_per_ray": 100.0, "valu_issue_busy_measured": 0.5, "traffic_bytes_raw": 1.0}
+    kernel = "void pbrt_hip::(anonymous namespace)::render_kernel<false, false, false, 30, 3, false, false>(pbrt_hip::DevScene, pbrt_hip::RenderParams)"
+    good = isa_id.kernel_id(LIB_PATH, kernel)
+    assert good, "the library has no such kernel"
+    pmc = {"kernel": kernel, "kernel_isa_id": "0123456789abcdef", "build_id": "some-other-source-hash", "valu_issue_quadcycles_per_ray": 100.0,
+           "valu_issue_busy_measured": 0.5, "traffic_bytes_raw": 1.0, "avg_ms": 1.0, "lane_utilisation": 0.5, "l2_hit_rate": 0.7}
     (tmp_path / "pmc_c2.json").write_text(json.dumps(pmc))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "c2", "--spp", "1", "1", "--no-cpu-baseline",
-           "--no-counters", "--profiles", str(tmp_path)]
+           "--profiles", str(tmp_path)]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert "0123456789abcdef" in line["roofline"]["stale_profile"] and pbrt_amd.build_id() in line["roofline"]["stale_profile"]
+    assert "0123456789abcdef" in line["roofline"]["stale_profile"] and good in line["roofline"]["stale_profile"]
     assert line["roofline"]["frac"] is None and line["roofline"]["traffic"] is None and "valu" not in line["roofline"]
     assert line["config"]["library_build_id"] == pbrt_amd.build_id()
-    pmc["build_id"] = pbrt_amd.build_id()
+    pmc["kernel_isa_id"] = good
     (tmp_path / "pmc_c2.json").write_text(json.dumps(pmc))
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert "stale_profile" not in line["roofline"]
+    roof = line["roofline"]
+    assert "stale_profile" not in roof and roof["profile_kernel"]["isa_id"] == good
+    # ... and the line is recomputable from (profile, rays_per_launch, kernel_ms) by the formulas of bench.py's docstring
+    rays_per_s = roof["rays_per_launch"] / (roof["kernel_ms"] * 1e-3)
+    assert abs(roof["achieved"] - 100.0 * rays_per_s / 1e9) < 1e-6 * roof["achieved"]
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and abs(roof["frac_useful"] - roof["frac"] * 0.5) < 1e-12
+    recs = (roof["hbm"]["kernel_fetches_per_ray"] + roof["hbm"]["kernel_tris_per_ray"]) * rays_per_s / 1e9
+    assert abs(roof["l2_miss"]["requests_per_s_G"] - recs * 0.3) < 1e-6 * recs and roof["l2_miss"]["peak_G"] == 58.08
+    assert roof["hbm"]["cache_resident"] is True and roof["hbm"]["hot_working_set_bytes"] < 20e6  # C2: 9 MB of quad nodes + triangle records
 
 
 @pytest.mark.timeout(900)

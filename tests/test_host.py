@@ -15,8 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
+    """Both headers: pbrt_hip.h (what a host binds) and pbrt_hip_debug.h (the hooks of tests and tools); no symbol in both, the
+    boundary's calls of SURVEY.md 8(b) in the first, and the ctypes binding covers exactly their union."""
     header = open(os.path.join(ROOT, "include", "pbrt_hip.h")).read()
-    declared = set(re.findall(r"\b(pbrt_hip_[a-z_0-9]+)\s*\(", header))
+    debug = open(os.path.join(ROOT, "include", "pbrt_hip_debug.h")).read()
+    stable = set(re.findall(r"\b(pbrt_hip_[a-z_0-9]+)\s*\(", header))
+    hooks = set(re.findall(r"\b(pbrt_hip_[a-z_0-9]+)\s*\(", debug))
+    assert not (stable & hooks), stable & hooks
+    assert {"pbrt_hip_device_count", "pbrt_hip_scene_create", "pbrt_hip_render", "pbrt_hip_scene_destroy", "pbrt_hip_last_error",
+            "pbrt_hip_render_multi", "pbrt_hip_multi_create", "pbrt_hip_load_file", "pbrt_hip_write_image"} <= stable
+    assert {"pbrt_hip_scene_export_quads", "pbrt_hip_scene_export_bvh", "pbrt_hip_scene_walk_info", "pbrt_hip_render_stack_plan", "pbrt_hip_bvh_build_host",
+            "pbrt_hip_quad_build_host", "pbrt_hip_quad_build_host_ex", "pbrt_hip_tokenize", "pbrt_hip_loaded_state", "pbrt_hip_sobol_matrices"} <= hooks
+    declared = stable | hooks
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     l = _lib.lib()
     for name in declared:
@@ -58,6 +68,21 @@ def test_bench_gpus_n_picks_a_launch_path_however_it_is_started():
         assert r.returncode != 0 and "needs a HIP device" in r.stderr and "torch.distributed.run" not in r.stderr
 
 
+def test_kernel_isa_ids():
+    """pbrt_amd/isa_id.py: a profile is keyed by the machine code of the kernel it measured.  Every production
+    instantiation of render_kernel has an id, different instantiations have different ones, the profiler's and the demangler's
+    spelling of a name find the same kernel, and a kernel the library does not have has none."""
+    from pbrt_amd import isa_id
+    ids = {isa_id.normalise(k): v for k, v in isa_id.kernel_ids(_lib.LIB_PATH).items()}
+    prod = {k: v for k, v in ids.items() if re.fullmatch(r"render_kernel<(true|false),false,false,\d+,\d+,(true|false),(true|false)>", k)}
+    assert len(prod) >= 8 and len(set(prod.values())) == len(prod), prod
+    assert all(re.fullmatch(r"[0-9a-f]{16}", v) for v in prod.values())
+    rocprof_name = "void pbrt_hip::(anonymous namespace)::render_kernel<false, false, false, 30, 3, false, false>(pbrt_hip::DevScene, pbrt_hip::RenderParams)"
+    assert isa_id.kernel_id(_lib.LIB_PATH, rocprof_name) == prod["render_kernel<false,false,false,30,3,false,false>"]
+    assert isa_id.kernel_id(_lib.LIB_PATH, "render_kernel<false, false, false, 31, 3, false, false>(x)") is None
+    assert any(k.startswith("intersect_kernel<") for k in ids) and "merge_kernel" in " ".join(ids)
+
+
 def test_library_holds_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"render_kernel" in blob
@@ -67,7 +92,7 @@ def test_struct_layouts_match_header(tmp_path):
     """include/pbrt_hip.h compiles as plain C, and the ctypes mirrors have the C sizes."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "pbrt_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "pbrt_hip.h"\n#include "pbrt_hip_debug.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(pbrt_hip_material),sizeof(pbrt_hip_light),sizeof(pbrt_hip_sphere),sizeof(pbrt_hip_scene_desc),"
                    "sizeof(pbrt_hip_render_desc),sizeof(pbrt_hip_stats));return 0;}\n")
     exe = tmp_path / "sz"

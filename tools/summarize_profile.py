@@ -81,6 +81,16 @@ def main():
                 break
             except (OSError, ValueError, KeyError):
                 continue
+        # ... and, what the validity of the profile is decided by: the machine code of the kernel the counters belong to
+        # (pbrt_amd/isa_id.py; computed from the library beside this script -- on the GPU box the one that was measured)
+        try:
+            sys.path.insert(0, ROOT)
+            from pbrt_amd import build, isa_id
+            if summary.get("kernel"):
+                summary["kernel_isa_id"] = isa_id.kernel_id(build.LIB_PATH, summary["kernel"])
+                summary["compiler"] = build.compiler_version().splitlines()[0]
+        except Exception as e:  # noqa: BLE001
+            summary["kernel_isa_id_error"] = repr(e)[:200]
         with open(os.path.join(P, f"{tag}_{wl}_summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         shutil.copy(os.path.join(P, f"{tag}_{wl}_summary.json"), os.path.join(P, f"pmc_{wl}.json"))
