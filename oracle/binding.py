@@ -210,6 +210,12 @@ def to_byte(v):
     return lib().orc_to_byte(v)
 
 
+def quad_walk_count_visits(per_node):
+    """per_node: a uint64 array with one word per quad node that the following quad_walk calls add their node steps to, or None"""
+    lib().orc_quad_walk_count_visits.argtypes = [C.c_void_p]
+    lib().orc_quad_walk_count_visits(_p(per_node) if per_node is not None else None)
+
+
 def quad_walk(quads, root_box, P, idx, order, o, d, tmax, any_hit=False, root_ref=None, n_threads=None, exact_boxes=None):
     """The production walk of the render kernel restated on the CPU (oracle/quad_walk.cpp) over a 4-wide tree a product
     builder emitted: dict(t, prim, b1, b2, occluded, steps, tris, max_stack).  root_ref: None = quad 0 (or no tree when

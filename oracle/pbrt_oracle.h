@@ -146,6 +146,8 @@ void orc_quad_walk(const uint32_t *quads, uint32_t n_quads, uint32_t root_ref, c
                    const uint32_t *idx, const uint32_t *order, int64_t n, const float *o, const float *d, const float *tmax,
                    int any_hit, float *t, uint32_t *prim, float *b1, float *b2, uint8_t *occluded, uint32_t *steps,
                    uint32_t *tris, uint32_t *max_stack, int n_threads, const float *exact_boxes /* diagnostics: NULL */);
+/* measurement aid: the walks that follow add their node steps to per_node[node] (n_quads words; NULL stops counting) */
+void orc_quad_walk_count_visits(uint64_t *per_node);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,9 @@ bool box_test(const float *b, V3 o, V3 inv, float tfar) {
   return tn <= tf * kBoxPad;
 }
 
+// measurement aid (tools/treetop_sim.py): when set, every node step adds one to its node's counter
+uint64_t *g_visits = nullptr;
+
 void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
   Out r;
   uint32_t cur = kDone;
@@ -103,6 +106,7 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
     if (!(cur & kLeafRef)) {
       const uint32_t *W = T.quads + (size_t)(cur / 64u) * 16u;
       r.steps++;
+      if (g_visits) __atomic_fetch_add(&g_visits[cur / 64u], 1ull, __ATOMIC_RELAXED);
       const float tfar = fminn(r.t, tmax);
       const float gx = (o.x - as_f(W[0])) * inv.x, gy = (o.y - as_f(W[1])) * inv.y, gz = (o.z - as_f(W[2])) * inv.z;
       constexpr float kMargin = 0x1.8p-22f;
@@ -221,6 +225,9 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
 }
 
 }  // namespace
+
+// per-node visit counters of the walks that follow (n_quads uint64 words, or null to stop counting)
+extern "C" void orc_quad_walk_count_visits(uint64_t *per_node) { g_visits = per_node; }
 
 extern "C" void orc_quad_walk(const uint32_t *quads, uint32_t n_quads, uint32_t root_ref, const float root_box[6], const float *P,
                               const uint32_t *idx, const uint32_t *order, int64_t n, const float *o, const float *d,

@@ -174,6 +174,8 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_addr(const uint32_t *p) { return (uint32_t)(uintptr_t)(const lds_u32 *)p; }
 __device__ __forceinline__ void lds_store(uint32_t a, uint32_t v) { *(lds_u32 *)(uintptr_t)a = v; }
 __device__ __forceinline__ uint32_t lds_load(uint32_t a) { return *(const lds_u32 *)(uintptr_t)a; }
+typedef __attribute__((address_space(3))) uint4 lds_u128;
+__device__ __forceinline__ uint4 lds_load128(uint32_t a) { return *(const lds_u128 *)(uintptr_t)a; }  // ds_read_b128 (a: 16-byte aligned)
 constexpr uint32_t kRowBytes = 256u;  // one stack row = 64 lanes x 4 bytes: consecutive entries of a lane are one row apart
 // row of the entry at LDS address `a` of the stack whose lane column starts at `stk`: measured from the ARRAY's base, a
 // link-time constant, so that no per-lane limit has to be kept in a register (the lane's 4-byte column offset is below a row)
@@ -196,6 +198,7 @@ struct Trav {
 struct TravTuning {
   uint32_t min_walkers;  // leave the loop when fewer lanes are walking and some lane waits for service
   uint32_t min_parked;   // test triangles once this many lanes are parked at a leaf
+  uint32_t top_bytes;    // TOP instantiations: quad nodes whose byte offset is below this are read from the workgroup's LDS copy
 };
 
 // s_setprio (A-B: -DPBRT_NO_PRIO compiles the priorities out; the levels can be overridden)
@@ -329,7 +332,10 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
 //     lanes keep their state and resume on the next call.
 // `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
 // caller once its walk is over.
-template <bool EXACT, bool COUNT, uint32_t OVFR, int STEPS = PBRT_STEPS_PER_CHECK>
+// TOP (production walk only): the first top_bytes / 64 quad nodes -- the top of the tree in the device builder's level-order
+// numbering -- sit in a copy at the start of the workgroup's LDS (render_kernel fills it); a step whose node is among them reads
+// it with four ds_read_b128 instead of four global_load_dwordx4 through the vector L1.
+template <bool EXACT, bool COUNT, uint32_t OVFR, int STEPS = PBRT_STEPS_PER_CHECK, bool TOP = false>
 __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf,
                                          const bool alive, const TravTuning tune, unsigned long long &cn,
                                          unsigned long long &ct) {
@@ -397,10 +403,18 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // its next node gets its loads out before the other waves' decode and slab tests.  With the same around the leaf
       // pass's triangle fetch and 1 for the service stage: C3 +3.5 %, C2 +0.7 % (tools/experiments/README.md).
       wave_prio(PBRT_PRIO_FETCH);
-      const uint4 W0 = *reinterpret_cast<const uint4 *>(quads + off);
-      const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
-      const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
-      const uint4 W3 = *reinterpret_cast<const uint4 *>(quads + off + 48u);
+      uint4 W0, W1, W2, W3;
+      if (TOP && off < tune.top_bytes) {  // (the treetop image starts at LDS address 0: the node's offset is its LDS address)
+        W0 = lds_load128(off);
+        W1 = lds_load128(off + 16u);
+        W2 = lds_load128(off + 32u);
+        W3 = lds_load128(off + 48u);
+      } else {
+        W0 = *reinterpret_cast<const uint4 *>(quads + off);
+        W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
+        W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
+        W3 = *reinterpret_cast<const uint4 *>(quads + off + 48u);
+      }
       EXP_STEP_EXTRA_LOADS(quads, off, T);
       wave_prio(PBRT_PRIO_ARITH);
       if (COUNT) cn++;  // one 64-byte fetch
@@ -809,17 +823,27 @@ __device__ __forceinline__ void film_add(unsigned long long *acc, const DevScene
     }
 }
 
-template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK, bool WIDE = false, bool SND = false>
+// TOP: the treetop variant of the production walk -- workgroups of several waves (blockDim.x / 64, ten by default) that share ONE
+// LDS copy of the tree's first R.top_bytes / 64 quad nodes, followed by the waves' stacks of STACK rows each.  The waves of a
+// workgroup synchronise once, after filling the copy, and are independent persistent waves from then on (the "workgroup" number
+// of the path records, the overflow area and the hand-out is the GLOBAL WAVE number).
+template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PER_CHECK, bool WIDE = false, bool SND = false, bool TOP = false>
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
-__global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
+__global__ void __launch_bounds__(TOP ? 1024 : 64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
   // the walk's stack, rows of 64 lanes x 4 bytes as dynamic shared memory: the launch sizes it per scene (render_stack_plan;
   // exact walk: STACK rows of refs followed by STACK rows of entry distances)
   extern __shared__ uint32_t lds_stack[];
-  const uint32_t lane = threadIdx.x;
-  uint32_t *stk = lds_stack + lane;
+  const uint32_t lane = TOP ? (threadIdx.x & 63u) : threadIdx.x;
+  // this wave's number among all waves of the launch (one-wave workgroups: the workgroup's)
+  const uint32_t gw = TOP ? blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : blockIdx.x;
+  if (TOP) {  // the workgroup's copy of the treetop, 16 bytes per thread and round (LDS address 0 onwards)
+    for (uint32_t i = threadIdx.x; i < R.top_bytes / 16u; i += blockDim.x) reinterpret_cast<uint4 *>(lds_stack)[i] = S.quads[i];
+    __syncthreads();
+  }
+  uint32_t *stk = lds_stack + (TOP ? R.top_bytes / 4u + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (uint32_t)(STACK * 64) : 0u) + lane;
   float *stkt = reinterpret_cast<float *>(lds_stack + (EXACT ? STACK : 0) * 64) + lane;  // entry distances: exact walk only
-  uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u;  // wave-uniform (SGPRs); the lane is added at use
+  uint32_t *ovf = R.stack_overflow + (size_t)gw * R.stack_overflow_entries * 64u;  // wave-uniform (SGPRs); the lane is added at use
 
   // Work is handed out dynamically (see the fetch step of the service stage) in ITEMS: item number `item` of this rank
   // is chunk ((item >> 6) & (K - 1)) of pixel (item & 63) of 8x8 block (item >> (6 + log2 K)) -- the 64 K items of a block are its 64
@@ -850,9 +874,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
   const uint32_t nL = S.n_lights;
   const float nLf = S.n_lights_f;  // (float)nL, converted on the host: a kernel argument stays in an SGPR
   const bool direct_only = R.integrator == 1u;
-  const TravTuning tune = {R.min_walkers, R.min_parked};
+  const TravTuning tune = {R.min_walkers, R.min_parked, TOP ? R.top_bytes : 0u};
 
-  const LaneRecords rec = {reinterpret_cast<char *>(R.lane_state + (size_t)blockIdx.x * 320u + 128u), lane * 16u};
+  const LaneRecords rec = {reinterpret_cast<char *>(R.lane_state + (size_t)gw * 320u + 128u), lane * 16u};
   uint32_t state = ST_FETCH;
   if (WIDE) wide_slots_clear(R.wide_slots, lane);  // the lane's footprint slots start empty, and every flush leaves them so
   uint32_t region = blockIdx.x % R.n_regions;  // the part of the pixel list this wave draws from
@@ -1197,7 +1221,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
     PROBE_SEC(8);
     if (__ballot(state != ST_DONE) == 0ull) break;
     wave_prio(PBRT_PRIO_ARITH);  // traversal arithmetic at priority 0, its fetches at 3 (trav_run)
-    trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? (uint32_t)STACK : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
+    trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? (uint32_t)STACK : 0u), STEPS, TOP>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
     wave_prio(PBRT_PRIO_SERVICE);  // the service stage of the next round: its lanes are not tracing while it lasts
     PROBE_SEC(0);
   }
@@ -1226,7 +1250,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
   uint32_t *stk = &lds_stack[wave][0][lane];
   float *stkt = &lds_tn[COUNT ? wave : 0][0][lane];
   uint32_t *ovf = B.stack_overflow + ((size_t)blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * B.stack_overflow_entries * 64u;  // wave-uniform
-  const TravTuning tune = {B.min_walkers, B.min_parked};
+  const TravTuning tune = {B.min_walkers, B.min_parked, 0u};
   unsigned long long cn = 0, ct = 0;
   EXP_PROBE_INIT_BLOCK();
   const int64_t stride = (int64_t)gridDim.x * 256;
