@@ -91,6 +91,7 @@ def kernel_ids(lib_path, arch="gfx950"):
             daddr, doff, _ = secs[dx]
             desc = bytearray(elf[doff + dv - daddr:doff + dv - daddr + ds])
             desc[16:24] = b"\0" * 8  # KERNEL_CODE_ENTRY_BYTE_OFFSET: where the code sits relative to the descriptor, not what it is
+            desc[8:12] = b"\0" * 4   # KERNARG_SIZE: an argument appended for ANOTHER kernel's use grows it and changes nothing this one runs
             h.update(bytes(desc))
             found[n] = h.hexdigest()[:16]
     names = sorted(found)
