@@ -1047,7 +1047,6 @@ namespace {
 struct RenderScratch {
   uint32_t n_workgroups = 0, chunk_shift = 0;
   RenderStackPlan plan{};
-  RenderTopPlan top{0u, 0u, 0u};  // treetop variant of the kernel (nodes == 0: not used)
 };
 int ensure_render_scratch(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, const FilmGeom &fg, const Shard &sh, RenderScratch *out) {
   const uint32_t spp = r->spp_x * r->spp_y;
@@ -1059,21 +1058,6 @@ int ensure_render_scratch(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, cons
   // (the instantiations for another filter radius and for the Sobol' sampler fit the 96 VGPRs of 5 waves per SIMD like the default one)
   const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, out->plan.waves_per_cu) : out->plan.waves_per_cu;
   out->n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
-  // The treetop variant (default filter, samplers 0 / 1, triangle scenes): measured and not adopted, so it runs
-  // only when asked for -- PBRT_HIP_TREETOP = nodes in LDS, PBRT_HIP_TREETOP_WAVES = waves per workgroup (10).  Its workgroups hold
-  // several waves: n_workgroups keeps counting WAVES (the scratch is per wave) and is rounded up to whole workgroups.
-  out->top = RenderTopPlan{0u, 0u, 0u};
-  if (!fg.wide && r->sampler != PBRT_HIP_SAMPLER_SOBOL_ND && s->dev.n_spheres == 0 && !(r->flags & PBRT_HIP_FLAG_COUNTERS)) {
-    const uint32_t n_quads = s->gpu_built ? s->n_quads_gpu : (uint32_t)(s->d_quads.n / 4);
-    out->top = render_top_plan(tuning("PBRT_HIP_TREETOP", 0u, 1 << 16), tuning("PBRT_HIP_TREETOP_WAVES", 10u, 16), n_quads);
-    if (out->top.nodes) {
-      out->n_workgroups = (out->n_workgroups + out->top.waves - 1u) / out->top.waves * out->top.waves;
-      const uint32_t need_rows = s->dev.quad_stack_need + 2u;
-      out->plan.rows = out->top.rows;
-      out->plan.overflow = true;
-      out->plan.extra_entries = need_rows > out->top.rows ? need_rows - out->top.rows : 1u;
-    }
-  }
   if (r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND && s->d_sobol.n == 0) {
     static_assert(kSobolNdDims == 2 * (int)kSobolNdRequests, "sampler 2: two dimensions per request");
     uint32_t mat[kSobolNdDims * 32];
@@ -1176,7 +1160,6 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.partials = fg.wide ? nullptr : s->d_partials.p;
     R.stack_overflow = s->d_stack_overflow.p;
     R.stack_overflow_entries = rs.plan.extra_entries;
-    R.top_bytes = rs.top.nodes * 64u; R.top_waves = rs.top.waves; R.top_rows = rs.top.rows;
     R.min_walkers = tuning("PBRT_HIP_MIN_WALKERS", s->dev.quad_stack_need <= kShallowStackNeed ? kMinWalkersShallow : kMinWalkers);
     R.min_parked = tuning("PBRT_HIP_MIN_PARKED", kMinParked);
     const int counters = (r->flags & PBRT_HIP_FLAG_COUNTERS) ? 1 : ((r->flags & PBRT_HIP_FLAG_WALK_COUNTERS) ? 2 : 0);

@@ -99,29 +99,6 @@ inline RenderStackPlan render_stack_plan(uint32_t quad_stack_need, bool force_ov
   p.extra_entries = p.overflow && need_rows > p.rows ? need_rows - p.rows : 0u;
   return p;
 }
-// The treetop variant of the render kernel (kernels.hip render_kernel<..., TOP>): workgroups of `waves` waves share one LDS copy of
-// the tree's first `nodes` quad nodes; every wave keeps `rows` stack rows in LDS behind it and deeper entries in the HBM overflow
-// area.  A CU holds kRenderMaxWavesPerCu waves: 20 / waves workgroups of nodes x 64 + waves x rows x 256 bytes each must fit its
-// 160 KB of LDS (in granules of 1280 bytes).  rows is one of the instantiated values.
-constexpr uint32_t kTopRowsChoices[3] = {28u, 24u, 18u};
-struct RenderTopPlan {
-  uint32_t nodes, waves, rows;  // nodes == 0: no treetop (the one-wave-workgroup kernel)
-  uint32_t lds_bytes() const { return nodes * 64u + waves * rows * 256u; }
-};
-inline RenderTopPlan render_top_plan(uint32_t want_nodes, uint32_t want_waves, uint32_t n_quads) {
-  RenderTopPlan p{0u, 0u, 0u};
-  if (want_nodes == 0u || n_quads == 0u) return p;
-  p.nodes = want_nodes < n_quads ? want_nodes : n_quads;
-  p.waves = want_waves < 1u ? 1u : (want_waves > 16u ? 16u : want_waves);
-  const uint32_t groups = (kRenderMaxWavesPerCu + p.waves - 1u) / p.waves;  // workgroups a CU must hold for 20 waves
-  const uint32_t budget = kLdsBytesPerCu / groups / kLdsGranule * kLdsGranule;
-  p.rows = 0u;
-  for (uint32_t r : kTopRowsChoices)
-    if (p.rows == 0u && p.nodes * 64u + p.waves * r * 256u <= budget) p.rows = r;
-  if (p.rows == 0u) return RenderTopPlan{0u, 0u, 0u};  // does not fit: no treetop
-  return p;
-}
-
 inline bool render_prefer_lds() {  // A-B runs: the whole stack in LDS whenever it fits kQuadLdsStack rows, whatever the occupancy
   static const bool f = debug_knob("PBRT_HIP_PREFER_LDS_STACK") != nullptr;
   return f;
@@ -189,9 +166,6 @@ struct RenderParams {
   unsigned long long *acc;
   // sampler 2 (render_kernel<..., SND>): generator matrices of the first ten Sobol' dimensions, 32 columns each
   const uint32_t *sobol_mat;
-  // treetop variant (render_kernel<..., TOP>): bytes of the tree's first quad nodes every workgroup copies into its LDS (a multiple
-  // of 64; 0 = the one-wave-workgroup kernel), waves per workgroup and LDS stack rows per wave of that launch
-  uint32_t top_bytes, top_waves, top_rows;
 };
 // 2^24 fixed-point units per unit of radiance, a component clamped to [0, 2^15]
 constexpr float kFixedOne = 16777216.0f, kFixedMax = 32768.0f;

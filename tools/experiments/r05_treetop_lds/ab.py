@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 os.environ["PBRT_HIP_DEBUG_KNOBS"] = "1"
 import pbrt_amd  # noqa: E402
 from pbrt_amd import scenes  # noqa: E402
@@ -21,7 +21,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 spp = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (8, 8)
 n, res = {"c3": (1_000_000, 2048), "c2": (100_000, 1024)}[wl]
 sd = scenes.random_mesh_scene(n, res, res)
-variants = [(0, 0)] + [(k, w) for w in (10, 5) for k in (64, 128, 256, 512)] + [(1024, 10), (0, 0)]
+variants = [(0, 0)] + [(k, w) for w in (4, 2, 1, 10) for k in (64, 128, 192)] + [(0, 0)]
 with pbrt_amd.Scene(sd) as sc:
     print("accelerator:", sc.build_info(), sc.info())
     # is the device-built tree numbered top first?  level of every node by a breadth-first walk over the exported nodes
