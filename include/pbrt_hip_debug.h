@@ -15,6 +15,10 @@ extern "C" {
 /* the canonical tree behind the counter flags: *ready = it exists (always for a host-built scene; for a device-built one
  * after the first call that counted), *build_ms = the host builder's time for it */
 int pbrt_hip_scene_canonical_info(const pbrt_hip_scene *scene, uint32_t *ready, double *build_ms);
+/* the objective of the device build's tree optimisation (pbrt_hip_scene_optimize_info: passes, moves, time): the summed half surface
+ * area of the interior nodes of the binary tree before the first pass and after the last one kept; *undone = 1 when a pass raised
+ * it, was undone and ended the passes (pbrt_amd/csrc/reinsert_core.hpp).  Zeros for a host-built scene.  Any pointer may be NULL. */
+int pbrt_hip_scene_optimize_cost(const pbrt_hip_scene *scene, double *before, double *after, uint32_t *undone);
 /* the production walk's tree as it sits in HBM: quads = 16 words per node (cap_nodes of them), order = leaf slot ->
  * triangle id (n_tris words); either may be NULL */
 int pbrt_hip_scene_export_quads(const pbrt_hip_scene *scene, uint32_t *quads, uint32_t cap_nodes, uint32_t *n_quads,

@@ -345,8 +345,11 @@ class Scene:
         check(lib().pbrt_hip_scene_canonical_info(self._h, C.byref(r), C.byref(cms)), "pbrt_hip_scene_canonical_info")
         op, om, oms = C.c_uint32(), C.c_uint32(), C.c_double()
         check(lib().pbrt_hip_scene_optimize_info(self._h, C.byref(op), C.byref(om), C.byref(oms)), "pbrt_hip_scene_optimize_info")
+        cb, ca, un = C.c_double(), C.c_double(), C.c_uint32()
+        check(lib().pbrt_hip_scene_optimize_cost(self._h, C.byref(cb), C.byref(ca), C.byref(un)), "pbrt_hip_scene_optimize_cost")
         return {"gpu_built": bool(g.value), "build_ms": ms.value, "canonical_tree_ready": bool(r.value), "canonical_tree_host_build_ms": cms.value,
-                "reinsert_passes": op.value, "reinsert_moves": om.value, "reinsert_ms": oms.value}
+                "reinsert_passes": op.value, "reinsert_moves": om.value, "reinsert_ms": oms.value,
+                "reinsert_area_before": cb.value, "reinsert_area_after": ca.value, "reinsert_pass_undone": bool(un.value)}
 
     def export_quads(self):
         """(quads[n, 16] uint32, order[n_tris] uint32): the production walk's tree as it sits in HBM."""

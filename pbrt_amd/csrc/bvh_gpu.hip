@@ -17,10 +17,12 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>  // (rocPRIM directly: hipCUB is its CUDA-compatibility face)
+#include <rocprim/device/device_scan.hpp>
 
 #include "device_types.h"
 #include "reinsert_core.hpp"
@@ -408,18 +410,23 @@ __global__ void ri_hold_kernel(reins::Tree t, const uint32_t *mv_y, const float 
   holds[x] = ok ? 1u : 0u;
 }
 
-__global__ void ri_free_kernel(reins::Tree t, uint32_t *mv_y, const uint32_t *mv_lca, const uint32_t *holds) {
+// (a holder on the target's path blocks only with a LARGER key: reinsert_core.hpp target_path_is_free)
+__global__ void ri_free_kernel(reins::Tree t, uint32_t *mv_y, const uint32_t *mv_lca, const float *mv_gain, const uint32_t *holds) {
   const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= 2u * t.n_int + 1u || mv_y[x] == kNone) return;
-  if (!(holds[x] && reins::target_path_is_free(t, x, mv_y[x], mv_lca[x], [&](uint32_t q) { return holds[q] != 0u; }))) mv_y[x] = kNone;
+  const unsigned long long key = reins::move_key(x, mv_gain[x]);
+  if (!(holds[x] && reins::target_path_is_free(t, x, mv_y[x], mv_lca[x], [&](uint32_t q) { return holds[q] != 0u && reins::move_key(q, mv_gain[q]) > key; })))
+    mv_y[x] = kNone;
 }
 
-__global__ void __launch_bounds__(256) ri_apply_kernel(reins::Tree t, const uint32_t *mv_y, unsigned long long *stats) {
+// (mv_from[x] = the grandparent x leaves: with its new parent, the two places whose ancestors' boxes the move changes)
+__global__ void __launch_bounds__(256) ri_apply_kernel(reins::Tree t, const uint32_t *mv_y, uint32_t *mv_from, unsigned long long *stats) {
   __shared__ unsigned int s_applied;
   if (threadIdx.x == 0) s_applied = 0u;
   __syncthreads();
   const uint32_t x = blockIdx.x * 256u + threadIdx.x;
   if (x < 2u * t.n_int + 1u && mv_y[x] != kNone) {
+    mv_from[x] = t.par[t.par[x]];  // (x's parent and grandparent are among the six nodes whose links this move alone may write)
     reins::apply_move(t, x, mv_y[x]);
     atomicAdd(&s_applied, 1u);
   }
@@ -453,6 +460,61 @@ __global__ void ri_refit_kernel(reins::Tree t, uint32_t *visits, uint32_t *cnt) 
     node = p;
     p = t.par[p];
   }
+}
+
+// ---- refit of what a pass moved (a pass moves 1.4 % of the nodes, the full refit above was 3/4 of its time) ----
+// mark[i], interior node i: bit 31 = some box below i changed (i must be refitted), low bits = children that have arrived.
+constexpr uint32_t kDirty = 0x80000000u;
+// every applied move dirties the chain above x's new parent (the re-used node p, now y's parent too) and above the grandparent x
+// left; a chain that meets a dirty node stops -- whoever dirtied it climbs on
+__global__ void ri_mark_kernel(reins::Tree t, const uint32_t *mv_y, const uint32_t *mv_from, uint32_t *mark) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= 2u * t.n_int + 1u || mv_y[x] == kNone) return;
+  for (int k = 0; k < 2; k++)
+    for (uint32_t q = k ? mv_from[x] : t.par[x]; q != kNone; q = t.par[q])
+      if (atomicOr(&mark[q], kDirty) & kDirty) break;
+}
+// One thread per interior node; the dirty nodes without a dirty child start (their children's boxes are final), fit their box and
+// climb; at a parent whose other child is dirty too the first to arrive stops and the second fits (as in ri_refit_kernel).  The
+// boxes that result are those of a full refit: a node that is not dirty has nothing changed below it, and min / max are exact.
+__global__ void ri_refit_dirty_kernel(reins::Tree t, uint32_t *mark) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.n_int || !(mark[i] & kDirty)) return;
+  auto dirty = [&](uint32_t c) { return c < t.n_int && (__hip_atomic_load(&mark[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kDirty) != 0u; };
+  uint32_t node = i, k0 = t.kid[2 * (size_t)i], k1 = t.kid[2 * (size_t)i + 1];
+  if (dirty(k0) || dirty(k1)) return;  // (a thread from below arrives here later)
+  for (;;) {
+    float lo[3], hi[3], slo[3], shi[3];
+    box_load<true>(t.bx, k0, lo, hi);
+    box_load<true>(t.bx, k1, slo, shi);
+    for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], slo[a]); hi[a] = fmaxf(hi[a], shi[a]); }
+    box_store(t.bx, node, lo, hi);
+    const uint32_t p = t.par[node];
+    if (p == kNone) return;
+    k0 = t.kid[2 * (size_t)p];
+    k1 = t.kid[2 * (size_t)p + 1];
+    if (dirty(k0 == node ? k1 : k0)) {  // the sibling's subtree is being refitted too: the second to arrive goes on
+      __threadfence();
+      if ((atomicAdd(&mark[p], 1u) & ~kDirty) == 0u) return;
+      __threadfence();
+    } else {
+      __threadfence();
+    }
+    node = p;
+  }
+}
+// The summed (half) surface area of the interior nodes in fixed point -- integers add up to the same sum in any order --, units of
+// 2^-se with the root's area below 2^40 units (find_move's scale): out[0] += the sum, out[1] = se + 1024.
+__global__ void ri_cost_kernel(reins::Tree t, unsigned long long *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  int se = 0;
+  (void)frexpf(reins::area(reins::load_box(t, 0u)), &se);
+  se = 40 - se;
+  se = se > 100 ? 100 : (se < -100 ? -100 : se);
+  unsigned long long v = i < t.n_int ? (unsigned long long)(reins::area(reins::load_box(t, i)) * ldexpf(1.0f, se)) : 0ull;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&out[0], v);
+  if (i == 0u) out[1] = (unsigned long long)(se + 1024);
 }
 
 __global__ void ri_order_kernel(reins::Tree t) {
@@ -720,7 +782,7 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   GB_TRY(counters.alloc(2 * 4));
   GB_TRY(level_counts.alloc(64 * 4));
   size_t sort_bytes = 0;
-  GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
+  GB_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, (size_t)n, 0u, 30u, stream));
   GB_TRY(sort_tmp.alloc(sort_bytes));
 
   struct Events {  // (destroyed on every exit, early returns of GB_TRY included)
@@ -736,7 +798,7 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   hipLaunchKernelGGL(centroid_bounds_kernel, dim3((n_tris + 2047u) / 2048u), block, 0, stream, d_P, d_idx, n_tris, bounds.as<uint32_t>());
   hipLaunchKernelGGL(morton_kernel, grid_t, block, 0, stream, d_P, d_idx, n_tris, bounds.as<uint32_t>(), keys.as<uint32_t>(), vals.as<uint32_t>());
   GB_TRY(hipGetLastError());
-  GB_TRY(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, n, 0, 30, stream));
+  GB_TRY(rocprim::radix_sort_pairs(sort_tmp.p, sort_bytes, keys.as<uint32_t>(), keys_out.as<uint32_t>(), vals.as<uint32_t>(), d_order, (size_t)n, 0u, 30u, stream));
   const uint32_t root_node = 0u;  // internal node the collapse starts from
   const bool sah_tree = true;
   {
@@ -749,7 +811,7 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
     GB_TRY(active.alloc(4 * cap)); GB_TRY(cbase.alloc(4 * cap)); GB_TRY(flags.alloc(4 * (size_t)n)); GB_TRY(scan.alloc(4 * (size_t)n));
     GB_TRY(segtab.alloc(4 * 6 * cap));
     size_t scan_bytes = 0;
-    GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags.as<uint32_t>(), scan.as<uint32_t>(), n, stream));
+    GB_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flags.as<uint32_t>(), scan.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     GB_TRY(scan_tmp.alloc(scan_bytes));
     SahSegs cur_s{segtab.as<uint32_t>(), segtab.as<uint32_t>() + cap, segtab.as<uint32_t>() + 2 * cap};
     SahSegs nxt_s{segtab.as<uint32_t>() + 3 * cap, segtab.as<uint32_t>() + 4 * cap, segtab.as<uint32_t>() + 5 * cap};
@@ -777,9 +839,9 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
       hipLaunchKernelGGL(sah_bins_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, tlo.as<float>(), thi.as<float>(), split.as<SahSplit>(), bins.as<uint32_t>());
       hipLaunchKernelGGL(sah_split_kernel, gs, b128, 0, stream, (int)n_seg, cur_s, bins.as<uint32_t>(), split.as<SahSplit>(), level, bx.as<unsigned long long>(),
                          active.as<uint32_t>());
-      GB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, active.as<uint32_t>(), cbase.as<uint32_t>(), (int)n_seg, stream));
+      GB_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, active.as<uint32_t>(), cbase.as<uint32_t>(), 0u, (size_t)n_seg, rocprim::plus<uint32_t>(), stream));
       hipLaunchKernelGGL(sah_flags_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, tlo.as<float>(), thi.as<float>(), cur_s, split.as<SahSplit>(), flags.as<uint32_t>());
-      GB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, flags.as<uint32_t>(), scan.as<uint32_t>(), n, stream));
+      GB_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, flags.as<uint32_t>(), scan.as<uint32_t>(), 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
       hipLaunchKernelGGL(sah_scatter_kernel, grid_t, block, 0, stream, ids_in, seg_in, n, cur_s, split.as<SahSplit>(), flags.as<uint32_t>(), scan.as<uint32_t>(),
                          cbase.as<uint32_t>(), ids_out, seg_out);
       hipLaunchKernelGGL(sah_children_kernel, gs, b128, 0, stream, (int)n_seg, cur_s, split.as<SahSplit>(), cbase.as<uint32_t>(), next_node, child.as<uint32_t>(), nxt_s,
@@ -809,8 +871,11 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
   info->reinsert_passes = 0;
   info->reinsert_moves = 0;
   info->reinsert_ms = 0.f;
+  info->reinsert_cost_before = info->reinsert_cost_after = 0.;
+  info->reinsert_undone = 0;
   {
-    int passes = 12;
+    reins::StopRule stop;  // (shared with the host run of the pass: reinsert_core.hpp)
+    int passes = stop.max_passes;
     uint32_t mu = 1;
     reins::Search sp;
     if (const char *v = debug_knob("PBRT_HIP_GPU_REINSERT")) passes = std::atoi(v);
@@ -819,50 +884,81 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
     if (const char *v = debug_knob("PBRT_HIP_REINSERT_MIN_REL")) sp.min_rel = (float)std::atof(v);
     if (const char *v = debug_knob("PBRT_HIP_REINSERT_QK")) sp.qk = (float)std::atof(v);
     if (const char *v = debug_knob("PBRT_HIP_REINSERT_QW")) sp.qw = (float)std::atof(v);
+    const bool full_refit = debug_knob("PBRT_HIP_REINSERT_FULL_REFIT") != nullptr;  // (A-B: every box every pass, as until round 4)
     if (!(flags & kGpuBuildReinsert)) passes = 0;
-    // Small trees are left as built: below kReinsertMinTris triangles (where the collapse is the greedy one, too) a walk is a handful
+    // Small trees are left as built: below StopRule::min_tris triangles (where the collapse is the greedy one, too) a walk is a handful
     // of steps in L1 and the surface-area objective decides nothing measurable -- BASELINE C4's 36 triangles rendered 2 % SLOWER with
     // the four moves the pass found (15 quad nodes instead of 19, profiles/r04p5_c4_ab.txt).  The test suite lowers the threshold
     // (tests/conftest.py) so that trees of 8 .. 300 triangles keep exercising the pass.
-    constexpr uint32_t kReinsertMinTris = 1024;
-    uint32_t min_tris = kReinsertMinTris;
+    uint32_t min_tris = stop.min_tris;
     if (const char *v = debug_knob("PBRT_HIP_REINSERT_MIN_TRIS")) min_tris = (uint32_t)std::max(8, std::atoi(v));
     if (sah_tree && n_tris >= min_tris && n >= 8 && passes > 0) {
-      constexpr unsigned long long kVisitBudget = 1024;
       const uint32_t n_int = (uint32_t)n - 1u, n_nodes = 2u * n_int + 1u;
       const dim3 grid_n((n_nodes + 255u) / 256u), grid_i((n_int + 255u) / 256u);
-      Tmp par, kid, mv_y, mv_lca, mv_gain, lock, holds, stats, cnt, newslot, order2, leaf_bx;
+      Tmp par, kid, mv_y, mv_lca, mv_gain, lock, holds, stats, cnt, newslot, order2, leaf_bx, par_b, kid_b, bx_b;
       GB_TRY(par.alloc(4 * (size_t)n_nodes)); GB_TRY(kid.alloc(8 * (size_t)n_int));
       GB_TRY(mv_y.alloc(4 * (size_t)n_nodes)); GB_TRY(mv_lca.alloc(4 * (size_t)n_nodes)); GB_TRY(mv_gain.alloc(4 * (size_t)n_nodes));
-      GB_TRY(lock.alloc(8 * (size_t)n_nodes)); GB_TRY(holds.alloc(4 * (size_t)n_nodes)); GB_TRY(stats.alloc(3 * 8));
+      GB_TRY(lock.alloc(8 * (size_t)n_nodes)); GB_TRY(holds.alloc(4 * (size_t)n_nodes)); GB_TRY(stats.alloc(5 * 8));
       GB_TRY(cnt.alloc(4 * (size_t)n_int)); GB_TRY(newslot.alloc(4 * (size_t)n)); GB_TRY(order2.alloc(4 * (size_t)n)); GB_TRY(leaf_bx.alloc(24 * (size_t)n));
+      // the tree as it stood before the pass in flight (links + interior boxes): a pass that raises the summed area is undone
+      GB_TRY(par_b.alloc(4 * (size_t)n_nodes)); GB_TRY(kid_b.alloc(8 * (size_t)n_int)); GB_TRY(bx_b.alloc(24 * (size_t)n_int));
       Events rev;
       GB_TRY(hipEventCreate(&rev.a));
       GB_TRY(hipEventCreate(&rev.b));
       GB_TRY(hipEventRecord(rev.a, stream));
       const reins::Tree t{n_int, par.as<uint32_t>(), kid.as<uint32_t>(), bx.as<unsigned long long>()};
       hipLaunchKernelGGL(ri_links_kernel, grid_i, block, 0, stream, n, child.as<uint32_t>(), par.as<uint32_t>(), kid.as<uint32_t>());
-      GB_TRY(hipMemsetAsync(stats.p, 0, 3 * 8, stream));
-      unsigned long long h_stats[3] = {0, 0, 0}, applied_before = 0;
+      // stats: [0] visits [1] found [2] applied (summed over the passes); [3] the tree's cost in fixed point, [4] its scale (ri_cost_kernel)
+      GB_TRY(hipMemsetAsync(stats.p, 0, 5 * 8, stream));
+      hipLaunchKernelGGL(ri_cost_kernel, grid_i, block, 0, stream, t, stats.as<unsigned long long>() + 3);
+      unsigned long long h_stats[5] = {0, 0, 0, 0, 0}, applied_before = 0, cost = 0;
+      GB_TRY(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, stream));
+      GB_TRY(hipStreamSynchronize(stream));
+      cost = h_stats[3];
+      const double cost_unit = std::ldexp(1.0, -((int)h_stats[4] - 1024));
+      info->reinsert_cost_before = info->reinsert_cost_after = (double)cost * cost_unit;
       int done = 0;
       for (int pass = 0; pass < passes; pass++) {
+        GB_TRY(hipMemcpyAsync(par_b.p, par.p, 4 * (size_t)n_nodes, hipMemcpyDeviceToDevice, stream));
+        GB_TRY(hipMemcpyAsync(kid_b.p, kid.p, 8 * (size_t)n_int, hipMemcpyDeviceToDevice, stream));
+        GB_TRY(hipMemcpyAsync(bx_b.p, bx.p, 24 * (size_t)n_int, hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(ri_search_kernel, grid_n, block, 0, stream, t, sp, (uint32_t)pass, mu, mv_y.as<uint32_t>(), mv_lca.as<uint32_t>(), mv_gain.as<float>(),
                            stats.as<unsigned long long>());
         GB_TRY(hipMemsetAsync(lock.p, 0, 8 * (size_t)n_nodes, stream));
         hipLaunchKernelGGL(ri_lock_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_gain.as<float>(), lock.as<unsigned long long>());
         hipLaunchKernelGGL(ri_hold_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_gain.as<float>(), lock.as<unsigned long long>(), holds.as<uint32_t>());
-        hipLaunchKernelGGL(ri_free_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_lca.as<uint32_t>(), holds.as<uint32_t>());
-        hipLaunchKernelGGL(ri_apply_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), stats.as<unsigned long long>());
+        hipLaunchKernelGGL(ri_free_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_lca.as<uint32_t>(), mv_gain.as<float>(), holds.as<uint32_t>());
+        // (mv_lca has served: the apply kernel leaves there the grandparent every moved node came from)
+        hipLaunchKernelGGL(ri_apply_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_lca.as<uint32_t>(), stats.as<unsigned long long>());
         GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
-        hipLaunchKernelGGL(ri_refit_kernel<false>, grid_t, block, 0, stream, t, visits.as<uint32_t>(), cnt.as<uint32_t>());
+        if (full_refit) {
+          hipLaunchKernelGGL(ri_refit_kernel<false>, grid_t, block, 0, stream, t, visits.as<uint32_t>(), cnt.as<uint32_t>());
+        } else {
+          hipLaunchKernelGGL(ri_mark_kernel, grid_n, block, 0, stream, t, mv_y.as<uint32_t>(), mv_lca.as<uint32_t>(), visits.as<uint32_t>());
+          hipLaunchKernelGGL(ri_refit_dirty_kernel, grid_i, block, 0, stream, t, visits.as<uint32_t>());
+        }
+        GB_TRY(hipMemsetAsync(stats.as<unsigned long long>() + 3, 0, 8, stream));
+        hipLaunchKernelGGL(ri_cost_kernel, grid_i, block, 0, stream, t, stats.as<unsigned long long>() + 3);
         GB_TRY(hipGetLastError());
         GB_TRY(hipMemcpyAsync(h_stats, stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, stream));
         GB_TRY(hipStreamSynchronize(stream));
-        done = pass + 1;
         const unsigned long long applied = h_stats[2] - applied_before;
+        if (h_stats[3] > cost) {
+          // The moves of a pass hold six link nodes each, not their paths, so their gains need not add up: one pass in a
+          // thousand or so comes out with MORE summed area than it went in with.  Such a pass is undone and ends the passes.
+          GB_TRY(hipMemcpyAsync(par.p, par_b.p, 4 * (size_t)n_nodes, hipMemcpyDeviceToDevice, stream));
+          GB_TRY(hipMemcpyAsync(kid.p, kid_b.p, 8 * (size_t)n_int, hipMemcpyDeviceToDevice, stream));
+          GB_TRY(hipMemcpyAsync(bx.p, bx_b.p, 24 * (size_t)n_int, hipMemcpyDeviceToDevice, stream));
+          h_stats[2] = applied_before;
+          info->reinsert_undone = 1;
+          break;
+        }
+        done = pass + 1;
+        cost = h_stats[3];
         applied_before = h_stats[2];
-        if (applied * 1024ull < n_nodes || h_stats[0] > kVisitBudget * n_nodes) break;
+        if (reins::stop_after_pass(stop, applied, h_stats[0], n_nodes)) break;
       }
+      info->reinsert_cost_after = (double)cost * cost_unit;
       // child order, leaf counts, leaves renumbered in depth-first order, and back to the builder's arrays
       hipLaunchKernelGGL(ri_order_kernel, grid_i, block, 0, stream, t);
       GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));

@@ -556,9 +556,9 @@ void make_quad_nodes(const RefBvh &b, const uint32_t *slot_of_ref, bool split_le
 // tools/experiments/r03_host_tree_builders/.)
 enum ProductionTree : uint32_t { kTreeCanonical = 0, kTreeReinsert = 2 };  // (= PBRT_HIP_TREE_*)
 ReinsertBatchParams reinsert_batch_params() {
-  ReinsertBatchParams p;
-  p.passes = 12;
+  ReinsertBatchParams p;  // (passes, stop rule and least tree size: reins::StopRule, shared with the device loop of bvh_gpu.hip)
   if (const char *v = debug_knob("PBRT_HIP_REINSERT")) p.passes = std::atoi(v);
+  if (const char *v = debug_knob("PBRT_HIP_REINSERT_MIN_TRIS")) p.stop.min_tris = (uint32_t)std::max(8, std::atoi(v));
   if (const char *v = debug_knob("PBRT_HIP_REINSERT_MU")) p.mu = (uint32_t)std::max(1, std::atoi(v));
   if (const char *v = debug_knob("PBRT_HIP_REINSERT_VISITS")) p.search.max_visits = (uint32_t)std::max(1, std::atoi(v));
   if (const char *v = debug_knob("PBRT_HIP_REINSERT_MIN_REL")) p.search.min_rel = (float)std::atof(v);
@@ -576,7 +576,8 @@ void build_production_quads(const Bvh &canon, const float *P, const uint32_t *id
   RefBvh rb;
   if (tree == kTreeReinsert && n_tris >= 2) {
     single_ref_tree(canon, P, idx, &rb);
-    reinsert_optimize_batch(&rb, reinsert_batch_params());
+    const ReinsertBatchParams rp = reinsert_batch_params();
+    if (n_tris >= rp.stop.min_tris) reinsert_optimize_batch(&rb, rp);  // (smaller trees stay as built, as on the device)
     if (std::getenv("PBRT_HIP_REINSERT_VERBOSE")) {
       LinkTree lt;
       link_tree_of(rb, &lt);
@@ -873,6 +874,9 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       s->reinsert_passes = gb.reinsert_passes;
       s->reinsert_moves = gb.reinsert_moves;
       s->reinsert_ms = gb.reinsert_ms;
+      s->reinsert_cost_before = gb.reinsert_cost_before;
+      s->reinsert_cost_after = gb.reinsert_cost_after;
+      s->reinsert_undone = gb.reinsert_undone;
     } else {
       HIP_TRY(up(s->d_order.p, s->bvh.order.data(), s->d_order.n * 4));
     }
@@ -968,6 +972,14 @@ int pbrt_hip_scene_optimize_info(const pbrt_hip_scene *s, uint32_t *passes, uint
   if (passes) *passes = s->reinsert_passes;
   if (moves) *moves = s->reinsert_moves;
   if (ms) *ms = s->reinsert_ms;
+  return PBRT_HIP_OK;
+}
+
+int pbrt_hip_scene_optimize_cost(const pbrt_hip_scene *s, double *before, double *after, uint32_t *undone) {
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "optimize_cost: null scene");
+  if (before) *before = s->reinsert_cost_before;
+  if (after) *after = s->reinsert_cost_after;
+  if (undone) *undone = s->reinsert_undone;
   return PBRT_HIP_OK;
 }
 

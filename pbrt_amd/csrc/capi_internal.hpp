@@ -75,6 +75,8 @@ struct pbrt_hip_scene {
   double build_ms = 0.0;
   uint32_t reinsert_passes = 0, reinsert_moves = 0;  // the device build's tree optimisation (GpuBuildInfo)
   double reinsert_ms = 0.0;
+  double reinsert_cost_before = 0.0, reinsert_cost_after = 0.0;  // summed half surface area of the interior nodes (GpuBuildInfo)
+  uint32_t reinsert_undone = 0;
   uint64_t pending_samples = 0;
   uint64_t device_bytes = 0;
 

@@ -201,6 +201,8 @@ struct GpuBuildInfo {
   float build_ms;  // everything, the optimisation included
   uint32_t reinsert_passes, reinsert_moves;  // the tree's optimisation by parallel re-insertion (reinsert_core.hpp)
   float reinsert_ms;
+  double reinsert_cost_before, reinsert_cost_after;  // summed half surface area of the interior nodes before the first and after the last kept pass
+  uint32_t reinsert_undone;                           // 1: a pass raised that sum, was undone and ended the passes
 };
 constexpr uint32_t kGpuBuildReinsert = 1u;  // flags of gpu_build_quads: optimise the binary tree by re-insertion before the collapse
 hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_tris, uint32_t *d_order, uint4 *d_quads,

@@ -136,6 +136,9 @@ int clone_scene(const pbrt_hip_scene *src, int device, pbrt_hip_scene **out) {
   s->reinsert_passes = src->reinsert_passes;
   s->reinsert_moves = src->reinsert_moves;
   s->reinsert_ms = src->reinsert_ms;
+  s->reinsert_cost_before = src->reinsert_cost_before;
+  s->reinsert_cost_after = src->reinsert_cost_after;
+  s->reinsert_undone = src->reinsert_undone;
   s->device_bytes = src->device_bytes;
   HIP_TRY(hipStreamCreate(&s->stream));
   HIP_TRY(hipEventCreate(&s->ev0));

@@ -242,7 +242,23 @@ void reinsert_batch_links(LinkTree *lt, const ReinsertBatchParams &prm, Reinsert
     for (uint32_t i = 0; i < n_int; i++) reins::order_children(t, i);
     return;
   }
+  // the summed area of the interior nodes as the device reduces it: exact integers (units of 2^-se of reinsert_core.hpp's find_move)
+  auto fixed_cost = [&]() {
+    int se = 0;
+    (void)frexpf(reins::area(reins::load_box(t, 0u)), &se);
+    se = 40 - se;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const float to_fix = ldexpf(1.0f, se);
+    unsigned long long sum = 0;
+    for (uint32_t i = 0; i < n_int; i++) sum += (unsigned long long)(reins::area(reins::load_box(t, i)) * to_fix);
+    return sum;
+  };
+  unsigned long long cost = fixed_cost();
+  if (stats) stats->cost_before = stats->cost_after = lt->cost();
+  uint64_t visits_total = 0;
   for (int pass = 0; pass < prm.passes; pass++) {
+    const std::vector<uint32_t> par_b = lt->par, kid_b = lt->kid;  // (a pass that raises the cost is undone)
+    const std::vector<unsigned long long> bx_b = lt->bx;
     // 1. search (read-only)
     uint64_t visits = 0, found = 0, max_v = 0;
     for (uint32_t x = 0; x < n_nodes; x++) {
@@ -252,6 +268,7 @@ void reinsert_batch_links(LinkTree *lt, const ReinsertBatchParams &prm, Reinsert
       max_v = std::max<uint64_t>(max_v, mv[x].visits);
       found += mv[x].y != kNone;
     }
+    visits_total += visits;
     // 2. lock
     std::fill(lock.begin(), lock.end(), 0ull);
     for (uint32_t x = 0; x < n_nodes; x++) {
@@ -270,23 +287,35 @@ void reinsert_batch_links(LinkTree *lt, const ReinsertBatchParams &prm, Reinsert
     }
     uint64_t applied = 0, held = 0;
     double gain = 0;
+    std::vector<uint8_t> go(n_nodes, 0);  // (decided from `holds` alone, as the device's ri_free_kernel does: not from each other)
     for (uint32_t x = 0; x < n_nodes; x++) {
       if (mv[x].y == kNone) continue;
       held += holds[x];
-      if (holds[x] && reins::target_path_is_free(t, x, mv[x].y, mv[x].lca, [&](uint32_t q) { return holds[q] != 0; })) { applied++; gain += mv[x].gain; }
-      else mv[x].y = kNone;
+      const unsigned long long key = reins::move_key(x, mv[x].gain);
+      if (holds[x] && reins::target_path_is_free(t, x, mv[x].y, mv[x].lca, [&](uint32_t q) { return holds[q] != 0 && reins::move_key(q, mv[q].gain) > key; })) {
+        go[x] = 1; applied++; gain += mv[x].gain;
+      }
     }
     // 4. apply
     for (uint32_t x = 0; x < n_nodes; x++)
-      if (mv[x].y != kNone) reins::apply_move(t, x, mv[x].y);
-    // 5. refit
+      if (go[x]) reins::apply_move(t, x, mv[x].y);
+    // 5. refit, and the pass's verdict
     refit_links(lt);
-    if (stats) { stats->passes++; stats->visits += visits; stats->found += found; stats->applied += applied; stats->max_visits = std::max(stats->max_visits, max_v); }
+    const unsigned long long cost_now = fixed_cost();
+    if (stats) { stats->passes++; stats->visits += visits; stats->found += found; stats->max_visits = std::max(stats->max_visits, max_v); }
     if (verbose)
-      std::fprintf(stderr, "reinsert pass %2d: %8llu searches found a move, %8llu hold their links, %8llu applied, %.1f visits per search (max %llu), gain %.6g, cost %.6g\n", pass,
+      std::fprintf(stderr, "reinsert pass %2d: %8llu searches found a move, %8llu hold their links, %8llu applied, %.1f visits per search (max %llu), gain %.6g, cost %.6g%s\n", pass,
                    (unsigned long long)found, (unsigned long long)held, (unsigned long long)applied, (double)visits / std::max<uint64_t>(1, (n_nodes + mu - 1) / mu), (unsigned long long)max_v,
-                   gain, lt->cost());
-    if (found == 0 && mu == 1) break;
+                   gain, lt->cost(), cost_now > cost ? " (ROSE: pass undone)" : "");
+    if (cost_now > cost) {  // the moves of a pass lock six nodes each, not their paths: their gains need not add up
+      lt->par = par_b; lt->kid = kid_b; lt->bx = bx_b;
+      t = reins::Tree{n_int, lt->par.data(), lt->kid.data(), lt->bx.data()};
+      if (stats) stats->undone = 1;
+      break;
+    }
+    cost = cost_now;
+    if (stats) { stats->applied += applied; stats->cost_after = lt->cost(); }
+    if (mu == 1 && reins::stop_after_pass(prm.stop, applied, visits_total, n_nodes)) break;
   }
   for (uint32_t i = 0; i < n_int; i++) reins::order_children(t, i);
 }

@@ -21,12 +21,15 @@ struct LinkTree {
 };
 
 struct ReinsertBatchParams {
-  int passes = 8;
+  reins::StopRule stop;         // the device loop's rule (passes at most, least moves per pass, visit budget): reinsert_core.hpp
+  int passes = reins::StopRule().max_passes;  // (= stop.max_passes unless a caller wants fewer)
   uint32_t mu = 1;              // pass k searches the nodes x with (x + k) % mu == 0
   reins::Search search;
 };
 struct ReinsertBatchStats {
   uint64_t passes = 0, visits = 0, found = 0, applied = 0, max_visits = 0;
+  uint64_t undone = 0;          // 1: the last pass raised the summed area and was undone
+  double cost_before = 0, cost_after = 0;  // summed half surface area of the interior nodes
 };
 
 // `rb`: every leaf holds one reference

@@ -17,18 +17,23 @@
 //               where nothing prunes, cost a bounded amount (ADVICE / DESIGN r03: the host pass's known limit).
 //   2. LOCK     a move rewrites the links of x, its parent, sibling and grandparent and of y and its parent: its key (gain, x)
 //               goes into each of the six with atomicMax.
-//   3. CHECK    a move whose key survived in ALL six holds them; of those, a move with another holder's node on the way from
-//               its target up to the common ancestor is dropped (target_path_is_free: no cycle can form).  The others are
+//   3. CHECK    a move whose key survived in ALL six holds them; of those, a move with the node of another holder OF LARGER KEY
+//               on the way from its target up to the common ancestor is dropped (target_path_is_free: no cycle can form).  The others are
 //               applied; dropped moves search again next pass.  No link is written twice, and the outcome does not depend on
 //               the order the threads run in: deterministic.  (Locking the whole paths, as Meister & Bittner do, would also
 //               make the gains of a pass's moves add up exactly -- but in a soup of triangles as large as their spacing one
 //               node in eight wants to move ACROSS the top of the tree, and every such move's path runs through the root's
 //               children: measured, 3 650 of 25 052 moves of the first pass survive and the pass converges to a worse tree.)
 //   4. APPLY    seven link writes per move.
-//   5. REFIT    all boxes bottom-up.
+//   5. REFIT    the boxes above the moved nodes, bottom-up (the device: only the chains above a move's old and new place -- a pass
+//               moves about one node in seventy, bvh_gpu.hip ri_mark_kernel / ri_refit_dirty_kernel; the host run: all of them;
+//               the same boxes either way, min / max being exact).  Then the summed area of the interior nodes in fixed point: a
+//               pass that RAISED it is undone and ends the passes (the moves of one pass lock six nodes each, not their
+//               paths, so their gains need not add up: one pass in a thousand or so comes out worse).
 // Node ids: interior nodes [0, n_int), the leaf of slot k = n_int + k (n_int = leaves - 1), root 0.  The root and its two
 // children are never moved (the root stays node 0); they can be targets.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -93,6 +98,19 @@ RI_HD uint32_t sibling(const Tree &t, uint32_t parent, uint32_t child) {
   return a == child ? b : a;
 }
 
+// When the passes end: ONE rule for the device loop (bvh_gpu.hip) and the host run (reinsert_batch.cpp), so that both make the same
+// tree from the same input whatever the number of passes it takes.
+struct StopRule {
+  int max_passes = 12;
+  uint32_t min_moved_div = 1024;            // a pass that applied fewer than nodes / 1024 moves was the last one
+  unsigned long long visit_budget = 1024;   // ... as is one after which the searches have looked at more than this many nodes PER NODE of the
+                                            // tree in total (coincident boxes, where nothing prunes a search, cost a bounded time)
+  uint32_t min_tris = 1024;                 // trees of fewer triangles are left as built (nothing measurable to gain)
+};
+inline bool stop_after_pass(const StopRule &r, unsigned long long applied, unsigned long long visits_total, uint32_t n_nodes) {
+  return applied * r.min_moved_div < n_nodes || visits_total > r.visit_budget * n_nodes;
+}
+
 struct Move {
   uint32_t y;       // x becomes the sibling of y (kNone: x stays)
   uint32_t lca;     // the node neither of whose links or box the move changes: the paths x -> lca and y -> lca are what it locks
@@ -127,6 +145,17 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
   if (p == kNone || t.par[p] == kNone) return m;  // the root and its children stay
   const Box bxx = load_box(t, x);
   const float ax = area(bxx);
+  // The growth `c` of the nodes above the candidate is kept in FIXED POINT (units of 2^-se, the root's area below 2^40 units): the
+  // stackless descent adds a node's term on the way down and takes the same term off on the way up, and integer addition undoes
+  // exactly -- a float sum drifted by an ulp per level over the hundreds of nodes a search may visit, and with it the bound and the
+  // gain that orders the locks.  A tree whose root area is not finite (coordinates near 1e30) has nothing to steer by.
+  const float a_root = area(load_box(t, 0u));
+  if (!(a_root < 3.0e38f)) return m;
+  int se = 0;
+  (void)frexpf(a_root, &se);
+  se = 40 - se;
+  se = se > 100 ? 100 : (se < -100 ? -100 : se);
+  const float to_fix = ldexpf(1.0f, se), from_fix = ldexpf(1.0f, -se);
   const Box bp0 = load_box(t, p);
   float saved = area(bp0);  // taking x out: p disappears (below: + what the ancestors under the pivot shrink by)
   float best = min_rel * saved;
@@ -141,7 +170,7 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
     Box top = load_box(t, other);
     {
       uint32_t out = other;
-      float c = 0.f;
+      long long ci = 0;
       bool down = true;
       for (;;) {
         if (down) {
@@ -149,14 +178,16 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
           visits++;
           const Box un = unite(bo, bxx);
           const float direct = area(un);
+          const float c = (float)ci * from_fix;
           if (!(first && out == other)) {  // (x's own sibling: putting x back where it was)
             float g = (saved - c) - direct;
             if (qk > 0.f) g -= wx * area_on(bxx, un, qk) - q_old;
             if (g > best) { best = g; m.y = out; m.lca = pivot; }
           }
-          const float cn = c + (direct - area(bo));
+          const long long di = (long long)((direct - area(bo)) * to_fix);
+          const float cn = (float)(ci + di) * from_fix;
           if (out < t.n_int && ((saved - cn) - ax) - (q_min - q_old) > best && visits < max_visits) {
-            c = cn;
+            ci += di;
             out = t.kid[2 * (size_t)out];
             continue;
           }
@@ -169,7 +200,7 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
           down = true;
         } else {
           const Box bq = load_box(t, q);
-          c -= area(unite(bq, bxx)) - area(bq);
+          ci -= (long long)((area(unite(bq, bxx)) - area(bq)) * to_fix);  // the term q added on the way down, bit for bit
           out = q;
         }
       }
@@ -211,14 +242,18 @@ RI_HD void for_move_nodes(const Tree &t, uint32_t x, uint32_t y, F &&f) {
 
 // Moves whose link sets are disjoint can still form a CYCLE together (x1 into the subtree of x2 and x2 into the subtree of
 // x1).  A cycle needs a move whose target y has, strictly between it and the common ancestor with x, another moving node:
-// such a move is dropped.  (Proof sketch: in the tree after the moves, a node's chain of ancestors climbs the old tree except
-// where it passes a moved node x' and jumps to the parent of its target; a closed chain must enter some moved x' from below,
-// i.e. through a target inside its old subtree, and not all the moved nodes of the chain can be nested in each other.)
-// moving(q): q is the node of another move that holds its link locks.
+// such a move is dropped -- when that other move has the LARGER key.  (Proof sketch: in the tree after the moves, a node's chain
+// of ancestors climbs the old tree except where it passes a moved node x' and jumps to the parent of its target; a closed chain
+// must enter some moved x' from below, i.e. through a target inside its old subtree, and not all the moved nodes of the chain
+// can be nested in each other: the moves of a closed chain block one another in a ring.  In every such ring the move in front of
+// the one with the largest key is blocked by a larger key and dropped, so no ring survives whole.  Until round 5 a move was dropped
+// whatever the blocker's key: both moves of a mutually crossing pair went, and the same pair could be found and dropped pass
+// after pass -- ADVICE r04.)
+// blocks(q): q is the node of another move that holds its link locks AND whose key is larger than this move's.
 template <class F>
-RI_HD bool target_path_is_free(const Tree &t, uint32_t x, uint32_t y, uint32_t lca, F &&moving) {
+RI_HD bool target_path_is_free(const Tree &t, uint32_t x, uint32_t y, uint32_t lca, F &&blocks) {
   for (uint32_t q = t.par[y]; q != lca && q != kNone; q = t.par[q])
-    if (q != x && moving(q)) return false;
+    if (q != x && blocks(q)) return false;
   return true;
 }
 

@@ -763,6 +763,32 @@ def test_device_reinsertion_cuts_the_walks_work(gpu, oracle):
     assert np.array_equal(order, out["gpu"][3][1]), "leaf order differs between two device builds"
     rows = lambda q: q[np.lexsort(q[:, :12].T[::-1])][:, :12]  # a node's origin, cells and child planes (words 0-11), sorted
     assert quads.shape == out["gpu"][3][0].shape and np.array_equal(rows(quads), rows(out["gpu"][3][0])), "quad nodes differ between two device builds"
+    # the objective the passes lower, and its guard: the summed area of the interior nodes fell, by more than a tenth
+    assert 0 < bi["reinsert_area_after"] < 0.9 * bi["reinsert_area_before"], bi
+
+
+def test_device_refit_of_what_moved_equals_the_full_refit(gpu, monkeypatch):
+    """after a pass the device refits only the chains above the nodes that moved (a pass moves about one node in
+    seventy; ri_mark_kernel / ri_refit_dirty_kernel).  The tree that comes out must be the one a refit of EVERY box after every pass
+    makes (PBRT_HIP_REINSERT_FULL_REFIT: the round-4 kernel, kept for this comparison), word for word -- the searches of the next
+    pass read those boxes, so a single stale box would change moves -- on 100k triangles and on the degenerate `ties` scene."""
+    rows = lambda q: q[np.lexsort(q[:, :12].T[::-1])][:, :12]
+    for make in (lambda: scenes.random_mesh_scene(100_000, 64, 64), SMALL_SCENES["ties"], SMALL_SCENES["mesh20k"]):
+        sd = make()
+        got = {}
+        for full in (False, True):
+            if full:
+                monkeypatch.setenv("PBRT_HIP_REINSERT_FULL_REFIT", "1")
+            else:
+                monkeypatch.delenv("PBRT_HIP_REINSERT_FULL_REFIT", raising=False)
+            with gpu.Scene(sd, builder="gpu") as sc:
+                got[full] = (sc.export_quads(), sc.build_info())
+        monkeypatch.delenv("PBRT_HIP_REINSERT_FULL_REFIT", raising=False)
+        (qa, oa), ia = got[False]
+        (qb, ob), ib = got[True]
+        assert np.array_equal(oa, ob) and qa.shape == qb.shape and np.array_equal(rows(qa), rows(qb)), "sparse refit changed the tree"
+        assert (ia["reinsert_passes"], ia["reinsert_moves"], ia["reinsert_area_after"]) == (ib["reinsert_passes"], ib["reinsert_moves"], ib["reinsert_area_after"])
+        assert ia["reinsert_moves"] > 0
 
 
 def test_device_build_of_coincident_boxes_is_bounded(gpu, oracle):
