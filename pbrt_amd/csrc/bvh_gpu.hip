@@ -436,23 +436,25 @@ __global__ void __launch_bounds__(256) ri_apply_kernel(reins::Tree t, const uint
 
 // all boxes bottom-up over the links (one thread per leaf climbs; the second thread to reach a node fits it); COUNT: also the
 // number of leaves below every interior node
-template <bool COUNT>
+template <bool COUNT, bool BOXES = true>
 __global__ void ri_refit_kernel(reins::Tree t, uint32_t *visits, uint32_t *cnt) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k > t.n_int) return;
   uint32_t node = t.n_int + k, c = 1u;
   float lo[3], hi[3];
-  box_load<false>(t.bx, node, lo, hi);  // (leaf boxes were written by an earlier launch)
+  if (BOXES) box_load<false>(t.bx, node, lo, hi);  // (leaf boxes were written by an earlier launch)
   uint32_t p = t.par[node];
   while (p != kNone) {
     __threadfence();
     if (atomicAdd(&visits[p], 1u) == 0u) return;  // the sibling subtree is not done yet
     __threadfence();
     const uint32_t sib = reins::sibling(t, p, node);
-    float slo[3], shi[3];
-    box_load<true>(t.bx, sib, slo, shi);
-    for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], slo[a]); hi[a] = fmaxf(hi[a], shi[a]); }
-    box_store(t.bx, p, lo, hi);
+    if (BOXES) {
+      float slo[3], shi[3];
+      box_load<true>(t.bx, sib, slo, shi);
+      for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], slo[a]); hi[a] = fmaxf(hi[a], shi[a]); }
+      box_store(t.bx, p, lo, hi);
+    }
     if (COUNT) {
       c += sib >= t.n_int ? 1u : __hip_atomic_load(&cnt[sib], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cnt[p] = c;
@@ -481,39 +483,47 @@ __global__ void ri_refit_dirty_kernel(reins::Tree t, uint32_t *mark) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= t.n_int || !(mark[i] & kDirty)) return;
   auto dirty = [&](uint32_t c) { return c < t.n_int && (__hip_atomic_load(&mark[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kDirty) != 0u; };
-  uint32_t node = i, k0 = t.kid[2 * (size_t)i], k1 = t.kid[2 * (size_t)i + 1];
+  uint32_t node = i;
+  const uint32_t k0 = t.kid[2 * (size_t)i], k1 = t.kid[2 * (size_t)i + 1];
   if (dirty(k0) || dirty(k1)) return;  // (a thread from below arrives here later)
+  float lo[3], hi[3], slo[3], shi[3];
+  box_load<false>(t.bx, k0, lo, hi);  // (neither child's box changed in this pass)
+  box_load<false>(t.bx, k1, slo, shi);
   for (;;) {
-    float lo[3], hi[3], slo[3], shi[3];
-    box_load<true>(t.bx, k0, lo, hi);
-    box_load<true>(t.bx, k1, slo, shi);
     for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], slo[a]); hi[a] = fmaxf(hi[a], shi[a]); }
-    box_store(t.bx, node, lo, hi);
+    box_store(t.bx, node, lo, hi);  // (lo, hi) stays in registers: the parent is fitted from it and the sibling's box
     const uint32_t p = t.par[node];
     if (p == kNone) return;
-    k0 = t.kid[2 * (size_t)p];
-    k1 = t.kid[2 * (size_t)p + 1];
-    if (dirty(k0 == node ? k1 : k0)) {  // the sibling's subtree is being refitted too: the second to arrive goes on
+    const uint32_t sib = reins::sibling(t, p, node);
+    if (dirty(sib)) {
+      // the sibling's subtree is being refitted too: the first to arrive has published its box and stops, the second reads it
       __threadfence();
       if ((atomicAdd(&mark[p], 1u) & ~kDirty) == 0u) return;
       __threadfence();
+      box_load<true>(t.bx, sib, slo, shi);
     } else {
-      __threadfence();
+      box_load<false>(t.bx, sib, slo, shi);  // (untouched by this pass: no ordering to establish, a chain of one thread)
     }
     node = p;
   }
 }
 // The summed (half) surface area of the interior nodes in fixed point -- integers add up to the same sum in any order --, units of
 // 2^-se with the root's area below 2^40 units (find_move's scale): out[0] += the sum, out[1] = se + 1024.
-__global__ void ri_cost_kernel(reins::Tree t, unsigned long long *out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) ri_cost_kernel(reins::Tree t, unsigned long long *out) {
+  __shared__ unsigned long long s_sum[4];
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   int se = 0;
   (void)frexpf(reins::area(reins::load_box(t, 0u)), &se);
   se = 40 - se;
   se = se > 100 ? 100 : (se < -100 ? -100 : se);
   unsigned long long v = i < t.n_int ? (unsigned long long)(reins::area(reins::load_box(t, i)) * ldexpf(1.0f, se)) : 0ull;
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  if ((threadIdx.x & 63u) == 0u && v) atomicAdd(&out[0], v);
+  if ((threadIdx.x & 63u) == 0u) s_sum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    const unsigned long long b = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    if (b) atomicAdd(&out[0], b);
+  }
   if (i == 0u) out[1] = (unsigned long long)(se + 1024);
 }
 
@@ -962,7 +972,8 @@ hipError_t gpu_build_quads(const float *d_P, const uint32_t *d_idx, uint32_t n_t
       // child order, leaf counts, leaves renumbered in depth-first order, and back to the builder's arrays
       hipLaunchKernelGGL(ri_order_kernel, grid_i, block, 0, stream, t);
       GB_TRY(hipMemsetAsync(visits.p, 0, 4 * (size_t)n, stream));
-      hipLaunchKernelGGL(ri_refit_kernel<true>, grid_t, block, 0, stream, t, visits.as<uint32_t>(), cnt.as<uint32_t>());
+      // (the leaves below every node; the boxes are right already -- the last pass refitted what it moved)
+      hipLaunchKernelGGL((ri_refit_kernel<true, false>), grid_t, block, 0, stream, t, visits.as<uint32_t>(), cnt.as<uint32_t>());
       hipLaunchKernelGGL(ri_leafpos_kernel, grid_t, block, 0, stream, t, cnt.as<uint32_t>(), newslot.as<uint32_t>());
       hipLaunchKernelGGL(ri_emit_kernel, grid_i, block, 0, stream, t, newslot.as<uint32_t>(), child.as<uint32_t>(), par_i.as<uint32_t>(), par_l.as<uint32_t>());
       hipLaunchKernelGGL(ri_leaves_kernel, grid_t, block, 0, stream, t, newslot.as<uint32_t>(), d_order, order2.as<uint32_t>(), leaf_bx.as<unsigned long long>());
