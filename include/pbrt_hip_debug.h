@@ -57,9 +57,9 @@ int pbrt_hip_quad_build_host_ex(const float *P, uint32_t n_verts, const uint32_t
                                 uint32_t *order, float *root_box, uint32_t *n_refs, float *exact_boxes);
 
 /* ---- samplers: the reference holds the Sobol' generator matrices (sobolmatrices.rs:81) and no sampler ---- */
-/* host only: the generator matrices sampler 2 uses -- 32 dimensions x 32 columns, rows 0 .. 31 of the reference's
- * SOBOL_MATRICES32 (sobolmatrices.rs:81) -- for tests of that claim */
-void pbrt_hip_sobol_matrices(uint32_t *out_1024_words);
+/* host only: the generator matrices sampler 2 uses -- 128 dimensions x 32 columns, rows 0 .. 127 of the reference's
+ * SOBOL_MATRICES32 (sobolmatrices.rs:81), the first 32 of its 52 columns -- for tests of that claim */
+void pbrt_hip_sobol_matrices(uint32_t *out_4096_words);
 /* ---- the parser's state and its tokenizer alone (conformance tests replay parser.rs:778-880, api.rs:979-1045) ---- */
 /* CTM (current_transform[0].m) when parsing stopped, and the directive names stored by the option setters
  * (api.rs:778-820) as "camera sampler integrator filter accelerator film" */

@@ -97,19 +97,9 @@ class StratifiedSampler : public Sampler {
 // (m_i >> (i - 32) beyond column 32), with m_i = 2 a_1 m_{i-1} ^ 4 a_2 m_{i-2} ^ ... ^ 2^s m_{i-s} ^ m_{i-s}.
 // The same layout as the reference's SOBOL_MATRICES32 (sobolmatrices.rs:81: 52 columns per dimension), which a
 // test compares it with where the reference is mounted.
-struct JoeKuo { uint32_t s, a; uint32_t m[8]; };
-static const JoeKuo kJoeKuo[] = {  // dimensions 2 .. 32 (rows 1 .. 31 of the reference's table)
-    {1, 0, {1}}, {2, 1, {1, 3}}, {3, 1, {1, 3, 1}},
-    {3, 2, {1, 1, 1}}, {4, 1, {1, 1, 3, 3}}, {4, 4, {1, 3, 5, 13}},
-    {5, 2, {1, 1, 5, 5, 17}}, {5, 4, {1, 1, 5, 5, 5}}, {5, 7, {1, 1, 7, 11, 19}},
-    {5, 11, {1, 1, 5, 1, 1}}, {5, 13, {1, 1, 1, 3, 11}}, {5, 14, {1, 3, 5, 5, 31}},
-    {6, 1, {1, 3, 3, 9, 7, 49}}, {6, 13, {1, 1, 1, 15, 21, 21}}, {6, 16, {1, 3, 1, 13, 27, 49}},
-    {6, 19, {1, 1, 1, 15, 7, 5}}, {6, 22, {1, 3, 1, 15, 13, 25}}, {6, 25, {1, 1, 5, 5, 19, 61}},
-    {7, 1, {1, 3, 7, 11, 23, 15, 103}}, {7, 4, {1, 3, 7, 13, 13, 15, 69}}, {7, 7, {1, 1, 3, 13, 7, 35, 63}},
-    {7, 8, {1, 3, 5, 9, 1, 25, 53}}, {7, 14, {1, 3, 1, 13, 9, 35, 107}}, {7, 19, {1, 3, 1, 5, 27, 61, 31}},
-    {7, 21, {1, 1, 5, 11, 19, 41, 61}}, {7, 28, {1, 3, 5, 3, 3, 13, 69}}, {7, 31, {1, 1, 7, 13, 1, 19, 1}},
-    {7, 32, {1, 3, 7, 5, 13, 19, 59}}, {7, 37, {1, 1, 3, 9, 25, 29, 41}}, {7, 41, {1, 3, 5, 13, 23, 1, 55}},
-    {7, 42, {1, 3, 7, 3, 13, 59, 17}},
+struct JoeKuo { uint32_t s, a; uint32_t m[10]; };
+static const JoeKuo kJoeKuo[] = {  // dimensions 2 .. 128 (rows 1 .. 127 of the reference's table)
+#include "joe_kuo.inc"
 };
 constexpr int kSobolDims = 1 + (int)(sizeof(kJoeKuo) / sizeof(kJoeKuo[0]));
 constexpr int kSobolColumns = 52;
@@ -186,10 +176,11 @@ class SobolSampler : public Sampler {
 };
 
 // Sobol' sampler proper (Sampler "sobol"): request j of a sample takes ITS OWN pair of Sobol' dimensions
-// (2j, 2j + 1) for j = 0 .. 15 -- the first 32 dimensions, whose generator matrices are pinned to the reference's
+// (2j, 2j + 1) for j = 0 .. 63 -- the first 128 dimensions, whose generator matrices are pinned to the reference's
 // SOBOL_MATRICES32 (sobolmatrices.rs:81) -- at point index i = the sample number, each coordinate XOR-scrambled with mix32(key +
-// (d + 1) * 0x9e3779b9), d the dimension; later requests (j >= 16: beyond the fifth bounce of a path that samples a light and a
-// direction at every vertex) are the padded (0,2)-sequence requests of 3.10 with the same request counter.  Integer arithmetic only.
+// (d + 1) * 0x9e3779b9), d the dimension.  64 requests cover every request a path of maxdepth 16 can make (the camera sample, three
+// per vertex, the roulette from the fifth vertex on: 61); later requests are the padded (0,2)-sequence requests of 3.10 with the
+// same request counter.  Integer arithmetic only.
 class SobolNdSampler : public SobolSampler {
  public:
   SobolNdSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s, int pad_x = 0, int pad_y = 0) : SobolSampler(nx, ny, seed, s, pad_x, pad_y) {

@@ -238,8 +238,8 @@ def film_from_acc(acc):
 
 
 def sobol_matrices():
-    """pbrt_hip_sobol_matrices: (32, 32) uint32 generator matrices of sampler 2 (host only)"""
-    out = np.zeros((32, 32), np.uint32)
+    """pbrt_hip_sobol_matrices: (128, 32) uint32 generator matrices of sampler 2 (host only)"""
+    out = np.zeros((128, 32), np.uint32)
     lib().pbrt_hip_sobol_matrices(_u32p(out))
     return out
 

@@ -76,7 +76,7 @@ inline uint32_t sample_chunk_shift(uint32_t spp) {  // log2 K
 
 // Sampler 2: the first kSobolNdRequests requests of a sample take their own pair of Sobol' dimensions (host_math.hpp
 // builds the 2 x kSobolNdRequests generator matrices; capi.cpp asserts the two constants agree)
-constexpr uint32_t kSobolNdRequests = 16u;
+constexpr uint32_t kSobolNdRequests = 64u;
 
 struct RenderStackPlan {
   uint32_t rows;           // LDS rows per wave

@@ -101,23 +101,18 @@ inline uint8_t to_byte(float v) {
   return (uint8_t)q;
 }
 
-// Generator matrices of the first 32 Sobol' dimensions, 32 columns each: dimension 0 is the van der
-// Corput sequence (column b = bit 31 - b); dimension d >= 1 from the Joe-Kuo direction numbers (S. Joe, F. Y. Kuo 2008, table
-// new-joe-kuo-6: degree s, coefficient bits a, initial numbers m_1 .. m_s; m_i = XOR_{k=1..s-1} a_k 2^k m_{i-k} ^ 2^s m_{i-s} ^
-// m_{i-s}; column i = m_i << (32 - i)).  These are rows 0 .. 31 of the reference's SOBOL_MATRICES32 (sobolmatrices.rs:81, 52
-// columns per dimension, of which a 2^20-sample pixel needs 20); tests compare them with the oracle's own construction and,
-// where the reference is mounted, with its table.  Sampler 2 gives request j < kSobolNdDims / 2 the dimensions (2j, 2j + 1).
-constexpr int kSobolNdDims = 32;
+// Generator matrices of the first 128 Sobol' dimensions, 32 columns each: dimension 0 is the van der
+// Corput sequence (column b = bit 31 - b); dimension d >= 1 from the Joe-Kuo direction numbers (joe_kuo.inc: degree s, coefficient
+// bits a, initial numbers m_1 .. m_s; m_i = XOR_{k=1..s-1} a_k 2^k m_{i-k} ^ 2^s m_{i-s} ^ m_{i-s}; column i = m_i << (32 - i)).
+// These are rows 0 .. 127 of the reference's SOBOL_MATRICES32 (sobolmatrices.rs:81, 52 columns per dimension, of which a
+// 2^20-sample pixel needs 20); tests compare them with the oracle's own construction and, where the reference is mounted, with
+// its table.  Sampler 2 gives request j < kSobolNdDims / 2 the dimensions (2j, 2j + 1): 64 requests, every one a path of maxdepth
+// 16 can make.
+constexpr int kSobolNdDims = 128;
 inline void sobol_nd_matrices(uint32_t out[kSobolNdDims * 32]) {
-  static const struct { uint32_t s, a, m[7]; } jk[kSobolNdDims - 1] = {
-      {1, 0, {1}}, {2, 1, {1, 3}}, {3, 1, {1, 3, 1}}, {3, 2, {1, 1, 1}},
-      {4, 1, {1, 1, 3, 3}}, {4, 4, {1, 3, 5, 13}}, {5, 2, {1, 1, 5, 5, 17}}, {5, 4, {1, 1, 5, 5, 5}},
-      {5, 7, {1, 1, 7, 11, 19}}, {5, 11, {1, 1, 5, 1, 1}}, {5, 13, {1, 1, 1, 3, 11}}, {5, 14, {1, 3, 5, 5, 31}},
-      {6, 1, {1, 3, 3, 9, 7, 49}}, {6, 13, {1, 1, 1, 15, 21, 21}}, {6, 16, {1, 3, 1, 13, 27, 49}}, {6, 19, {1, 1, 1, 15, 7, 5}},
-      {6, 22, {1, 3, 1, 15, 13, 25}}, {6, 25, {1, 1, 5, 5, 19, 61}}, {7, 1, {1, 3, 7, 11, 23, 15, 103}}, {7, 4, {1, 3, 7, 13, 13, 15, 69}},
-      {7, 7, {1, 1, 3, 13, 7, 35, 63}}, {7, 8, {1, 3, 5, 9, 1, 25, 53}}, {7, 14, {1, 3, 1, 13, 9, 35, 107}}, {7, 19, {1, 3, 1, 5, 27, 61, 31}},
-      {7, 21, {1, 1, 5, 11, 19, 41, 61}}, {7, 28, {1, 3, 5, 3, 3, 13, 69}}, {7, 31, {1, 1, 7, 13, 1, 19, 1}}, {7, 32, {1, 3, 7, 5, 13, 19, 59}},
-      {7, 37, {1, 1, 3, 9, 25, 29, 41}}, {7, 41, {1, 3, 5, 13, 23, 1, 55}}, {7, 42, {1, 3, 7, 3, 13, 59, 17}}};
+  static const struct { uint32_t s, a, m[10]; } jk[kSobolNdDims - 1] = {
+#include "joe_kuo.inc"
+  };
   for (int b = 0; b < 32; b++) out[b] = 1u << (31 - b);
   for (int d = 1; d < kSobolNdDims; d++) {
     const uint32_t s = jk[d - 1].s, a = jk[d - 1].a;
