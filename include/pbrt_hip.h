@@ -88,13 +88,16 @@ typedef struct {
                                         child-pair records fetched, tris_tested = triangles tested */
 
 #define PBRT_HIP_SAMPLER_STRATIFIED 0 /* Sampler "stratified" (north_star's sampler) */
-#define PBRT_HIP_SAMPLER_SOBOL 1      /* Sampler "halton" / "02sequence" / "lowdiscrepancy": the (0,2)-sequence
-                                         sampler of DESIGN.md 3.10 (the reference holds only the names, api.rs:235, and the
-                                         generator matrices, sobolmatrices.rs:81) */
+#define PBRT_HIP_SAMPLER_SOBOL 1      /* Sampler "02sequence" / "lowdiscrepancy": the (0,2)-sequence sampler of DESIGN.md 3.10
+                                         (the reference holds only names, api.rs:235, and the generator matrices,
+                                         sobolmatrices.rs:81) */
 #define PBRT_HIP_SAMPLER_SOBOL_ND 2   /* Sampler "sobol": Sobol' proper -- request j of a sample takes its own dimensions (2j, 2j + 1)
                                          of the first 128 of the reference's table (sobolmatrices.rs:81): 64 requests, every one a
                                          path of maxdepth 16 can make; later requests the padded scheme of sampler 1 (DESIGN.md
                                          3.12).  Not with the counter flags, not with a box filter radius other than 0.5 */
+#define PBRT_HIP_SAMPLER_HALTON 3     /* Sampler "halton" -- the reference's DEFAULT sampler name (api.rs:235): scrambled radical
+                                         inverses in the prime bases 2 .. 719, request j of a sample on the dimensions (2j, 2j + 1)
+                                         for 64 requests.  Same restrictions as sampler 2 */
 #define PBRT_HIP_MAX_SPP (1u << 20)   /* spp_x * spp_y: the kernels pack the sample index into 20 bits */
 #define PBRT_HIP_MAX_DEPTH 1023u      /* max_depth: the bounce count is packed into 10 bits */
 

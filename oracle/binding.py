@@ -105,6 +105,7 @@ def lib(native=False):
         l.orc_sobol_dims.restype = C.c_int
         l.orc_sobol_matrix.argtypes = [C.c_int, C.c_void_p]
         l.orc_sobol_points.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        l.orc_halton_points.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         l.orc_quad_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
         _libs[native] = l
     return _libs[native]
@@ -137,6 +138,11 @@ def sobol_matrices():
     for d in range(n):
         lib().orc_sobol_matrix(d, _p(out[d]))
     return out
+
+
+def halton_points(d, key, n):
+    """(u float32[n], v uint32[n]): the Halton sampler's dimension d (base = the d-th prime) at point indices 0 .. n - 1 under `key`"""
+    u = np.zeros(n, np.float32); v = np.zeros(n, np.uint32); lib().orc_halton_points(d, key, n, _p(u), _p(v)); return u, v
 
 
 def sobol_points(n):
@@ -287,7 +293,7 @@ class OracleScene:
     def _rd(self, integrator, max_depth, spp, seed, rank, world_size, sampler=0, filter_width=None, max_sample_luminance=0.0):
         r = RenderDesc(); r.integrator = integrator; r.max_depth = max_depth; r.spp_x, r.spp_y = spp
         r.seed = seed; r.rank = rank; r.world_size = world_size
-        r.sampler = {"stratified": 0, "sobol": 1, "sobol_nd": 2}.get(sampler, sampler)
+        r.sampler = {"stratified": 0, "sobol": 1, "sobol_nd": 2, "halton": 3}.get(sampler, sampler)
         if filter_width is not None:
             r.filter_xwidth, r.filter_ywidth = filter_width
         r.max_sample_luminance = max_sample_luminance

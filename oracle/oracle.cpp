@@ -205,6 +205,67 @@ class SobolNdSampler : public SobolSampler {
   uint32_t m_[kSobolDims][kSobolColumns];
 };
 
+// Halton sampler proper (Sampler "halton", the reference's default sampler NAME, api.rs:235 -- it has no sampler
+// code): request j < 64 of a sample takes the dimensions (2j, 2j + 1), dimension d the radical inverse of the sample's number in
+// the pixel in base p_d (the d-th prime, 2 .. 719), every digit position scrambled per pixel and dimension.  Integer arithmetic
+// up to the last step:
+//   base 2 (d = 0):  v = bit-reversal of the index, XOR mix32(key + 0x9e3779b9);  u = v * 2^-32
+//   base b > 2:      K = the largest K with b^K < 2^32 digits a_0 .. a_{K-1} of the index (least significant first; the index is
+//                    below 2^20, higher digits are zeros and are scrambled like any other);
+//                    a'_k = (a_k m_k + c_k) mod b with h = mix32(key + (d + 1) 0x9e3779b9 + k 0x85ebca6b),
+//                    m_k = 1 + (((h & 0xffff) (b - 1)) >> 16), c_k = ((h >> 16) b) >> 16   (a random linear bijection of Z_b);
+//                    v = sum a'_k b^(K-1-k);  u = (float)v * (1 / (float)b^K)
+//   u = min(u, 1 - eps).  Requests j >= 64 are the padded requests of 3.10 (as for sampler 2).
+static const uint32_t *halton_primes() {
+  static uint32_t p[128];
+  if (!p[0]) {
+    int n = 0;
+    for (uint32_t c = 2; n < 128; c++) {
+      bool prime = true;
+      for (uint32_t q = 2; q * q <= c; q++) if (c % q == 0) { prime = false; break; }
+      if (prime) p[n++] = c;
+    }
+  }
+  return p;
+}
+class HaltonSampler : public SobolSampler {
+ public:
+  HaltonSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s, int pad_x = 0, int pad_y = 0) : SobolSampler(nx, ny, seed, s, pad_x, pad_y) {}
+  static uint32_t scrambled_radical_inverse(uint32_t d, uint32_t index, uint32_t key, float *u) {
+    const float one_minus_eps = 1.0f - std::numeric_limits<float>::epsilon();
+    const uint32_t b = halton_primes()[d];
+    uint32_t v = 0;
+    float f;
+    if (b == 2u) {
+      for (uint32_t k = 0; k < 32; k++) v |= ((index >> k) & 1u) << (31 - k);
+      v ^= mix32(key + (d + 1u) * 0x9e3779b9u);
+      f = (float)v * 2.3283064365386963e-10f;
+    } else {
+      uint32_t K = 0;
+      uint64_t bk = 1;
+      while (bk * b < (1ull << 32)) { bk *= b; K++; }
+      uint32_t n = index;
+      for (uint32_t k = 0; k < K; k++) {
+        const uint32_t a = n % b;
+        n /= b;
+        const uint32_t h = mix32(key + (d + 1u) * 0x9e3779b9u + k * 0x85ebca6bu);
+        const uint32_t m = 1u + (((h & 0xffffu) * (b - 1u)) >> 16), c = ((h >> 16) * b) >> 16;
+        v = v * b + (a * m + c) % b;
+      }
+      f = (float)v * (1.0f / (float)(uint32_t)bk);
+    }
+    *u = f > one_minus_eps ? one_minus_eps : f;
+    return v;
+  }
+  void Get2D(float *u1, float *u2) override {
+    if (j_ >= 64u) { SobolSampler::Get2D(u1, u2); return; }
+    const uint32_t d0 = 2u * j_;
+    j_++;
+    scrambled_radical_inverse(d0, s_, key_, u1);
+    scrambled_radical_inverse(d0 + 1u, s_, key_, u2);
+  }
+};
+
 // pbrt-v3 ConcentricSampleDisk with the fixed polynomials instead of libm sin/cos
 static inline void concentric_sample_disk(float u1, float u2, float *dx, float *dy) {
   float ox = 2.0f * u1 - 1.0f;
@@ -471,7 +532,8 @@ static void render_pixel_wide(const Scene &s, const PathIntegrator &integ, const
   StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
   SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
   SobolNdSampler sobol_nd(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
-  Sampler &sampler = r.sampler == 2 ? (Sampler &)sobol_nd : (r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat);
+  HaltonSampler halton(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
+  Sampler &sampler = r.sampler == 3 ? (Sampler &)halton : (r.sampler == 2 ? (Sampler &)sobol_nd : (r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat));
   const int W = s.cropped[2] - s.cropped[0];
   for (uint32_t c = 0, n_chunks = sample_chunks(r.spp_x * r.spp_y); c < n_chunks; c++)
     for (sampler.StartChunk(x, y, c); !sampler.ChunkDone(); sampler.StartNextSample()) {
@@ -504,7 +566,8 @@ static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_
   StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s);
   SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s);
   SobolNdSampler sobol_nd(r.spp_x, r.spp_y, r.seed, s);
-  Sampler &sampler = r.sampler == 2 ? (Sampler &)sobol_nd : (r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat);
+  HaltonSampler halton(r.spp_x, r.spp_y, r.seed, s);
+  Sampler &sampler = r.sampler == 3 ? (Sampler &)halton : (r.sampler == 2 ? (Sampler &)sobol_nd : (r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat));
   Vec3 sum = {0, 0, 0};
   uint32_t i = 0;
   for (uint32_t c = 0, n_chunks = sample_chunks(r.spp_x * r.spp_y); c < n_chunks; c++) {
@@ -537,6 +600,10 @@ struct orc_scene {
 extern "C" {
 
 int orc_sobol_dims(void) { return kSobolDims; }
+// Halton sampler: u and the integer numerator of dimension d for indices 0 .. n - 1 under `key` (tests of the radical inverse)
+void orc_halton_points(uint32_t d, uint32_t key, uint32_t n, float *u, uint32_t *v) {
+  for (uint32_t i = 0; i < n; i++) v[i] = HaltonSampler::scrambled_radical_inverse(d, i, key, &u[i]);
+}
 void orc_sobol_matrix(int dim, uint32_t *out52) { sobol_matrix(dim, out52); }
 void orc_sobol_points(uint32_t key_seed, uint32_t n, float *out2n) {
   // the first n points of the unscrambled (0,2)-sequence (dimensions 1 and 2), for the net-property test
@@ -702,7 +769,7 @@ void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int
 // fixed-point accumulators of DESIGN.md 3.11 over the sample bounds
 static int render_any(const orc_scene *sc, const orc_render_desc *r, float *film, int64_t *acc, orc_stats *out, int n_threads) {
   const Scene &s = sc->s;
-  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 2) return -1;
+  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 3) return -1;
   if (!(filter_radius(r->filter_xwidth) > 0.f) || !(filter_radius(r->filter_ywidth) > 0.f)) return -1;
   PathIntegrator integ(s, r->max_depth, r->integrator == 1);
   const WideFilter wf = wide_filter(s, *r);

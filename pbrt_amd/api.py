@@ -101,7 +101,7 @@ def fill_desc(desc, sd, mat_t, light_t, sphere_t):
     return [mats, lights, spheres, sd]
 
 
-SAMPLERS = {"stratified": 0, "sobol": 1, "sobol_nd": 2}  # "sobol": the padded (0,2)-sequence sampler (3.10); "sobol_nd": Sobol' proper (3.12)
+SAMPLERS = {"stratified": 0, "sobol": 1, "sobol_nd": 2, "halton": 3}  # "sobol": the padded (0,2)-sequence sampler (3.10); "sobol_nd": Sobol' proper (3.12); "halton": 3.13
 
 
 def make_render_desc(desc_t, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,

@@ -1023,9 +1023,11 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (r->spp_x == 0 || r->spp_y == 0) return fail(PBRT_HIP_ERR_INVALID, "render: spp_x and spp_y must be >= 1");
   if (r->world_size == 0 || r->rank >= r->world_size) return fail(PBRT_HIP_ERR_INVALID, "render: rank must be < world_size");
   if (r->integrator > 1) return fail(PBRT_HIP_ERR_INVALID, "render: unknown integrator");
-  if (r->sampler > PBRT_HIP_SAMPLER_SOBOL_ND) return fail(PBRT_HIP_ERR_INVALID, "render: unknown sampler");
-  if (r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
-    return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags are not available with the Sobol' sampler (sampler 2)");
+  if (r->sampler > PBRT_HIP_SAMPLER_HALTON) return fail(PBRT_HIP_ERR_INVALID, "render: unknown sampler");
+  // (samplers 2 and 3 -- Sobol' proper and Halton -- share one instantiation of the kernel: "the table samplers")
+  const bool table_sampler = r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND || r->sampler == PBRT_HIP_SAMPLER_HALTON;
+  if (table_sampler && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
+    return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags are not available with the Sobol' / Halton samplers (samplers 2, 3)");
   // the kernels pack the sample index into 20 bits and the bounce count into 10 (kernels.hip path_store): beyond that a
   // persistent wave would never see its pixel finish
   if ((uint64_t)r->spp_x * (uint64_t)r->spp_y > PBRT_HIP_MAX_SPP)
@@ -1037,8 +1039,8 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (fx > 16.f || fy > 16.f) return fail(PBRT_HIP_ERR_LIMIT, "render: filter radius above 16 pixels");
   if ((fx != 0.5f || fy != 0.5f) && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
     return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags need the default box filter (radius 0.5)");
-  if ((fx != 0.5f || fy != 0.5f) && r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND)
-    return fail(PBRT_HIP_ERR_LIMIT, "render: the Sobol' sampler (sampler 2) with a box filter radius other than 0.5 is not instantiated");
+  if ((fx != 0.5f || fy != 0.5f) && table_sampler)
+    return fail(PBRT_HIP_ERR_LIMIT, "render: the Sobol' / Halton samplers (2, 3) with a box filter radius other than 0.5 are not instantiated");
   if (!(r->max_sample_luminance >= 0.f)) return fail(PBRT_HIP_ERR_INVALID, "render: max_sample_luminance must be >= 0 (0 = none)");
   if (fx != 0.5f || fy != 0.5f) {
     // the fixed-point film: a sample adds at most 2^39 units to a pixel's int64 accumulator, and a pixel receives
@@ -1072,10 +1074,17 @@ int ensure_render_scratch(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, cons
   out->n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
   if (r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND && s->d_sobol.n == 0) {
     static_assert(kSobolNdDims == 2 * (int)kSobolNdRequests, "sampler 2: two dimensions per request");
-    uint32_t mat[kSobolNdDims * 32];
-    sobol_nd_matrices(mat);
-    HIP_TRY(s->d_sobol.alloc(kSobolNdDims * 32));
-    HIP_TRY(hipMemcpy(s->d_sobol.p, mat, sizeof(mat), hipMemcpyHostToDevice));
+    std::vector<uint32_t> mat((size_t)kSobolNdDims * 32);
+    sobol_nd_matrices(mat.data());
+    HIP_TRY(s->d_sobol.alloc(mat.size()));
+    HIP_TRY(hipMemcpy(s->d_sobol.p, mat.data(), mat.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (r->sampler == PBRT_HIP_SAMPLER_HALTON && s->d_halton.n == 0) {
+    static_assert(kHaltonDims == 2 * (int)kSobolNdRequests, "sampler 3: two dimensions per request, as many requests as sampler 2");
+    uint32_t tab[kHaltonDims * 4];
+    halton_table(tab);
+    HIP_TRY(s->d_halton.alloc(kHaltonDims * 4));
+    HIP_TRY(hipMemcpy(s->d_halton.p, tab, sizeof(tab), hipMemcpyHostToDevice));
   }
   {
     // float4 records: 5 x 64 per one-wave workgroup (kernels.hip LaneRecords); with another box filter radius 16 x 2 x 64 more
@@ -1131,11 +1140,11 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     R.max_lum = r->max_sample_luminance > 0.f ? r->max_sample_luminance : std::numeric_limits<float>::infinity();
     R.filter_rx = fg.rx; R.filter_ry = fg.ry;
     R.acc = fg.wide ? (unsigned long long *)d_slab : nullptr;
-    const bool sobol_nd = r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND;
+    const bool sobol_nd = r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND || r->sampler == PBRT_HIP_SAMPLER_HALTON;  // the table samplers' instantiation
     RenderScratch rs;
     rc = ensure_render_scratch(s, r, fg, sh, &rs);  // (no allocation when pbrt_hip_render_prepare ran for this description, or an earlier frame did)
     if (rc) return rc;
-    R.sobol_mat = sobol_nd ? s->d_sobol.p : nullptr;
+    R.sobol_mat = r->sampler == PBRT_HIP_SAMPLER_HALTON ? s->d_halton.p : (sobol_nd ? s->d_sobol.p : nullptr);
     R.integrator = r->integrator;
     R.max_depth = r->max_depth;
     R.spp_x = r->spp_x;

@@ -69,6 +69,7 @@ struct pbrt_hip_scene {
   pbrt_hip::DevScene dev_exact{};
   bool canonical_ready = false;
   pbrt_hip::DevBuf<uint32_t> d_sobol;  // generator matrices of sampler 2 (uploaded at its first use)
+  pbrt_hip::DevBuf<uint32_t> d_halton; // per-dimension table of sampler 3 (likewise)
   pbrt_hip::DevBuf<float4> d_tris_exact;
   pbrt_hip::DevBuf<uint32_t> d_order_exact;
   double canonical_build_ms = 0.0;
@@ -84,7 +85,7 @@ struct pbrt_hip_scene {
     d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release(); d_quads.release(); d_stack_overflow.release();
     d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
     d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release(); d_partials.release();
-    d_tris_exact.release(); d_order_exact.release(); d_sobol.release();
+    d_tris_exact.release(); d_order_exact.release(); d_sobol.release(); d_halton.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);

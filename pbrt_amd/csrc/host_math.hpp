@@ -128,4 +128,28 @@ inline void sobol_nd_matrices(uint32_t out[kSobolNdDims * 32]) {
   }
 }
 
+// The Halton sampler's table, four words per dimension d < 128: {base b = the d-th prime, K = the largest K with
+// b^K < 2^32 (32 for b = 2), ceil(2^32 / b), the bits of the float 1 / (float)b^K}.  The kernel's digit loop divides by b with the
+// reciprocal (kernels.hip halton_dim); the oracle divides (oracle.cpp HaltonSampler).
+constexpr int kHaltonDims = 128;
+inline void halton_table(uint32_t out[kHaltonDims * 4]) {
+  int n = 0;
+  for (uint32_t c = 2; n < kHaltonDims; c++) {
+    bool prime = true;
+    for (uint32_t q = 2; q * q <= c; q++) if (c % q == 0) { prime = false; break; }
+    if (!prime) continue;
+    uint32_t K = 0;
+    uint64_t bk = 1;
+    while (bk * c < (1ull << 32)) { bk *= c; K++; }
+    const float inv = c == 2u ? 2.3283064365386963e-10f : 1.0f / (float)(uint32_t)bk;
+    uint32_t bits;
+    std::memcpy(&bits, &inv, 4);
+    out[4 * n] = c;
+    out[4 * n + 1] = c == 2u ? 32u : K;
+    out[4 * n + 2] = (uint32_t)(((1ull << 32) + c - 1u) / c);
+    out[4 * n + 3] = bits;
+    n++;
+  }
+}
+
 }  // namespace pbrt_hip

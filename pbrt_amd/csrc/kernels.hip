@@ -732,11 +732,45 @@ __device__ __forceinline__ uint32_t mix32(uint32_t v) {  // lowbias32
 // (Joe-Kuo s = 1, a = 0, m = 1) -- XOR-scrambled with keys hashed from the pixel and the request number j.
 // SND (sampler 2): requests 0 .. 15 of a sample take their own Sobol' dimensions (2j, 2j + 1) from the
 // generator matrices in `mat` at point index s, XOR-scrambled per dimension; later requests are the padded ones below.
+// Sampler 3: dimension d of the Halton sampler at point index i under the pixel's key: the radical inverse of i in
+// base b = the d-th prime with every digit scrambled by a random linear bijection of Z_b.  tab = {b, K, ceil(2^32 / b), bits of
+// 1 / b^K} (host_math.hpp halton_table); n / b by the reciprocal: the estimate is the quotient or one more.
+__device__ __forceinline__ float halton_dim(const uint32_t *tab, uint32_t d, uint32_t i, uint32_t key) {
+  const uint4 t = reinterpret_cast<const uint4 *>(tab)[d];
+  const uint32_t b = t.x, salt = key + (d + 1u) * 0x9e3779b9u;
+  uint32_t v = 0u;
+  if (b == 2u) {
+    v = __builtin_bitreverse32(i) ^ mix32(salt);
+  } else {
+    uint32_t n = i;
+    for (uint32_t k = 0u; k < t.y; k++) {
+      uint32_t q = __umulhi(n, t.z);
+      if (q * b > n) q--;
+      const uint32_t a = n - q * b;
+      n = q;
+      const uint32_t h = mix32(salt + k * 0x85ebca6bu);
+      const uint32_t w = a * (1u + (((h & 0xffffu) * (b - 1u)) >> 16)) + (((h >> 16) * b) >> 16);  // a m + c < b^2
+      uint32_t wq = __umulhi(w, t.z);
+      if (wq * b > w) wq--;
+      v = v * b + (w - wq * b);
+    }
+  }
+  return fminf(kOneMinusEps, (float)v * __uint_as_float(t.w));
+}
+// HAL (with SND): the table sampler in use is the Halton one (sampler 3), `mat` its table
 template <bool SND = false>
-__device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const uint32_t spp_mask, float &u1, float &u2, const uint32_t *mat = nullptr) {
+__device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const uint32_t spp_mask, float &u1, float &u2, const uint32_t *mat = nullptr,
+                                          const bool halton = false) {
   if (!sobol) {
     u1 = pcg_float(P.rng);
     u2 = pcg_float(P.rng);
+    return;
+  }
+  if (SND && halton && (uint32_t)(P.rng.state >> 32) < kSobolNdRequests) {
+    const uint32_t key = (uint32_t)P.rng.state, d0 = 2u * (uint32_t)(P.rng.state >> 32);
+    P.rng.state += 1ull << 32;  // next request
+    u1 = halton_dim(mat, d0, P.s, key);
+    u2 = halton_dim(mat, d0 + 1u, P.s, key);
     return;
   }
   if (SND && (uint32_t)(P.rng.state >> 32) < kSobolNdRequests) {
@@ -772,10 +806,15 @@ __device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const 
   u2 = fminf(kOneMinusEps, (float)y * 2.3283064365386963e-10f);
 }
 template <bool SND = false>
-__device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const uint32_t spp_mask, const uint32_t *mat = nullptr) {
+__device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const uint32_t spp_mask, const uint32_t *mat = nullptr, const bool halton = false) {
   if (!sobol) return pcg_float(P.rng);
+  if (SND && halton && (uint32_t)(P.rng.state >> 32) < kSobolNdRequests) {  // (a 1-D request takes the first coordinate of its pair)
+    const float u = halton_dim(mat, 2u * (uint32_t)(P.rng.state >> 32), P.s, (uint32_t)P.rng.state);
+    P.rng.state += 1ull << 32;
+    return u;
+  }
   float u1, u2;
-  sample_2d<SND>(P, true, spp_mask, u1, u2, mat);
+  sample_2d<SND>(P, true, spp_mask, u1, u2, mat, halton);
   return u1;
 }
 
@@ -844,7 +883,8 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
   auto slab_pos = [](uint32_t q) {
     return (size_t)(q >> 12) * 4096u + (((q >> 9) & 7u) * 8u + ((q >> 3) & 7u)) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u);
   };
-  const bool sobol = SND ? true : R.sampler == 1u;  // (both low-discrepancy samplers keep {pixel key, request counter} in rng.state)
+  const bool sobol = SND ? true : R.sampler == 1u;  // (the low-discrepancy samplers keep {pixel key, request counter} in rng.state)
+  const bool halton = SND && R.sampler == 3u;       // (samplers 2 and 3 share the SND instantiations: R.sobol_mat is the one's matrices or the other's table)
   const uint32_t spp = R.spp_x * R.spp_y;
   const uint32_t spp_mask = R.spp_mask;  // Sobol: 2^ceil(log2 spp) - 1
   const uint32_t nL = S.n_lights;
@@ -941,9 +981,9 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
             bool alive = true;
             if (__float_as_uint(m0.x) == 0u) {  // matte
               if (nL > 0u) {
-                const float xi = sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat);
+                const float xi = sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat, halton);
                 float u1, u2;
-                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat);
+                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat, halton);
                 uint32_t li = (uint32_t)(xi * nLf);
                 li = min(li, nL - 1u);
                 V3 Ld;
@@ -958,7 +998,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
                 alive = false;
               } else {
                 float u1, u2;
-                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat);
+                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat, halton);
                 const float z = cosine_about(nf, u1, u2, P.wi_next);
                 EXP_DEBUG_PIXEL("HIP s %u   cos u1 %a u2 %a z %a nf %a %a %a wi %a %a %a\n", P.s, u1, u2, z, nf.x, nf.y, nf.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
                 if (z == 0.f) alive = false;
@@ -974,7 +1014,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
             if (alive && P.bounces > 3u) {
               const float mx = fmaxf(P.beta.x, fmaxf(P.beta.y, P.beta.z));
               const float q = fmaxf(0.05f, 1.0f - mx);
-              if (sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat) < q) alive = false;
+              if (sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat, halton) < q) alive = false;
               else P.beta = P.beta / (1.0f - q);
             }
             P.cont = alive;
@@ -1161,7 +1201,7 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
         if (true) {
           // stratified camera sample and PerspectiveCamera ray (3.2)
           float u1, u2;
-          sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat);
+          sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat, halton);
           float jx = u1, jy = u2;  // Sobol: the (0,2)-net point is the film offset
           if (!sobol) {
             // P.s / spp_x by R.spp_x_recip = ceil(2^32 / spp_x): the estimate is the quotient or one more

@@ -762,17 +762,18 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
           out->spp_y = (uint32_t)std::max(1, ps.one_int("ysamples", 4));
           ps.find("jitter", "bool"); ps.find("dimensions", "integer");
         } else {
-          // the low-discrepancy names ("halton" is the reference's default, api.rs:235; it ships Sobol' matrices,
-          // sobolmatrices.rs:81, and no sampler) are served by the padded (0,2)-sequence sampler of DESIGN.md 3.10,
-          // "random" and anything unknown by the stratified one; pixelsamples = spp_x * spp_y either way
+          // "halton" (the reference's default name, api.rs:235) and "sobol" have samplers of their own; the
+          // other low-discrepancy names are served by the padded (0,2)-sequence sampler of 3.10, "random" and anything unknown
+          // by the stratified one; pixelsamples = spp_x * spp_y either way
           auto s = strata_for(ps.one_int("pixelsamples", 16));
           out->spp_x = s.first; out->spp_y = s.second;
           if (name == "sobol") {
             out->sampler = PBRT_HIP_SAMPLER_SOBOL_ND;  // Sobol' proper: own dimensions per request
-          } else if (name == "halton" || name == "02sequence" || name == "lowdiscrepancy" || name == "zerotwosequence" || name == "maxmindist") {
+          } else if (name == "halton") {
+            out->sampler = PBRT_HIP_SAMPLER_HALTON;    // the reference's default name (api.rs:235): scrambled radical inverses
+          } else if (name == "02sequence" || name == "lowdiscrepancy" || name == "zerotwosequence" || name == "maxmindist") {
             out->sampler = PBRT_HIP_SAMPLER_SOBOL;
-            if (name != "02sequence" && name != "lowdiscrepancy" && name != "zerotwosequence")
-              api.warn("Sampler \"" + name + "\": served by the (0,2)-sequence (Sobol') sampler");
+            if (name == "maxmindist") api.warn("Sampler \"" + name + "\": served by the (0,2)-sequence (Sobol') sampler");
           } else {
             out->sampler = PBRT_HIP_SAMPLER_STRATIFIED;
             if (name != "random") api.warn("Sampler \"" + name + "\" is unknown: the stratified sampler is used");

@@ -79,7 +79,7 @@ struct LoadedScene {
   uint32_t integrator = PBRT_HIP_INTEGRATOR_PATH, max_depth = 5, spp_x = 4, spp_y = 4;
   float max_sample_luminance = 0.f;  // Film "float maxsampleluminance" (film.rs:75,279); 0 = none
   float film_scale = 1.f;  // Film "float scale" (film.rs:368-371), exported by pbrt_hip_loaded_film_scale
-  uint32_t sampler = PBRT_HIP_SAMPLER_SOBOL;  // the default sampler name is "halton" (api.rs:235): a low-discrepancy sampler, see scene_parser.cpp "Sampler"
+  uint32_t sampler = PBRT_HIP_SAMPLER_HALTON;  // the default sampler name is "halton" (api.rs:235): DESIGN.md 3.13, see scene_parser.cpp "Sampler"
   bool world_ended = false;
   float final_ctm[16];  // CTM when parsing stopped (for the state-machine tests)
   std::vector<std::string> warnings;

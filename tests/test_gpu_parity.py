@@ -551,7 +551,7 @@ def test_native_cli_renders_c0(gpu, tmp_path):
     from pbrt_amd import loader
     ls = loader.load_string(scene.read_text())
     with gpu.Scene(ls.scene) as sc:
-        kw = dict(ls.render_kwargs(), spp=(ls.spp[0] // 2, ls.spp[1] // 2))  # --quick; Sampler "halton" -> the (0,2)-sequence sampler
+        kw = dict(ls.render_kwargs(), spp=(ls.spp[0] // 2, ls.spp[1] // 2))  # --quick; Sampler "halton" -> sampler 3
         film, _ = sc.render(**kw)
     assert_bit_equal(img, gpu.film_to_rgb(film, scale=ls.film_scale), "CLI image vs library render")  # PFM is lossless
     # the CLI renders through pbrt_hip_render_multi on every visible GPU; --gpus 1 must give the same image
@@ -931,8 +931,10 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     with gpu.Scene(sd, builder="gpu" if seed % 3 == 1 else "host") as sc:
         parts = sum(sc.render_acc(fw, rank=r, world_size=world, **kw)[0] for r in range(world))
         nd, _ = sc.render(**dict(kw, sampler="sobol_nd"))
+        hal, _ = sc.render(**dict(kw, sampler="halton"))
     assert np.array_equal(parts, o.render_acc(fw, **kw)[0]), f"random scene {seed}: accumulators, box filter {fw}, {world} ranks, clamp {ml}"
     assert_bit_equal(nd, o.render(**dict(kw, sampler="sobol_nd"))[0], f"random scene {seed}: sampler 2")
+    assert_bit_equal(hal, o.render(**dict(kw, sampler="halton"))[0], f"random scene {seed}: sampler 3")
 
 
 @pytest.mark.timeout(900)
@@ -1170,13 +1172,15 @@ def test_wide_box_filter_in_one_process_multi_gpu_and_scene_file(gpu, oracle):
 @pytest.mark.parametrize("name,integrator,depth,spp,seed", [
     ("mesh1k", INTEGRATOR_PATH, 8, (4, 4), 3), ("cornell", INTEGRATOR_PATH, 12, (9, 8), 1), ("check_sphere", INTEGRATOR_PATH, 5, (2, 2), 9),
     ("sphere", INTEGRATOR_DIRECT, 5, (4, 2), 0), ("deep", INTEGRATOR_PATH, 6, (2, 2), 6), ("mesh20k", INTEGRATOR_PATH, 8, (5, 3), 2)])
-def test_sobol_nd_sampler_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed):
+@pytest.mark.parametrize("sampler", ["sobol_nd", "halton"])
+def test_sobol_nd_sampler_matches_oracle(gpu, oracle, name, integrator, depth, spp, seed, sampler):
     """Sampler "sobol" (sampler 2): every request of a sample takes its own pair of Sobol' dimensions from
     the generator matrices (rows of the reference's SOBOL_MATRICES32), later requests fall back to the padded scheme: integer
     arithmetic, so the film equals the oracle's bit for bit -- sphere and triangle kernels, LDS and overflow stacks, a
-    non-power-of-two sample count, three ranks."""
+    non-power-of-two sample count, three ranks.  Sampler "halton" (sampler 3, 3.13: scrambled radical inverses in 128 prime
+    bases; the kernel divides by reciprocals where the oracle divides) in the same instantiations of the kernel, likewise."""
     sd = SMALL_SCENES[name]()
-    kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=seed, sampler="sobol_nd")
+    kw = dict(integrator=integrator, max_depth=depth, spp=spp, seed=seed, sampler=sampler)
     ref, _ = oracle.OracleScene(sd).render(**kw)
     with gpu.Scene(sd) as sc:
         film, _ = sc.render(**kw)
@@ -1187,6 +1191,20 @@ def test_sobol_nd_sampler_matches_oracle(gpu, oracle, name, integrator, depth, s
                 sc.render(**dict(kw, **bad))
             assert e.value.code == code
         other, _ = sc.render(**dict(kw, sampler="sobol"))
-    assert_bit_equal(film, ref, f"{name} film, sampler 2")
+    assert_bit_equal(film, ref, f"{name} film, sampler {sampler}")
     assert_bit_equal(acc, ref, "three ranks")
     assert not np.array_equal(other, film)
+
+
+def test_table_samplers_on_a_long_path(gpu, oracle):
+    """maxdepth 16 in a closed Cornell-style box (BASELINE C4's scene and depth): a path makes up to 61 requests, every one of which
+    has its own dimensions in samplers 2 and 3 since round 5 (64 requests: 128 Sobol' dimensions / 128 prime bases) -- films equal
+    to the oracle's, and maxdepth 40 runs past the tables into the padded requests."""
+    sd = scenes.cornell_scene(40, 24)
+    for sampler in ("sobol_nd", "halton"):
+        for depth in (16, 40):
+            kw = dict(max_depth=depth, spp=(8, 8), seed=11, sampler=sampler)
+            ref, _ = oracle.OracleScene(sd).render(**kw)
+            with gpu.Scene(sd) as sc:
+                film, _ = sc.render(**kw)
+            assert_bit_equal(film, ref, f"{sampler}, maxdepth {depth}")
