@@ -826,6 +826,14 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     }
   }
   if (p.err != ParseError::None) return fin(false);
+  // A box filter radius other than 0.5 takes the fixed-point film path, which is instantiated for the stratified and
+  // the (0,2)-sequence sampler only: a scene that asks for the Halton sampler (or leaves the default) or for Sobol' with such a filter
+  // is rendered with the (0,2)-sequence sampler -- said, not refused (api.rs:291-332: log and continue).
+  if ((out->sampler == PBRT_HIP_SAMPLER_HALTON || out->sampler == PBRT_HIP_SAMPLER_SOBOL_ND) &&
+      !((out->filter_radius[0] == 0.5f || out->filter_radius[0] == 0.f) && (out->filter_radius[1] == 0.5f || out->filter_radius[1] == 0.f))) {
+    api.warn("Sampler \"" + out->sampler_name + "\" with a box filter radius other than 0.5: served by the (0,2)-sequence (Sobol') sampler");
+    out->sampler = PBRT_HIP_SAMPLER_SOBOL;
+  }
   if (!api.camera_set) mat_identity(out->cam_to_world);
   return fin(true);
 }
