@@ -46,8 +46,19 @@ typedef struct {
   float k[3];
   float le[3]; /* emitted radiance; non-zero turns every triangle using it into an area light
                   (replaces api.rs:476-478 area_light_source -> todo!()) */
-  float pad;
+  uint32_t kd_tex; /* matte only: 0 = Kd is k; t > 0 = Kd is textures[t - 1] evaluated at the hit's (u, v) -- on triangles; a
+                      sphere keeps k, which the parser sets to the mean of the texture's colours ("texture Kd": check-sphere.pbrt:26) */
 } pbrt_hip_material;
+
+/* Texture "name" "spectrum" "checkerboard" (check-sphere.pbrt:24-25; the reference: api.rs:524-580 stores nothing, texture.rs is an
+ * empty marker): pbrt-v3's Checkerboard2DTexture over a UVMapping2D, point-sampled (aamode "none": no ray differentials here):
+ * (s, t) = (su u + du, sv v + dv); tex1 where floor(s) + floor(t) is even, tex2 where odd.  64 bytes. */
+typedef struct {
+  uint32_t type;  /* 0 = checkerboard, dimension 2, "uv" mapping */
+  float tex1[3], tex2[3];
+  float su, sv, du, dv; /* "float uscale" / "vscale" / "udelta" / "vdelta" */
+  uint32_t pad[5];
+} pbrt_hip_texture;
 
 /* LightSource "point" / "distant" / "infinite" (api.rs:334-351 make_light: todo!() for all). */
 typedef struct {
@@ -78,6 +89,12 @@ typedef struct {
   float fov;              /* Camera "perspective" "float fov" (degrees, shorter axis) */
   int32_t xres, yres;     /* Film "integer xresolution" / "yresolution" */
   float crop[4];          /* Film "float cropwindow" x0 x1 y0 y1 (film.rs:92-101) */
+  /* textured materials (all three may be 0 / NULL): */
+  const float *tri_uv;    /* 6 * n_tris: (u, v) of the three corners of every triangle -- Shape "trianglemesh" "float st" / "uv"
+                             (check-sphere.pbrt:31), or pbrt-v3's default (0,0) (1,0) (1,1) for a mesh without them.  Needed
+                             (PBRT_HIP_ERR_INVALID otherwise) when a material of a triangle has kd_tex != 0 */
+  const pbrt_hip_texture *textures;
+  uint32_t n_textures;
 } pbrt_hip_scene_desc;
 
 #define PBRT_HIP_INTEGRATOR_PATH 0   /* Integrator "path" (default name, api.rs:239) */

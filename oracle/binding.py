@@ -14,7 +14,12 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 
 
 class Material(C.Structure):
-    _fields_ = [("type", C.c_uint32), ("k", C.c_float * 3), ("le", C.c_float * 3), ("pad", C.c_float)]
+    _fields_ = [("type", C.c_uint32), ("k", C.c_float * 3), ("le", C.c_float * 3), ("kd_tex", C.c_uint32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("tex1", C.c_float * 3), ("tex2", C.c_float * 3), ("su", C.c_float), ("sv", C.c_float),
+                ("du", C.c_float), ("dv", C.c_float), ("pad", C.c_uint32 * 5)]
 
 
 class Light(C.Structure):
@@ -33,6 +38,7 @@ class SceneDesc(C.Structure):
         ("n_spheres", C.c_uint32),
         ("cam_to_world", C.c_float * 16), ("fov", C.c_float), ("xres", C.c_int32), ("yres", C.c_int32),
         ("crop", C.c_float * 4),
+        ("tri_uv", C.POINTER(C.c_float)), ("textures", C.POINTER(Texture)), ("n_textures", C.c_uint32),
     ]
 
 
@@ -252,7 +258,7 @@ class OracleScene:
         self.l = lib(native)
         self.sd = sd.normalized()
         desc = SceneDesc()
-        keep = fill_desc(desc, self.sd, Material, Light, Sphere)
+        keep = fill_desc(desc, self.sd, Material, Light, Sphere, Texture)
         self.h = self.l.orc_scene_create(C.byref(desc))
         del keep
 

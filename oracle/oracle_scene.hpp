@@ -77,6 +77,8 @@ class Scene {
   std::vector<uint32_t> idx;
   std::vector<uint16_t> mat_id;
   std::vector<orc_material> mats;
+  std::vector<orc_texture> textures;
+  std::vector<float> tri_uv;          // 6 per triangle (corner u, v), or empty
   std::vector<orc_sphere> spheres;
   std::vector<LightRec> lights;
   Vec3 le_infinite{0, 0, 0};

@@ -32,8 +32,15 @@ typedef struct {
   uint32_t type;  /* 0 = matte, 1 = mirror */
   float k[3];     /* Kd (matte) or Kr (mirror) */
   float le[3];    /* emitted radiance (one-sided, along the geometric normal) */
-  float pad;
+  uint32_t kd_tex; /* matte: 0 = Kd is k, t > 0 = textures[t - 1] at the hit's (u, v) on triangles */
 } orc_material;
+
+typedef struct {
+  uint32_t type;  /* 0 = checkerboard 2D over (u, v): pbrt-v3 Checkerboard2DTexture, aamode none */
+  float tex1[3], tex2[3];
+  float su, sv, du, dv;
+  uint32_t pad[5];
+} orc_texture;
 
 typedef struct {
   uint32_t type;  /* 0 point, 1 distant, 2 infinite(constant) */
@@ -61,6 +68,9 @@ typedef struct {
   float fov;               /* degrees, on the shorter image axis */
   int32_t xres, yres;
   float crop[4];           /* x0 x1 y0 y1 in [0,1], film.rs crop_window */
+  const float *tri_uv;     /* 6 * n_tris corner (u, v), or NULL */
+  const orc_texture *textures;
+  uint32_t n_textures;
 } orc_scene_desc;
 
 typedef struct {

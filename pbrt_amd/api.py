@@ -9,7 +9,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import Light, Material, RenderDesc, SceneDesc, Sphere, Stats, check, lib
+from ._lib import Light, Material, RenderDesc, SceneDesc, Sphere, Stats, Texture, check, lib
 
 MATTE, MIRROR = 0, 1
 LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2
@@ -35,7 +35,9 @@ def _u32p(a):
 class SceneData:
     """Plain arrays describing a scene: RenderOptions + the geometry the reference never stores
     (api.rs:220-223).  `materials` rows: (type, kr, kg, kb, ler, leg, leb); `lights` rows:
-    (type, px, py, pz, cr, cg, cb); `spheres` rows: (cx, cy, cz, r, material)."""
+    (type, px, py, pz, cr, cg, cb); `spheres` rows: (cx, cy, cz, r, material).  Textured materials: `mat_tex[i]` =
+    0 or 1 + the row of `textures` that is material i's Kd, `textures` rows: (type 0 = checkerboard, tex1 rgb, tex2 rgb, su, sv, du,
+    dv), `tri_uv` rows: (u0, v0, u1, v1, u2, v2) per triangle (needed when a triangle's material is textured)."""
     P: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     idx: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.uint32))
     mat_id: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.uint16))
@@ -47,6 +49,9 @@ class SceneData:
     xres: int = 64
     yres: int = 64
     crop: tuple = (0.0, 1.0, 0.0, 1.0)
+    mat_tex: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.uint32))
+    textures: np.ndarray = field(default_factory=lambda: np.zeros((0, 11), np.float32))
+    tri_uv: np.ndarray = field(default_factory=lambda: np.zeros((0, 6), np.float32))
 
     def normalized(self):
         self.P = np.ascontiguousarray(self.P, np.float32).reshape(-1, 3)
@@ -56,7 +61,13 @@ class SceneData:
         self.lights = np.ascontiguousarray(self.lights, np.float32).reshape(-1, 7)
         self.spheres = np.ascontiguousarray(self.spheres, np.float32).reshape(-1, 5)
         self.cam_to_world = np.ascontiguousarray(self.cam_to_world, np.float32).reshape(4, 4)
-        assert self.idx.shape[0] == self.mat_id.shape[0]
+        self.mat_tex = np.ascontiguousarray(self.mat_tex, np.uint32).reshape(-1)
+        if self.mat_tex.shape[0] != self.materials.shape[0]:
+            assert self.mat_tex.shape[0] == 0
+            self.mat_tex = np.zeros(self.materials.shape[0], np.uint32)
+        self.textures = np.ascontiguousarray(self.textures, np.float32).reshape(-1, 11)
+        self.tri_uv = np.ascontiguousarray(self.tri_uv, np.float32).reshape(-1, 6)
+        assert self.idx.shape[0] == self.mat_id.shape[0] and self.tri_uv.shape[0] in (0, self.idx.shape[0])
         return self
 
     def crop_size(self):
@@ -64,7 +75,7 @@ class SceneData:
         return max(b[2] - b[0], 0), max(b[3] - b[1], 0)
 
 
-def fill_desc(desc, sd, mat_t, light_t, sphere_t):
+def fill_desc(desc, sd, mat_t, light_t, sphere_t, tex_t=None):
     """Fill a SceneDesc-shaped ctypes struct from a SceneData; returns the keep-alive list."""
     sd.normalized()
     mats = (mat_t * max(len(sd.materials), 1))()
@@ -72,6 +83,20 @@ def fill_desc(desc, sd, mat_t, light_t, sphere_t):
         mats[i].type = int(m[0])
         mats[i].k[:] = [float(x) for x in m[1:4]]
         mats[i].le[:] = [float(x) for x in m[4:7]]
+        mats[i].kd_tex = int(sd.mat_tex[i])
+    texs = None
+    if len(sd.textures):
+        tex_t = tex_t or dict(desc._fields_)["textures"]._type_  # (the Texture class of the caller's own struct mirror)
+        texs = (tex_t * len(sd.textures))()
+        for i, t in enumerate(sd.textures):
+            texs[i].type = int(t[0])
+            texs[i].tex1[:] = [float(x) for x in t[1:4]]
+            texs[i].tex2[:] = [float(x) for x in t[4:7]]
+            texs[i].su, texs[i].sv, texs[i].du, texs[i].dv = (float(x) for x in t[7:11])
+        desc.textures = texs
+    desc.n_textures = len(sd.textures)
+    if sd.tri_uv.shape[0]:
+        desc.tri_uv = _fp(sd.tri_uv)
     lights = (light_t * max(len(sd.lights), 1))()
     for i, l in enumerate(sd.lights):
         lights[i].type = int(l[0])
@@ -98,7 +123,7 @@ def fill_desc(desc, sd, mat_t, light_t, sphere_t):
     desc.xres = int(sd.xres)
     desc.yres = int(sd.yres)
     desc.crop[:] = [float(x) for x in sd.crop]
-    return [mats, lights, spheres, sd]
+    return [mats, lights, spheres, texs, sd]
 
 
 SAMPLERS = {"stratified": 0, "sobol": 1, "sobol_nd": 2, "halton": 3}  # "sobol": the padded (0,2)-sequence sampler (3.10); "sobol_nd": Sobol' proper (3.12); "halton": 3.13
@@ -264,7 +289,7 @@ class MultiScene:
         self._h = None
         self.sd = sd.normalized()
         desc = SceneDesc()
-        keep = fill_desc(desc, self.sd, Material, Light, Sphere)
+        keep = fill_desc(desc, self.sd, Material, Light, Sphere, Texture)
         h = C.c_void_p()
         check(lib().pbrt_hip_multi_create(C.byref(desc), int(n_gpus), BUILDERS[builder] if builder else 0, C.byref(h)),
               "pbrt_hip_multi_create")
@@ -305,7 +330,7 @@ def render_multi(sd, n_gpus=0, **kw):
     """pbrt_hip_render_multi: create + render on n GPUs + destroy in one call -> (film, [stats per GPU])."""
     sd = sd.normalized()
     desc = SceneDesc()
-    keep = fill_desc(desc, sd, Material, Light, Sphere)
+    keep = fill_desc(desc, sd, Material, Light, Sphere, Texture)
     r = make_render_desc(RenderDesc, **kw)
     n = n_gpus if n_gpus > 0 else device_count()
     w, h = sd.crop_size()
@@ -328,7 +353,7 @@ class Scene:
         is used."""
         self.sd = sd.normalized()
         desc = SceneDesc()
-        keep = fill_desc(desc, self.sd, Material, Light, Sphere)
+        keep = fill_desc(desc, self.sd, Material, Light, Sphere, Texture)
         h = C.c_void_p()
         if builder is None:
             check(lib().pbrt_hip_scene_create(C.byref(desc), device, C.byref(h)), "pbrt_hip_scene_create")

@@ -736,6 +736,22 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     if (!(d->fov > 0.f && d->fov < 180.f)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: fov must lie in (0, 180) degrees");
     for (uint32_t s = 0; s < d->n_spheres; s++)
       if (d->spheres[s].mat >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere material id out of range");
+    bool textured = false;  // a triangle whose material's Kd is a texture
+    for (uint32_t i = 0; i < d->n_mats; i++) {
+      if (d->mats[i].kd_tex > d->n_textures) return fail(PBRT_HIP_ERR_INVALID, "scene_create: material texture number out of range");
+      if (d->mats[i].kd_tex && !d->textures) return fail(PBRT_HIP_ERR_INVALID, "scene_create: textured material but no texture table");
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+      const pbrt_hip_texture &tx = d->textures[i];
+      if (tx.type != 0u) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown texture type");
+      if (!std::isfinite(tx.su) || !std::isfinite(tx.sv) || !std::isfinite(tx.du) || !std::isfinite(tx.dv))
+        return fail(PBRT_HIP_ERR_INVALID, "scene_create: texture mapping is not finite");
+    }
+    for (uint32_t t = 0; t < d->n_tris && !textured; t++) textured = d->mats[d->mat_id[t]].kd_tex != 0u && d->mats[d->mat_id[t]].type == 0u;
+    if (textured && !d->tri_uv) return fail(PBRT_HIP_ERR_INVALID, "scene_create: a triangle's material is textured but tri_uv is NULL");
+    if (textured)
+      for (size_t i = 0; i < 6 * (size_t)d->n_tris; i++)
+        if (!std::isfinite(d->tri_uv[i])) return fail(PBRT_HIP_ERR_INVALID, "scene_create: tri_uv is not finite");
 
     int ndev = pbrt_hip_device_count();
     if (ndev <= 0) return fail(PBRT_HIP_ERR_NO_DEVICE, "scene_create: no HIP device (there is no CPU fallback)");
@@ -753,6 +769,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     s->desc = *d;
     s->desc.P = nullptr; s->desc.idx = nullptr; s->desc.mat_id = nullptr;
     s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
+    s->desc.tri_uv = nullptr; s->desc.textures = nullptr;
+    s->textured = textured;
 
     // --- accelerator: ONE default -- the device builder further down (binned SAH + parallel re-insertion + collapse), whoever asks
     // and however (pbrt_hip_scene_create, flags 0, pbrt_hip_render_multi, the command line, bench.py); the host's binned-SAH
@@ -824,7 +842,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       const pbrt_hip_material &m = d->mats[i];
       if (m.type > 1) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown material type");
       mats[2 * i] = make_float4(as_f(m.type), m.k[0], m.k[1], m.k[2]);
-      mats[2 * i + 1] = make_float4(m.le[0], m.le[1], m.le[2], 0);
+      mats[2 * i + 1] = make_float4(m.le[0], m.le[1], m.le[2], as_f(m.type == 0u ? m.kd_tex : 0u));
     }
     std::vector<float4> spheres(2 * (size_t)d->n_spheres);
     for (uint32_t i = 0; i < d->n_spheres; i++) {
@@ -886,8 +904,24 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     HIP_TRY(up(s->d_lights.p, lights.data(), lights.size() * 16));
     HIP_TRY(up(s->d_spheres.p, spheres.data(), spheres.size() * 16));
     HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order.p, nt, s->d_tris.p, s->stream));
+    if (textured) {  // corner (u, v) into leaf-slot order (whichever builder made d_order), the texture table as 3 x 16 B records
+      std::vector<float4> tex(3 * (size_t)d->n_textures);
+      for (uint32_t i = 0; i < d->n_textures; i++) {
+        const pbrt_hip_texture &tx = d->textures[i];
+        tex[3 * i] = make_float4(as_f(tx.type), tx.tex1[0], tx.tex1[1], tx.tex1[2]);
+        tex[3 * i + 1] = make_float4(tx.tex2[0], tx.tex2[1], tx.tex2[2], tx.su);
+        tex[3 * i + 2] = make_float4(tx.sv, tx.du, tx.dv, 0.f);
+      }
+      HIP_TRY(s->d_tri_uv_in.alloc(6 * (size_t)nt));
+      HIP_TRY(s->d_tri_uv.alloc(3 * (size_t)nt));
+      HIP_TRY(s->d_textures.alloc(tex.size()));
+      HIP_TRY(up(s->d_tri_uv_in.p, d->tri_uv, 24 * (size_t)nt));
+      HIP_TRY(up(s->d_textures.p, tex.data(), tex.size() * 16));
+      HIP_TRY(launch_pack_uv(s->d_tri_uv_in.p, s->d_order.p, nt, s->d_tri_uv.p, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));  // (tex is a local)
+    }
     HIP_TRY(hipStreamSynchronize(s->stream));
-    s->device_bytes = s->d_P.n * 4 + s->d_idx.n * 4 + s->d_mat_id.n * 2 + s->d_order.n * 4 + s->d_nodes.n * 16 + s->d_quads.n * 16 +
+    s->device_bytes = s->d_tri_uv_in.n * 4 + s->d_tri_uv.n * 8 + s->d_textures.n * 16 + s->d_P.n * 4 + s->d_idx.n * 4 + s->d_mat_id.n * 2 + s->d_order.n * 4 + s->d_nodes.n * 16 + s->d_quads.n * 16 +
                       s->d_tris.n * 16 + s->d_mats.n * 16 + s->d_lights.n * 16 + s->d_spheres.n * 16;
 
     // --- kernel argument block ---
@@ -1039,6 +1073,8 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (fx > 16.f || fy > 16.f) return fail(PBRT_HIP_ERR_LIMIT, "render: filter radius above 16 pixels");
   if ((fx != 0.5f || fy != 0.5f) && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
     return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags need the default box filter (radius 0.5)");
+  if (s->textured && ((r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)) || fx != 0.5f || fy != 0.5f))
+    return fail(PBRT_HIP_ERR_LIMIT, "render: a scene with textured materials renders with the default filter and no counter flags (the variants are not combined)");
   if ((fx != 0.5f || fy != 0.5f) && table_sampler)
     return fail(PBRT_HIP_ERR_LIMIT, "render: the Sobol' / Halton samplers (2, 3) with a box filter radius other than 0.5 are not instantiated");
   if (!(r->max_sample_luminance >= 0.f)) return fail(PBRT_HIP_ERR_INVALID, "render: max_sample_luminance must be >= 0 (0 = none)");
@@ -1145,6 +1181,8 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     rc = ensure_render_scratch(s, r, fg, sh, &rs);  // (no allocation when pbrt_hip_render_prepare ran for this description, or an earlier frame did)
     if (rc) return rc;
     R.sobol_mat = r->sampler == PBRT_HIP_SAMPLER_HALTON ? s->d_halton.p : (sobol_nd ? s->d_sobol.p : nullptr);
+    R.tri_uv = s->d_tri_uv.p;
+    R.textures = s->d_textures.p;
     R.integrator = r->integrator;
     R.max_depth = r->max_depth;
     R.spp_x = r->spp_x;
@@ -1193,7 +1231,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     HIP_TRY(hipEventRecord(s->ev0, st));
     // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order (a wide
     // filter has no partial sums: its samples go straight into the accumulators)
-    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, sobol_nd, st));
+    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, sobol_nd, st, false, s->textured));
     if (!fg.wide) HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
@@ -1584,6 +1622,9 @@ int pbrt_hip_loaded_get(const pbrt_hip_loaded *l, pbrt_hip_scene_desc *d, pbrt_h
     std::memcpy(d->cam_to_world, s.cam_to_world, 64);
     d->fov = s.fov; d->xres = s.xres; d->yres = s.yres;
     std::memcpy(d->crop, s.crop, 16);
+    d->tri_uv = s.tri_uv.empty() ? nullptr : s.tri_uv.data();
+    d->textures = s.textures.empty() ? nullptr : s.textures.data();
+    d->n_textures = (uint32_t)s.textures.size();
   }
   if (r) {
     std::memset(r, 0, sizeof *r);

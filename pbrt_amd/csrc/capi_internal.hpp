@@ -70,6 +70,10 @@ struct pbrt_hip_scene {
   bool canonical_ready = false;
   pbrt_hip::DevBuf<uint32_t> d_sobol;  // generator matrices of sampler 2 (uploaded at its first use)
   pbrt_hip::DevBuf<uint32_t> d_halton; // per-dimension table of sampler 3 (likewise)
+  pbrt_hip::DevBuf<float> d_tri_uv_in;  // textured scenes: corner (u, v) as uploaded (triangle order) ...
+  pbrt_hip::DevBuf<float2> d_tri_uv;    // ... and in leaf-slot order (3 per slot)
+  pbrt_hip::DevBuf<float4> d_textures;
+  bool textured = false;                // some triangle's material has kd_tex != 0: the TEX instantiations render it
   pbrt_hip::DevBuf<float4> d_tris_exact;
   pbrt_hip::DevBuf<uint32_t> d_order_exact;
   double canonical_build_ms = 0.0;
@@ -85,7 +89,7 @@ struct pbrt_hip_scene {
     d_P.release(); d_idx.release(); d_order.release(); d_mat_id.release(); d_nodes.release(); d_quads.release(); d_stack_overflow.release();
     d_tris.release(); d_mats.release(); d_lights.release(); d_spheres.release();
     d_slab.release(); d_film.release(); d_counters.release(); d_lane_state.release(); d_partials.release();
-    d_tris_exact.release(); d_order_exact.release(); d_sobol.release(); d_halton.release();
+    d_tris_exact.release(); d_order_exact.release(); d_sobol.release(); d_halton.release(); d_tri_uv_in.release(); d_tri_uv.release(); d_textures.release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);

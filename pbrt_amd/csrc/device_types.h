@@ -166,6 +166,12 @@ struct RenderParams {
   unsigned long long *acc;
   // sampler 2 (render_kernel<..., SND>): generator matrices of the first ten Sobol' dimensions, 32 columns each
   const uint32_t *sobol_mat;
+  // textured materials (render_kernel_x<..., TEX>): corner (u, v) per leaf slot -- 3 x float2 --, and 3 x 16 B per
+  // texture {type, tex1.rgb}{tex2.rgb, su}{sv, du, dv, 0}; a material's texture number rides in mats[2 i + 1].w (0 = none).  (Scene
+  // data -- but appended HERE, to the kernel's last argument: a field added to DevScene would move every offset of this block and
+  // with them the machine code of the instantiations the counter profiles are keyed by.)
+  const float2 *tri_uv;
+  const float4 *textures;
 };
 // 2^24 fixed-point units per unit of radiance, a component clamped to [0, 2^15]
 constexpr float kFixedOne = 16777216.0f, kFixedMax = 32768.0f;
@@ -185,12 +191,15 @@ struct RayBatch {
 
 // launchers (kernels.hip)
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         int counters /* 0 none, 1 exact walk, 2 production walk */, bool wide_filter, bool sobol_nd, hipStream_t stream);
+                         int counters /* 0 none, 1 exact walk, 2 production walk */, bool wide_filter, bool sobol_nd, hipStream_t stream,
+                         bool mis = false, bool textured = false);
 // fixed-point accumulators -> film pixels {X, Y, Z, weight}
 hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, size_t n_px, hipStream_t stream);
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);
+// corner (u, v) of every triangle (6 floats, triangle order) -> leaf-slot order
+hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n_tris, float2 *out, hipStream_t stream);
 // adds the K partial sums of every pixel of a rank's slab in chunk order and converts to XYZ (Film::merge_film_tile)
 hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
                         uint32_t n_local_super, uint32_t spp, hipStream_t stream);

@@ -852,405 +852,19 @@ template <bool SPH, bool COUNT, bool EXACT, int STACK, int STEPS = PBRT_STEPS_PE
 // (scenes with spheres -- C0 / C1: a handful of primitives, nothing to gain from occupancy -- get the register budget
 // of 3 waves per SIMD: the f64 quadratic of lib.rs:181-203 does not fit 128 VGPRs beside the path state)
 __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD))) render_kernel(const DevScene S, const RenderParams R) {
-  // the walk's stack, rows of 64 lanes x 4 bytes as dynamic shared memory: the launch sizes it per scene (render_stack_plan;
-  // exact walk: STACK rows of refs followed by STACK rows of entry distances)
-  extern __shared__ uint32_t lds_stack[];
-  const uint32_t lane = threadIdx.x;
-  uint32_t *stk = lds_stack + lane;
-  float *stkt = reinterpret_cast<float *>(lds_stack + (EXACT ? STACK : 0) * 64) + lane;  // entry distances: exact walk only
-  uint32_t *ovf = R.stack_overflow + (size_t)blockIdx.x * R.stack_overflow_entries * 64u;  // wave-uniform (SGPRs); the lane is added at use
-
-  // Work is handed out dynamically (see the fetch step of the service stage) in ITEMS: item number `item` of this rank
-  // is chunk ((item >> 6) & (K - 1)) of pixel (item & 63) of 8x8 block (item >> (6 + log2 K)) -- the 64 K items of a block are its 64
-  // pixels at chunk 0, then at chunk 1, ... so a wave that draws 64 consecutive items holds one 8x8 block at one
-  // chunk.  Pixel number q = block * 64 + pixel is pixel (q & 63) of 8x8 block ((q >> 6) & 63) of local super-tile
-  // (q >> 12), both row-major.
-  const int32_t W = R.sw, H = R.sh;  // the sampled pixels: the cropped window, plus the halo of a wide filter
-  const uint32_t stx = (uint32_t)(W + 63) >> 6;
-  const uint64_t seq0 = R.seed * (uint64_t)R.seq_w * (uint64_t)R.seq_h;
-  uint32_t item = 0;
-  // tsup / stx by R.stx_recip = ceil(2^32 / stx): exact for tsup * stx < 2^32 (checked by the host); the compiler's own
-  // division by a run-time value keeps a float reciprocal in a VGPR for the whole kernel
-  auto pixel_xy = [&](uint32_t q, int32_t &xr, int32_t &yr) {
-    const uint32_t tsup = R.rank + (q >> 12) * R.world;
-    const uint32_t ty = stx == 1u ? tsup : __umulhi(tsup, R.stx_recip), tx = tsup - ty * stx;
-    xr = (int32_t)(tx * 64u + ((q >> 6) & 7u) * 8u + (q & 7u));
-    yr = (int32_t)(ty * 64u + ((q >> 9) & 7u) * 8u + ((q >> 3) & 7u));
-  };
-  const uint32_t kb = R.chunk_shift, chunk_mask = (1u << kb) - 1u;  // K = 2^kb chunks per pixel
-  auto item_pixel = [&](uint32_t it) { return ((it >> (6u + kb)) << 6) | (it & 63u); };
-  // place of pixel q in the rank's slab (super-tiles back to back, row-major inside) and so of its 8 partial sums
-  auto slab_pos = [](uint32_t q) {
-    return (size_t)(q >> 12) * 4096u + (((q >> 9) & 7u) * 8u + ((q >> 3) & 7u)) * 64u + ((q >> 6) & 7u) * 8u + (q & 7u);
-  };
-  const bool sobol = SND ? true : R.sampler == 1u;  // (the low-discrepancy samplers keep {pixel key, request counter} in rng.state)
-  const bool halton = SND && R.sampler == 3u;       // (samplers 2 and 3 share the SND instantiations: R.sobol_mat is the one's matrices or the other's table)
-  const uint32_t spp = R.spp_x * R.spp_y;
-  const uint32_t spp_mask = R.spp_mask;  // Sobol: 2^ceil(log2 spp) - 1
-  const uint32_t nL = S.n_lights;
-  const float nLf = S.n_lights_f;  // (float)nL, converted on the host: a kernel argument stays in an SGPR
-  const bool direct_only = R.integrator == 1u;
-  const TravTuning tune = {R.min_walkers, R.min_parked};
-
-  const LaneRecords rec = {reinterpret_cast<char *>(R.lane_state + (size_t)blockIdx.x * 320u + 128u), lane * 16u};
-  uint32_t state = ST_FETCH;
-  if (WIDE) wide_slots_clear(R.wide_slots, lane);  // the lane's footprint slots start empty, and every flush leaves them so
-  uint32_t region = blockIdx.x % R.n_regions;  // the part of the pixel list this wave draws from
-  unsigned long long c_cam = 0, c_bounce = 0, c_shadow = 0, c_nodes = 0, c_tris = 0;
-  Trav T;
-  T.o = mk(0.f, 0.f, 0.f);
-  T.d = mk(0.f, 0.f, 1.f);
-  T.tmax = 0.f;
-  T.cur = kDone;
-  T.sp = 0;
-  T.any = 0;
-  T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
-
-  EXP_PROBE_INIT(lane);
-  for (;;) {
-    // ---- service stage: lanes whose walk is over consume the result and launch the next ray ----
-    EXP_PROBE_LANES(4, state != ST_DONE && T.cur == kDone);
-    const bool serve = state != ST_DONE && T.cur == kDone;
-    PathState P;
-    bool launch = false, launch_any = false;
-    V3 ro = T.o, rd = T.d;
-    float rtmax = kInf;
-    int32_t xr = 0, yr = 0;
-    if (serve && state != ST_FETCH) {
-      path_load(rec, P);
-      pixel_xy(item_pixel(item), xr, yr);
-      P.rng.inc = ((((seq0 + (uint64_t)(R.seq_y0 + yr) * (uint64_t)R.seq_w + (uint64_t)(R.seq_x0 + xr)) << kb) + ((item >> 6) & chunk_mask)) << 1) | 1u;
-      PROBE_SEC(1);
-      if (state != ST_NEW) {
-        if (SPH) trav_spheres(S, T);
-        bool advance = false;  // take the prepared bounce (or end the sample)
-        if (state == ST_SHADOW) {
-          EXP_DEBUG_PIXEL("HIP s %u   shadow Lpend %08x occluded %u tmax %a\n", P.s, __float_as_uint(rec_load(rec, kRecLpend).x), T.any >> 1, T.tmax);
-          if (T.any != 3u) {  // unoccluded: the light sample counts
-            const float4 lp = rec_load(rec, kRecLpend);
-            P.L = P.L + mk(lp.x, lp.y, lp.z);
-          }
-          advance = true;
-        } else {
-          const HitRec h = T.h;
-          const bool hit = h.prim != kNoPrim;
-          EXP_DEBUG_PIXEL("HIP s %u bounce %u prim %u t %08x b1 %a b2 %a L %08x beta %08x\n", P.s, P.bounces, h.prim, __float_as_uint(h.t), h.b1, h.b2,
-                          __float_as_uint(P.L.x), __float_as_uint(P.beta.x));
-          EXP_DEBUG_PIXEL("HIP s %u   ray o %a %a %a d %a %a %a\n", P.s, T.o.x, T.o.y, T.o.z, T.d.x, T.d.y, T.d.z);
-          V3 p = {0.f, 0.f, 0.f}, ng = {0.f, 0.f, 1.f};
-          float4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
-          const V3 wo = -T.d;
-          if (hit) {
-            uint32_t mid;
-            if (!SPH || h.prim < S.n_tris) {
-              const float4 a = S.tris[kTriStride * h.slot], b = S.tris[kTriStride * h.slot + 1], c = S.tris[kTriStride * h.slot + 2];
-              const V3 p0 = xyz(a), p1 = xyz(b), p2 = xyz(c);
-              ng = unit(cross(p1 - p0, p2 - p0));
-              const float w = (1.0f - h.b1) - h.b2;
-              p = (p0 * w + p1 * h.b1) + p2 * h.b2;
-              mid = __float_as_uint(b.w);
-            } else {
-              const uint32_t si = h.prim - S.n_tris;
-              const float4 cr = S.spheres[2 * si];
-              const V3 c = xyz(cr);
-              const V3 ph = (T.o - c) + T.d * h.t;
-              ng = ph / cr.w;
-              p = c + ph;
-              mid = __float_as_uint(S.spheres[2 * si + 1].x);
-            }
-            m0 = S.mats[2 * mid];
-            m1 = S.mats[2 * mid + 1];
-          }
-          if (P.bounces == 0 || P.specular) {
-            if (hit) {
-              const V3 le = xyz(m1);
-              if ((le.x > 0.f || le.y > 0.f || le.z > 0.f) && dot(ng, wo) > 0.f) P.L = P.L + P.beta * le;
-            } else if (S.has_inf) {
-              P.L = P.L + P.beta * mk(S.le_inf[0], S.le_inf[1], S.le_inf[2]);
-            }
-          }
-          PROBE_SEC(2);
-          P.cont = false;
-          bool need_shadow = false;
-          if (hit && P.bounces < R.max_depth) {
-            const V3 nf = dot(ng, wo) < 0.f ? -ng : ng;
-            const V3 po = p + nf * kSpawnEps;
-            const V3 k = {m0.y, m0.z, m0.w};
-            V3 sh_d = {0.f, 0.f, 1.f};
-            float sh_tmax = kInf;
-            bool alive = true;
-            if (__float_as_uint(m0.x) == 0u) {  // matte
-              if (nL > 0u) {
-                const float xi = sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat, halton);
-                float u1, u2;
-                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat, halton);
-                uint32_t li = (uint32_t)(xi * nLf);
-                li = min(li, nL - 1u);
-                V3 Ld;
-                if (sample_light(S, li, po, nf, k, u1, u2, nLf, Ld, sh_d, sh_tmax)) {
-                  need_shadow = true;
-                  const V3 lpend = P.beta * Ld;
-                  rec_store(rec, kRecLpend, make_float4(lpend.x, lpend.y, lpend.z, 0.f));
-                }
-              }
-              PROBE_SEC(3);
-              if (direct_only) {
-                alive = false;
-              } else {
-                float u1, u2;
-                sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat, halton);
-                const float z = cosine_about(nf, u1, u2, P.wi_next);
-                EXP_DEBUG_PIXEL("HIP s %u   cos u1 %a u2 %a z %a nf %a %a %a wi %a %a %a\n", P.s, u1, u2, z, nf.x, nf.y, nf.z, P.wi_next.x, P.wi_next.y, P.wi_next.z);
-                if (z == 0.f) alive = false;
-                else { P.beta = P.beta * k; P.specular = false; }
-              }
-            } else {  // mirror
-              const float c = dot(wo, nf);
-              P.wi_next = -wo + nf * (2.0f * c);
-              P.beta = P.beta * k;
-              P.specular = true;
-            }
-            if (alive && P.beta.x == 0.f && P.beta.y == 0.f && P.beta.z == 0.f) alive = false;
-            if (alive && P.bounces > 3u) {
-              const float mx = fmaxf(P.beta.x, fmaxf(P.beta.y, P.beta.z));
-              const float q = fmaxf(0.05f, 1.0f - mx);
-              if (sample_1d<SND>(P, sobol, spp_mask, R.sobol_mat, halton) < q) alive = false;
-              else P.beta = P.beta / (1.0f - q);
-            }
-            P.cont = alive;
-            ro = po;  // shadow ray and bounce ray both leave from the offset point
-            if (need_shadow) {
-              rd = sh_d;
-              rtmax = sh_tmax;
-              state = ST_SHADOW;
-              launch = true;
-              launch_any = true;
-              if (COUNT) c_shadow++;
-            }
-          }
-          if (!need_shadow) advance = true;
-        }
-        PROBE_SEC(4);
-        if (advance) {
-          bool go = P.cont;
-          if (go) {
-            P.bounces++;
-            // a ray at the depth limit can only collect emission, and only after a P.specular bounce
-            if (P.bounces >= R.max_depth && !P.specular) go = false;
-          }
-          if (go) {
-            rd = P.wi_next;
-            rtmax = kInf;
-            state = ST_CLOSEST;
-            launch = true;
-            launch_any = false;
-            if (COUNT) c_bounce++;
-          } else {
-            // radiance sanitising of SamplerIntegrator::Render, then FilmTile::AddSample (box filter)
-            const float y = (0.212671f * P.L.x + 0.715160f * P.L.y) + 0.072169f * P.L.z;
-            if (isnan(P.L.x) || isnan(P.L.y) || isnan(P.L.z) || y < -1e-5f || isinf(y)) P.L = {0.f, 0.f, 0.f};
-            else if (y > R.max_lum) P.L = P.L * (R.max_lum / y);  // Film "maxsampleluminance" (film.rs:75,279); +inf = none
-            EXP_DEBUG_PIXEL("SAMPLE %u %08x %08x %08x\n", P.s, __float_as_uint(P.L.x), __float_as_uint(P.L.y), __float_as_uint(P.L.z));  // (to diff against oracle pixel_samples())
-            if (WIDE) {
-              // FilmTile::AddSample for a box filter of any radius: weight 1 to every pixel of the cropped
-              // window within the radius of the sample's film point (kept in the record the default path has its partial
-              // sum in), as 2^-24 fixed point: integer atomics make the sums independent of the order of arrival
-              const float4 fp = rec_load(rec, kRecSum);
-              const float dx = fp.x - 0.5f, dy = fp.y - 0.5f;
-              int32_t x0 = (int32_t)ceilf(dx - R.filter_rx), x1 = (int32_t)floorf(dx + R.filter_rx) + 1;
-              int32_t y0 = (int32_t)ceilf(dy - R.filter_ry), y1 = (int32_t)floorf(dy + R.filter_ry) + 1;
-              x0 = max(x0, S.cx0); x1 = min(x1, S.cx1);
-              y0 = max(y0, S.cy0); y1 = min(y1, S.cy1);
-              unsigned long long ar = (unsigned long long)(long long)(fminf(fmaxf(P.L.x, 0.f), kFixedMax) * kFixedOne);
-              unsigned long long ag = (unsigned long long)(long long)(fminf(fmaxf(P.L.y, 0.f), kFixedMax) * kFixedOne);
-              unsigned long long ab = (unsigned long long)(long long)(fminf(fmaxf(P.L.z, 0.f), kFixedMax) * kFixedOne);
-              uint32_t an = 1u;
-              // Integer sums do not care how they are grouped, and the samples of a chunk -- all in one pixel -- have few
-              // distinct footprints: each bound takes one of two neighbouring values as the film point moves through the
-              // pixel.  The chunk's samples are therefore added up per footprint in 16 slots of the lane (indexed by the
-              // parities of the four bounds; a sample that finds another footprint in its slot goes to the film by
-              // itself, which does not happen while a bound keeps to two values) and go to the film in ONE set of atomics
-              // per footprint at the chunk's end, instead of (2r + 1)^2 x 4 atomics per sample.
-              const int32_t X = R.sx0 + (int32_t)xr - 64, Y = R.sy0 + (int32_t)yr - 64;  // the bounds lie within +-20 of the pixel
-              const uint32_t key = (uint32_t)(x0 - X) | ((uint32_t)(x1 - X) << 7) | ((uint32_t)(y0 - Y) << 14) | ((uint32_t)(y1 - Y) << 21);
-              const uint32_t slot = ((uint32_t)x0 & 1u) | (((uint32_t)x1 & 1u) << 1) | (((uint32_t)y0 & 1u) << 2) | (((uint32_t)y1 & 1u) << 3);
-              // (address = wave-uniform base + a 32-bit lane offset made opaque, as for the path records: nothing of it is
-              // hoisted out of the kernel's loop into long-lived registers)
-              uint32_t so = lane_here() * 16u + slot * 2048u;
-              asm volatile("" : "+v"(so));
-              char *sb = reinterpret_cast<char *>(R.wide_slots + (size_t)blockIdx.x * kWideSlotFloat4) + so;
-              const float4 a1 = *reinterpret_cast<const float4 *>(sb + 1024);  // {b, samples, footprint}
-              const uint32_t pn = __float_as_uint(a1.z), pkey = __float_as_uint(a1.w);
-              P.s++;
-              if (sobol) P.rng.state &= 0xffffffffull;
-              if (__builtin_expect(pn != 0u && pkey != key, 0)) {
-                // the slot holds another footprint of this pixel (a bound that takes three values: possible only when
-                // r +- 1/2 lies within rounding of an integer): this sample goes to the film by itself
-                film_add(R.acc, S, x0, x1, y0, y1, ar, ag, ab, 1u);
-              } else {
-                if (pn != 0u) {
-                  const float4 a0 = *reinterpret_cast<const float4 *>(sb);         // {r, g}
-                  ar += (unsigned long long)__float_as_uint(a0.x) | ((unsigned long long)__float_as_uint(a0.y) << 32);
-                  ag += (unsigned long long)__float_as_uint(a0.z) | ((unsigned long long)__float_as_uint(a0.w) << 32);
-                  ab += (unsigned long long)__float_as_uint(a1.x) | ((unsigned long long)__float_as_uint(a1.y) << 32);
-                  an += pn;
-                }
-                *reinterpret_cast<float4 *>(sb) = make_float4(__uint_as_float((uint32_t)ar), __uint_as_float((uint32_t)(ar >> 32)), __uint_as_float((uint32_t)ag), __uint_as_float((uint32_t)(ag >> 32)));
-                *reinterpret_cast<float4 *>(sb + 1024) = make_float4(__uint_as_float((uint32_t)ab), __uint_as_float((uint32_t)(ab >> 32)), __uint_as_float(an), __uint_as_float(key));
-              }
-              // (a complete chunk's sums go to the film where the lane asks for its next item: fewer live registers there)
-              state = P.s == chunk_begin(((item >> 6) & chunk_mask) + 1u, spp, kb) ? ST_FETCH : ST_NEW;
-            } else {
-            // FilmTile::AddSample with the box filter: this pixel, weight 1.  The chunk's partial sum lives in its record.
-            const float4 sm = rec_load(rec, kRecSum);
-            const V3 sum = mk(sm.x, sm.y, sm.z) + P.L;
-            P.s++;
-            if (sobol) P.rng.state &= 0xffffffffull;  // request counter of the next sample
-            if (P.s == chunk_begin(((item >> 6) & chunk_mask) + 1u, spp, kb)) {
-              // the chunk is complete: its partial sum goes to the item's slot; merge_kernel adds a pixel's K in
-              // chunk order (Film::merge_film_tile, core/film.rs:313-326)
-              R.partials[(slab_pos(item_pixel(item)) << kb) + ((item >> 6) & chunk_mask)] = make_float4(sum.x, sum.y, sum.z, 0.f);
-              state = ST_FETCH;  // this lane takes another item
-            } else {
-              rec_store(rec, kRecSum, make_float4(sum.x, sum.y, sum.z, 0.f));
-              state = ST_NEW;
-            }
-            }
-          }
-          P.cont = false;
-        }
-      }
-    }
-    PROBE_SEC(5);
-    // ---- fetch: lanes without an item draw the next ones of this rank's item list (wave-uniform; one atomic per
-    // wave and round).  An item stays with its lane for all its samples, so its RNG stream, sample order and partial
-    // sum are those of DESIGN.md 3.1 whichever lane happens to take it; what the dynamic hand-out removes is the
-    // idling of lanes whose pixels have short paths (sky) beside long ones, and -- items being a K-th of a pixel --
-    // the wait for the sequential samples of the frame's most expensive pixels at its end. ----
-    if (WIDE && state == ST_FETCH) {
-      // the finished chunk's sums, one set of atomics per footprint (xr, yr are still its pixel)
-      const int32_t X = R.sx0 + (int32_t)xr - 64, Y = R.sy0 + (int32_t)yr - 64;
-      uint32_t lo = lane_here() * 16u;
-      asm volatile("" : "+v"(lo));
-      const char *lb = reinterpret_cast<const char *>(R.wide_slots + (size_t)blockIdx.x * kWideSlotFloat4) + lo;
-#pragma nounroll
-      for (uint32_t sl = 0u; sl < 16u; sl++) {
-        const float4 f1 = *reinterpret_cast<const float4 *>(lb + sl * 2048u + 1024u);
-        const uint32_t fn = __float_as_uint(f1.z), fk = __float_as_uint(f1.w);
-        if (fn == 0u) continue;
-        const float4 f0 = *reinterpret_cast<const float4 *>(lb + sl * 2048u);
-        film_add(R.acc, S, X + (int32_t)(fk & 127u), X + (int32_t)((fk >> 7) & 127u), Y + (int32_t)((fk >> 14) & 127u), Y + (int32_t)((fk >> 21) & 127u),
-                 (unsigned long long)__float_as_uint(f0.x) | ((unsigned long long)__float_as_uint(f0.y) << 32),
-                 (unsigned long long)__float_as_uint(f0.z) | ((unsigned long long)__float_as_uint(f0.w) << 32),
-                 (unsigned long long)__float_as_uint(f1.x) | ((unsigned long long)__float_as_uint(f1.y) << 32), fn);
-        *reinterpret_cast<float4 *>(const_cast<char *>(lb) + sl * 2048u + 1024u) = make_float4(0.f, 0.f, 0.f, 0.f);  // empty again
-      }
-    }
-    for (;;) {
-      const unsigned long long mw = __ballot(state == ST_FETCH);
-      if (mw == 0ull) break;
-      // XCD-aware hand-out: workgroup w runs on XCD w mod 8 (each XCD has its own 4 MiB L2), so the list is cut into
-      // n_regions contiguous parts and a wave draws from the part of its XCD -- the waves that share an L2 render
-      // one part of the image -- and helps the next part when its own is exhausted.
-      uint32_t base = 0, lim = R.n_items;
-      for (uint32_t tries = 0; tries < R.n_regions; tries++) {
-        // (parts are cut at multiples of 64 K items = whole 8x8 blocks)
-        const uint32_t nblk = R.n_items >> (6u + kb);
-        const uint32_t lo = ((nblk * region) / R.n_regions) << (6u + kb);  // (nblk < 2^26 / 8, at most 8 regions)
-        const uint32_t hi = ((nblk * (region + 1u)) / R.n_regions) << (6u + kb);
-        if (lane == 0) base = atomicAdd(R.next_item + 16u * region, (uint32_t)__popcll(mw));
-        base = __builtin_amdgcn_readfirstlane(base) + lo;
-        lim = hi;
-        if (base < hi) break;
-        region = region + 1u < R.n_regions ? region + 1u : 0u;  // own part exhausted: help the next one
-        base = lim;
-      }
-      if (state == ST_FETCH) {
-        const uint32_t it = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));  // set bits below this lane
-        if (it >= lim) {
-          if (base >= lim) state = ST_DONE;  // every part exhausted (else: this lane draws again in the next round)
-        } else {
-          const uint32_t q = item_pixel(it), chunk = (it >> 6) & chunk_mask;
-          pixel_xy(q, xr, yr);
-          if (xr < W && yr < H) {  // (pixels of a ragged super-tile outside the image are skipped)
-            if (chunk_begin(chunk, spp, kb) == chunk_begin(chunk + 1u, spp, kb)) {
-              // an empty chunk (fewer than 8 samples per pixel): its partial sum is zero; the lane draws again
-              if (!WIDE) R.partials[(slab_pos(q) << kb) + chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-              item = it;
-              if (!WIDE) rec_store(rec, kRecSum, make_float4(0.f, 0.f, 0.f, 0.f));
-              P.L = {0.f, 0.f, 0.f};
-              P.beta = {1.f, 1.f, 1.f};
-              P.wi_next = {0.f, 0.f, 0.f};
-              const uint64_t pixel_seq = seq0 + (uint64_t)(R.seq_y0 + yr) * (uint64_t)R.seq_w + (uint64_t)(R.seq_x0 + xr);
-              if (sobol) P.rng.state = mix32((uint32_t)pixel_seq ^ mix32((uint32_t)(pixel_seq >> 32) + 0x9e3779b9u));
-              else pcg_seq(P.rng, (pixel_seq << kb) + chunk);
-              P.s = chunk_begin(chunk, spp, kb);
-              P.bounces = 0;
-              P.specular = false;
-              P.cont = false;
-              state = ST_NEW;
-            }
-          }
-        }
-      }
-    }
-    PROBE_SEC(6);
-    if (serve && state != ST_DONE) {
-      if (state == ST_NEW) {
-        if (true) {
-          // stratified camera sample and PerspectiveCamera ray (3.2)
-          float u1, u2;
-          sample_2d<SND>(P, sobol, spp_mask, u1, u2, R.sobol_mat, halton);
-          float jx = u1, jy = u2;  // Sobol: the (0,2)-net point is the film offset
-          if (!sobol) {
-            // P.s / spp_x by R.spp_x_recip = ceil(2^32 / spp_x): the estimate is the quotient or one more
-            uint32_t sy = R.spp_x == 1u ? P.s : __umulhi(P.s, R.spp_x_recip);
-            if (sy * R.spp_x > P.s) sy--;
-            const uint32_t sx = P.s - sy * R.spp_x;
-            jx = fminf(((float)sx + u1) * R.inv_nx, kOneMinusEps);
-            jy = fminf(((float)sy + u2) * R.inv_ny, kOneMinusEps);
-          }
-          const float fx = (float)(R.sx0 + xr) + jx, fy = (float)(R.sy0 + yr) + jy;
-          if (WIDE) rec_store(rec, kRecSum, make_float4(fx, fy, 0.f, 0.f));  // the film point, for the filter's footprint
-          const V3 dc = unit(mk(fx * S.cam_ax + S.cam_bx, fy * S.cam_ay + S.cam_by, 1.0f));
-          rd = {(S.c2w[0] * dc.x + S.c2w[1] * dc.y) + S.c2w[2] * dc.z,
-                (S.c2w[4] * dc.x + S.c2w[5] * dc.y) + S.c2w[6] * dc.z,
-                (S.c2w[8] * dc.x + S.c2w[9] * dc.y) + S.c2w[10] * dc.z};
-          ro = {S.c2w[3], S.c2w[7], S.c2w[11]};
-          rtmax = kInf;
-          P.L = {0.f, 0.f, 0.f};
-          P.beta = {1.f, 1.f, 1.f};
-          P.specular = false;
-          P.bounces = 0;
-          state = ST_CLOSEST;
-          launch = true;
-          launch_any = false;
-          if (COUNT) c_cam++;
-        }
-      }
-      PROBE_SEC(7);
-      path_store(rec, P);
-      EXP_RAY_LOG(launch, ro, rd, rtmax, launch_any);
-      if (launch) trav_begin<EXACT>(S, T, stk, ro, rd, rtmax, launch_any, c_nodes);
-    }
-    PROBE_SEC(8);
-    if (__ballot(state != ST_DONE) == 0ull) break;
-    wave_prio(PBRT_PRIO_ARITH);  // traversal arithmetic at priority 0, its fetches at 3 (trav_run)
-    trav_run<EXACT, COUNT, ((!EXACT && STACK != 0) ? (uint32_t)STACK : 0u), STEPS>(S, T, stk, stkt, ovf, state != ST_DONE, tune, c_nodes, c_tris);
-    wave_prio(PBRT_PRIO_SERVICE);  // the service stage of the next round: its lanes are not tracing while it lasts
-    PROBE_SEC(0);
-  }
-
-  EXP_PROBE_FINI(lane);
-  if (COUNT) {
-    unsigned long long v[5] = {c_cam, c_bounce, c_shadow, c_nodes, c_tris};
-    for (int i = 0; i < 5; i++) {
-      unsigned long long x = v[i];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-      if (lane == 0) atomicAdd(&R.counters[i], x);
-    }
-  }
+  constexpr bool MIS = false, TEX = false;  // (the variants: render_kernel_x below)
+  (void)MIS;
+#include "render_body.inc"
+}
+// The variants of the path that BASELINE's configs do not use, in a kernel of their own name so that the instantiations above keep
+// theirs (and their machine code): MIS = multiple importance sampling of the direct-light estimate, TEX = materials
+// whose Kd is a checkerboard texture (3.15); with the stratified / (0,2) samplers or (SND) the table samplers 2 and 3.  Default filter,
+// no counters.
+template <bool SPH, int STACK, bool MIS, bool TEX, bool SND>
+__global__ void __launch_bounds__(64, (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD)) render_kernel_x(const DevScene S, const RenderParams R) {
+  constexpr bool COUNT = false, EXACT = false, WIDE = false;
+  constexpr int STEPS = PBRT_STEPS_PER_CHECK;
+#include "render_body.inc"
 }
 
 #ifndef PBRT_INTERSECT_WAVES_PER_SIMD
@@ -1327,6 +941,14 @@ __global__ void pack_tris_kernel(const float *P, const uint32_t *idx, const uint
   tris[kTriStride * slot] = make_float4(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2], __uint_as_float(t));
   tris[kTriStride * slot + 1] = make_float4(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2], __uint_as_float((uint32_t)mat_id[t]));
   tris[kTriStride * slot + 2] = make_float4(P[3 * i2], P[3 * i2 + 1], P[3 * i2 + 2], 0.f);
+}
+
+// corner (u, v) of the triangle in leaf slot `slot` (textured scenes: DESIGN.md 3.15)
+__global__ void pack_uv_kernel(const float *tri_uv, const uint32_t *order, uint32_t n_tris, float2 *out) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_tris) return;
+  const uint32_t t = order[slot];
+  for (int v = 0; v < 3; v++) out[3u * slot + v] = make_float2(tri_uv[6 * (size_t)t + 2 * v], tri_uv[6 * (size_t)t + 2 * v + 1]);
 }
 
 __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
@@ -1429,10 +1051,30 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
   }
 }
 
+template <bool SPH, bool MIS, bool TEX, bool SND>
+static hipError_t launch_render_x(const DevScene &S, const RenderParams &R, hipStream_t st) {
+  const dim3 grid(R.n_workgroups), block(64);
+  const RenderStackPlan plan = render_stack_plan(S.quad_stack_need, render_force_overflow(), render_prefer_lds());
+  const uint32_t lds = plan.rows * 256u;
+  if (plan.overflow) hipLaunchKernelGGL((render_kernel_x<SPH, (int)kQuadLdsStackOvf, MIS, TEX, SND>), grid, block, lds, st, S, R);
+  else hipLaunchKernelGGL((render_kernel_x<SPH, 0, MIS, TEX, SND>), grid, block, lds, st, S, R);
+  return hipGetLastError();
+}
+template <bool SPH>
+static hipError_t launch_render_x_pick(const DevScene &S, const RenderParams &R, bool mis, bool tex, bool snd, hipStream_t st) {
+  if (mis && tex) return snd ? launch_render_x<SPH, true, true, true>(S, R, st) : launch_render_x<SPH, true, true, false>(S, R, st);
+  if (mis) return snd ? launch_render_x<SPH, true, false, true>(S, R, st) : launch_render_x<SPH, true, false, false>(S, R, st);
+  return snd ? launch_render_x<SPH, false, true, true>(S, R, st) : launch_render_x<SPH, false, true, false>(S, R, st);
+}
+
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
-                         int counters, bool wide_filter, bool sobol_nd, hipStream_t stream) {
+                         int counters, bool wide_filter, bool sobol_nd, hipStream_t stream, bool mis, bool textured) {
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
+  if (mis || textured) {  // the variants (render_kernel_x): default filter, no counters -- refused otherwise by check_render_desc
+    if (wide_filter || counters != 0) return hipErrorInvalidValue;
+    return sph ? launch_render_x_pick<true>(S, R, mis, textured, sobol_nd, stream) : launch_render_x_pick<false>(S, R, mis, textured, sobol_nd, stream);
+  }
   if (wide_filter && sobol_nd) return hipErrorInvalidValue;  // (not instantiated: refused by check_render_desc)
   if (wide_filter) return sph ? launch_render_variant<true, true, false>(S, R, stream) : launch_render_variant<false, true, false>(S, R, stream);
   if (sobol_nd) return sph ? launch_render_variant<true, false, true>(S, R, stream) : launch_render_variant<false, false, true>(S, R, stream);
@@ -1479,6 +1121,12 @@ hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t 
   if (n_tris == 0) return hipSuccess;
   hipLaunchKernelGGL(pack_tris_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, stream, P, idx, mat_id, order, n_tris,
                      tris);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n_tris, float2 *out, hipStream_t stream) {
+  if (n_tris == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_uv_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, stream, tri_uv, order, n_tris, out);
   return hipGetLastError();
 }
 

@@ -153,7 +153,7 @@ int clone_scene(const pbrt_hip_scene *src, int device, pbrt_hip_scene **out) {
       HIP_TRY(hipMemcpyPeerAsync(s->field.p, device, src->field.p, src->device, src->field.n * sizeof(*src->field.p), s->stream)); \
   } while (0)
   CLONE(d_P); CLONE(d_idx); CLONE(d_order); CLONE(d_mat_id); CLONE(d_nodes); CLONE(d_quads);
-  CLONE(d_tris); CLONE(d_mats); CLONE(d_lights); CLONE(d_spheres);
+  CLONE(d_tris); CLONE(d_mats); CLONE(d_lights); CLONE(d_spheres); CLONE(d_tri_uv); CLONE(d_textures);
 #undef CLONE
   HIP_TRY(s->d_counters.alloc(80));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -164,6 +164,7 @@ int clone_scene(const pbrt_hip_scene *src, int device, pbrt_hip_scene **out) {
   s->dev.mats = s->d_mats.p;
   s->dev.lights = s->d_lights.p;
   s->dev.spheres = s->d_spheres.p;
+  s->textured = src->textured;
   *out = s.release();
   return PBRT_HIP_OK;
 }

@@ -226,6 +226,7 @@ std::string dequote(const std::string &s) { return s.substr(1, s.size() - 2); }
 struct MaterialDef {
   uint32_t type = 0;  // matte
   float k[3] = {0.5f, 0.5f, 0.5f};
+  uint32_t kd_tex = 0;  // 1 + index into LoadedScene::textures when "texture Kd" names a checkerboard
 };
 struct GraphicsState {  // api.rs:251-289
   MaterialDef material;
@@ -248,8 +249,9 @@ struct Api {
   std::vector<std::pair<Xform, Xform>> pushed_ctm;
   std::vector<uint32_t> pushed_bits;
   std::map<std::string, std::array<float, 3>> spectrum_textures;
+  std::map<std::string, uint32_t> checker_textures;  // name -> 1 + index into out->textures
   std::map<std::string, MaterialDef> named_materials;
-  std::map<std::tuple<uint32_t, float, float, float, float, float, float>, uint16_t> material_ids;
+  std::map<std::tuple<uint32_t, float, float, float, float, float, float, uint32_t>, uint16_t> material_ids;
   bool camera_set = false;
 
   explicit Api(LoadedScene *o) : out(o) {
@@ -306,6 +308,12 @@ struct Api {
     MaterialDef m;
     if (type == "matte") {
       m.type = 0;
+      if (const ParamItem *p = ps.find("Kd", "texture")) {  // a checkerboard keeps its pattern; k = its mean colour (spheres, fallbacks)
+        if (p->strs.size() == 1) {
+          auto it = checker_textures.find(p->strs[0]);
+          if (it != checker_textures.end()) m.kd_tex = it->second;
+        }
+      }
       spectrum(ps, "Kd", m.k);
       ps.find("sigma", "float");
     } else if (type == "mirror") {
@@ -319,11 +327,12 @@ struct Api {
   }
 
   uint16_t material_id(const MaterialDef &m, const float le[3]) {
-    auto key = std::make_tuple(m.type, m.k[0], m.k[1], m.k[2], le[0], le[1], le[2]);
+    auto key = std::make_tuple(m.type, m.k[0], m.k[1], m.k[2], le[0], le[1], le[2], m.kd_tex);
     auto it = material_ids.find(key);
     if (it != material_ids.end()) return it->second;
     pbrt_hip_material pm{};
     pm.type = m.type;
+    pm.kd_tex = m.kd_tex;
     for (int i = 0; i < 3; i++) { pm.k[i] = m.k[i]; pm.le[i] = le[i]; }
     const uint16_t id = (uint16_t)out->mats.size();
     out->mats.push_back(pm);
@@ -331,8 +340,10 @@ struct Api {
     return id;
   }
 
-  // Textures are out of scope for the path: a spectrum texture is
-  // reduced to one constant colour so that materials naming it still load.
+  // Texture "name" "spectrum" "class" ... (api.rs:524-580 stores nothing; texture.rs is an empty marker).  On this path: a 2-D
+  // CHECKERBOARD over the (u, v) mapping keeps its pattern (pbrt-v3 Checkerboard2DTexture, point-sampled: DESIGN.md 3.15) when a
+  // matte material names it as Kd; every spectrum texture is also reduced to one constant colour, which is what a parameter other
+  // than a matte Kd -- and a sphere, whose (u, v) need libm -- gets.
   void texture(const std::string &name, const std::string &kind, const std::string &cls, const ParamSet &ps) {
     if (kind != "spectrum" && kind != "color" && kind != "rgb") return;  // float textures: nothing on the path uses them
     std::array<float, 3> c = {0.5f, 0.5f, 0.5f};
@@ -340,11 +351,31 @@ struct Api {
     if (cls == "constant") {
       spectrum(ps, "value", a);
       c = {a[0], a[1], a[2]};
-    } else if (cls == "checkerboard" || cls == "mix" || cls == "dots") {
+    } else if (cls == "checkerboard") {
+      spectrum(ps, "tex1", a);
+      spectrum(ps, "tex2", b);
+      c = {0.5f * (a[0] + b[0]), 0.5f * (a[1] + b[1]), 0.5f * (a[2] + b[2])};
+      const int dim = ps.one_int("dimension", 2);
+      std::string mapping = "uv", aamode = "closedform";
+      if (const ParamItem *p = ps.find("mapping", "string")) if (p->strs.size() == 1) mapping = p->strs[0];
+      if (const ParamItem *p = ps.find("aamode", "string")) if (p->strs.size() == 1) aamode = p->strs[0];
+      if (dim == 2 && mapping == "uv") {
+        pbrt_hip_texture t{};
+        t.type = 0;
+        for (int i = 0; i < 3; i++) { t.tex1[i] = a[i]; t.tex2[i] = b[i]; }
+        t.su = ps.one_float("uscale", 1.f); t.sv = ps.one_float("vscale", 1.f);
+        t.du = ps.one_float("udelta", 0.f); t.dv = ps.one_float("vdelta", 0.f);
+        out->textures.push_back(t);
+        checker_textures[name] = (uint32_t)out->textures.size();
+        if (aamode != "none") warn("Texture \"" + name + "\" (checkerboard): point-sampled (aamode \"none\": ray differentials are not carried)");
+      } else {
+        warn("Texture \"" + name + "\" (checkerboard): only dimension 2 with the \"uv\" mapping keeps its pattern, replaced by the mean of its two colours");
+      }
+    } else if (cls == "mix" || cls == "dots") {
       spectrum(ps, cls == "dots" ? "inside" : "tex1", a);
       spectrum(ps, cls == "dots" ? "outside" : "tex2", b);
       c = {0.5f * (a[0] + b[0]), 0.5f * (a[1] + b[1]), 0.5f * (a[2] + b[2])};
-      warn("Texture \"" + name + "\" (" + cls + "): textures are out of scope, replaced by the mean of its two colours");
+      warn("Texture \"" + name + "\" (" + cls + "): not supported, replaced by the mean of its two colours");
     } else if (cls == "scale") {
       b[0] = b[1] = b[2] = 1.f;
       spectrum(ps, "tex1", a);
@@ -354,6 +385,7 @@ struct Api {
       warn("Texture \"" + name + "\" (" + cls + "): not supported, replaced by grey 0.5");
     }
     spectrum_textures[name] = c;
+    report_unused("Texture", ps);
   }
 
   void shape(const std::string &name, const ParamSet &ps) {
@@ -374,6 +406,7 @@ struct Api {
       s.mat = mid;
       out->spheres.push_back(s);
       if (gs.has_area_light) warn("sphere area lights emit but are not sampled by the direct-light estimate");
+      if (gs.material.kd_tex) warn("a textured Kd on a sphere: the texture's mean colour is used (a sphere's (u, v) is not computed on this path)");
     } else if (name == "trianglemesh") {
       const ParamItem *pi = ps.find("indices", "integer");
       const ParamItem *pp = ps.find("P", "point3");
@@ -386,14 +419,23 @@ struct Api {
         out->P.insert(out->P.end(), q, q + 3);
       }
       const bool flip = gs.reverse_orientation ^ swaps_handedness(M);
+      // per-vertex (u, v): "uv" or "st" (pbrt-v3 CreateTriangleMeshShape; floats or point2s), else Triangle::GetUVs' (0,0) (1,0) (1,1)
+      const ParamItem *puv = ps.find("uv", "float", "point2");
+      if (!puv) puv = ps.find("st", "float", "point2");
+      else ps.find("st", "float", "point2");
+      if (puv && puv->nums.size() != 2 * (size_t)nv) { warn("trianglemesh: \"uv\" / \"st\" does not hold two numbers per vertex: ignored"); puv = nullptr; }
       for (size_t t = 0; t + 2 < pi->nums.size(); t += 3) {
         uint32_t a = (uint32_t)pi->nums[t], b = (uint32_t)pi->nums[t + 1], c = (uint32_t)pi->nums[t + 2];
         if (a >= nv || b >= nv || c >= nv) { warn("trianglemesh index out of range: triangle skipped"); continue; }
         if (flip) std::swap(b, c);
         out->idx.push_back(base + a); out->idx.push_back(base + b); out->idx.push_back(base + c);
         out->mat_id.push_back(mid);
+        const uint32_t corner[3] = {a, b, c};
+        const float dflt[6] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};
+        for (int v = 0; v < 3; v++)
+          for (int k = 0; k < 2; k++) out->tri_uv.push_back(puv ? (float)puv->nums[2 * (size_t)corner[v] + k] : dflt[2 * (flip && v ? 3 - v : v) + k]);
       }
-      ps.find("st", "float", "point2"); ps.find("uv", "float", "point2"); ps.find("N", "normal"); ps.find("S", "vector3");
+      ps.find("N", "normal"); ps.find("S", "vector3");
     } else {
       warn("Shape \"" + name + "\" is not supported by this path: skipped");
       return;
@@ -833,6 +875,11 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
       !((out->filter_radius[0] == 0.5f || out->filter_radius[0] == 0.f) && (out->filter_radius[1] == 0.5f || out->filter_radius[1] == 0.f))) {
     api.warn("Sampler \"" + out->sampler_name + "\" with a box filter radius other than 0.5: served by the (0,2)-sequence (Sobol') sampler");
     out->sampler = PBRT_HIP_SAMPLER_SOBOL;
+  }
+  {  // corner (u, v) travel only when some triangle's material is textured
+    bool textured = false;
+    for (uint16_t m : out->mat_id) textured = textured || out->mats[m].kd_tex != 0u;
+    if (!textured) { out->tri_uv.clear(); out->tri_uv.shrink_to_fit(); }
   }
   if (!api.camera_set) mat_identity(out->cam_to_world);
   return fin(true);

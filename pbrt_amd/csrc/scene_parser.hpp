@@ -67,6 +67,8 @@ struct LoadedScene {
   std::vector<pbrt_hip_material> mats;
   std::vector<pbrt_hip_light> lights;
   std::vector<pbrt_hip_sphere> spheres;
+  std::vector<pbrt_hip_texture> textures;  // checkerboards named by a material's "texture Kd" 
+  std::vector<float> tri_uv;               // 6 per triangle (corner u, v); empty when no material is textured
   // RenderOptions (api.rs:201-249) resolved to values
   float cam_to_world[16];
   float fov = 90.f;

@@ -47,7 +47,11 @@ def _collect(h):
             lights=np.array([[d.lights[i].type, *d.lights[i].p, *d.lights[i].c] for i in range(d.n_lights)], np.float32).reshape(-1, 7),
             spheres=np.array([[*d.spheres[i].c, d.spheres[i].r, d.spheres[i].mat] for i in range(d.n_spheres)], np.float32).reshape(-1, 5),
             cam_to_world=np.array(list(d.cam_to_world), np.float32).reshape(4, 4), fov=d.fov, xres=d.xres, yres=d.yres,
-            crop=tuple(d.crop)).normalized()
+            crop=tuple(d.crop),
+            mat_tex=np.array([d.mats[i].kd_tex for i in range(d.n_mats)], np.uint32),
+            textures=np.array([[d.textures[i].type, *d.textures[i].tex1, *d.textures[i].tex2, d.textures[i].su, d.textures[i].sv, d.textures[i].du,
+                                d.textures[i].dv] for i in range(d.n_textures)], np.float32).reshape(-1, 11),
+            tri_uv=(arr(d.tri_uv, 6 * d.n_tris, np.float32).reshape(-1, 6) if d.tri_uv else np.zeros((0, 6), np.float32))).normalized()
         wbuf = C.create_string_buffer(1 << 16)
         nw = l.pbrt_hip_loaded_warnings(h, wbuf, len(wbuf))
         ctm = np.zeros(16, np.float32)

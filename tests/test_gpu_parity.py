@@ -521,6 +521,42 @@ def test_c0_as_baseline_states_it(gpu, oracle):
         assert_bit_equal(film, ref, f"C0 film at 256x256, 4 spp, Sampler \"{sampler}\"")
 
 
+def test_checkerboard_texture(gpu, oracle):
+    """DESIGN.md 3.15, the TEX instantiations of the kernel (render_kernel_x): the closed form of tests/util.py on the HIP path itself,
+    then films equal to the oracle's bit for bit -- path integrator over a textured plane with a mirror sphere (spheres + texture),
+    every sampler, three ranks -- and the combinations that are not instantiated refused loudly."""
+    from util import check_checker_plane, checker_plane_scene
+    from pbrt_amd import _lib
+    def render(sd):
+        with gpu.Scene(sd) as sc:
+            return gpu.film_to_rgb(sc.render(integrator=INTEGRATOR_DIRECT, max_depth=1, spp=(1, 1), seed=3)[0])
+    assert check_checker_plane(render, lambda sd, x, y: oracle.OracleScene(sd).camera_ray(x, y)) > 0.9
+    sd, _ = checker_plane_scene(72)
+    sd.spheres = np.array([[0.3, 0.2, 0.6, 0.6, 1]], np.float32)
+    sd.materials = np.concatenate([sd.materials, [[1, .9, .9, .9, 0, 0, 0]]]).astype(np.float32)
+    sd.mat_tex = np.array([1, 0], np.uint32)
+    sd.lights = np.concatenate([sd.lights, [[LIGHT_INFINITE, 0, 0, 0, .3, .35, .4]]]).astype(np.float32)
+    sd.normalized()
+    o = oracle.OracleScene(sd)
+    for builder in (None, "host"):
+        with gpu.Scene(sd, builder=builder) as sc:
+            for sampler in ("stratified", "sobol", "sobol_nd", "halton"):
+                kw = dict(max_depth=5, spp=(3, 2), seed=4, sampler=sampler)
+                film, _ = sc.render(**kw)
+                assert_bit_equal(film, o.render(**kw)[0], f"textured plane + mirror sphere, {sampler}, builder {builder}")
+            kw = dict(max_depth=5, spp=(3, 2), seed=4)
+            assert_bit_equal(sum(sc.render(rank=r, world_size=3, **kw)[0] for r in range(3)), o.render(**kw)[0], "three ranks")
+            for bad in (dict(counters=True), dict(counters="walk"), dict(filter_width=(1.5, 1.5))):
+                with pytest.raises(_lib.PbrtHipError) as e:
+                    sc.render(**dict(kw, **bad))
+                assert e.value.code == -4
+    # a textured material without corner (u, v) is an invalid scene, not a silent constant colour
+    sd.tri_uv = np.zeros((0, 6), np.float32)
+    with pytest.raises(_lib.PbrtHipError) as e:
+        gpu.Scene(sd)
+    assert e.value.code == -1
+
+
 def test_cli_renders_c0(gpu, tmp_path):
     import os
     from pbrt_amd import cli

@@ -400,3 +400,14 @@ def test_halton_sampler_radical_inverse(oracle):
                 assert np.array_equal(u, want), d
             seen.add(tuple(v[:8].tolist()))
         assert len(seen) == 3, "pixels must not share a scramble"
+
+
+def test_checkerboard_texture_closed_form(oracle):
+    """DESIGN.md 3.15 on the oracle: a matte plane whose Kd is a checkerboard, one distant light, one sample per pixel -- every pixel is
+    exactly tex1 or tex2 x L cos / pi, in the pattern the (u, v) mapping predicts (the same check runs on the kernel: -m gpu)."""
+    from util import check_checker_plane
+    def render(sd):
+        o = oracle.OracleScene(sd)
+        return oracle.film_write_rgb(o.render(integrator=1, max_depth=1, spp=(1, 1), seed=3)[0])
+    agree = check_checker_plane(render, lambda sd, x, y: oracle.OracleScene(sd).camera_ray(x, y))
+    assert agree > 0.9

@@ -110,7 +110,11 @@ def _expect_check_sphere(ls, res):
     assert 1.0 < r < 1.25 and 0.45 < g < 0.62 and 0.1 < b < 0.25  # 3000 K normalised blackbody x 1.5: warm white
     want_c2w = pbrt_amd.look_at((3, 4, 1.5), (.5, .5, 0), (0, 0, 1))[1]  # camera_to_world = CTM^-1 (api.rs:813-820)
     assert np.array_equal(sd.cam_to_world, want_c2w)
-    assert len(ls.warnings) == 1 and "checkerboard" in ls.warnings[0]
+    assert len(ls.warnings) == 1 and "checkerboard" in ls.warnings[0] and "point-sampled" in ls.warnings[0]
+    # the ground's Kd is the checkerboard itself: texture 1 on material 1, 8 x 8 checks over the quad's "float st"
+    assert sd.mat_tex.tolist() == [0, 1] and sd.textures.shape == (1, 11)
+    assert np.allclose(sd.textures[0], [0, .1, .1, .1, .8, .8, .8, 8, 8, 0, 0])
+    assert sd.tri_uv.tolist() == [[0, 0, 1, 0, 1, 1], [0, 0, 1, 1, 0, 1]]
     assert ls.sampler == 3  # Sampler "halton": the Halton sampler proper
 
 

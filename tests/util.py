@@ -187,3 +187,44 @@ def lit_plane_scene(kind, res=16):
     sd = SceneData(P=P, idx=idx, mat_id=np.zeros(2, np.uint16), materials=np.array([[MATTE, *rho, 0, 0, 0]], np.float32), lights=lights,
                    cam_to_world=look_at((1.0, -2.0, 3.0), (0.2, 0.3, 0.0), (0, 0, 1))[1], fov=40.0, xres=res, yres=res).normalized()
     return sd, want.astype(np.float64)
+
+
+def checker_plane_scene(res=64, scale=7.0, delta=(0.25, -0.5)):
+    """lit_plane_scene("distant") with its Kd replaced by a 2-D checkerboard over the plane's (u, v): the quad's corner
+    (u, v) are (0,0) (1,0) (1,1) (0,1), so a point (x, y) of the plane has u = (x + 50) / 100, v = (y + 50) / 100 and lies on tex1 where
+    floor(scale u + du) + floor(scale v + dv) is even.  Returns (scene_data, value(x, y) -> expected rgb of a sample that hits (x, y, 0))."""
+    sd, _ = lit_plane_scene("distant", res)
+    t1, t2 = np.array([0.1, 0.2, 0.3]), np.array([0.8, 0.7, 0.6])
+    sd.mat_tex = np.array([1], np.uint32)
+    sd.textures = np.array([[0, *t1, *t2, scale, scale, delta[0], delta[1]]], np.float32)
+    sd.tri_uv = np.array([[0, 0, 1, 0, 1, 1], [0, 0, 1, 1, 0, 1]], np.float32)
+    sd.normalized()
+    light = np.array([3.0, 2.0, 1.0]) * 0.8 / np.pi
+
+    def value(x, y):
+        cell = np.floor(scale * (x + 50) / 100 + delta[0]) + np.floor(scale * (y + 50) / 100 + delta[1])
+        return np.where((cell.astype(np.int64) & 1)[..., None] == 0, t1 * light, t2 * light)
+    return sd, value
+
+
+def check_checker_plane(render_rgb, camera_ray, res=64):
+    """Closed form for a textured matte plane under one distant light, on either side (the oracle, or the kernel on a GPU): with one
+    sample per pixel every pixel is EXACTLY one of the two colours x L cos / pi, and it is the colour of the cell the pixel's own
+    sample landed in -- which is the cell under the pixel centre except for pixels a cell border crosses."""
+    sd, value = checker_plane_scene(res)
+    rgb = render_rgb(sd).astype(np.float64)
+    a, b = value(np.array(-49.0), np.array(-49.0)), value(np.array(-49.0 + 100 / 7), np.array(-49.0))
+    da, db = np.abs(rgb - a).max(-1), np.abs(rgb - b).max(-1)
+    assert (np.minimum(da, db) < 3e-6).all(), "a pixel that is neither colour"
+    assert (da < 3e-6).mean() > 0.2 and (db < 3e-6).mean() > 0.2, "both colours must show"
+    # where the pixel centre's ray meets the plane
+    xs = np.zeros((res, res)); ys = np.zeros((res, res))
+    for py in range(res):
+        for px in range(res):
+            o, d = camera_ray(sd, px + 0.5, py + 0.5)
+            t = -o[2] / d[2]
+            xs[py, px], ys[py, px] = o[0] + t * d[0], o[1] + t * d[1]
+    want = value(xs, ys)
+    agree = (np.abs(rgb - want).max(-1) < 3e-6).mean()
+    assert agree > 0.9, agree
+    return agree
