@@ -876,6 +876,13 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     api.warn("Sampler \"" + out->sampler_name + "\" with a box filter radius other than 0.5: served by the (0,2)-sequence (Sobol') sampler");
     out->sampler = PBRT_HIP_SAMPLER_SOBOL;
   }
+  const bool wide_filter = !((out->filter_radius[0] == 0.5f || out->filter_radius[0] == 0.f) && (out->filter_radius[1] == 0.5f || out->filter_radius[1] == 0.f));
+  if (wide_filter && !out->textures.empty()) {
+    // (the fixed-point film path of DESIGN.md 3.11 is not instantiated with textures: the pattern gives way to its mean colour)
+    bool any = false;
+    for (pbrt_hip_material &m : out->mats) { any = any || m.kd_tex != 0u; m.kd_tex = 0u; }
+    if (any) api.warn("a textured Kd with a box filter radius other than 0.5: the texture's mean colour is used");
+  }
   {  // corner (u, v) travel only when some triangle's material is textured
     bool textured = false;
     for (uint16_t m : out->mat_id) textured = textured || out->mats[m].kd_tex != 0u;
