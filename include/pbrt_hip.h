@@ -99,6 +99,10 @@ typedef struct {
 
 #define PBRT_HIP_INTEGRATOR_PATH 0   /* Integrator "path" (default name, api.rs:239) */
 #define PBRT_HIP_INTEGRATOR_DIRECT 1 /* Integrator "directlighting" */
+#define PBRT_HIP_INTEGRATOR_PATH_MIS 2 /* Integrator "path" "bool mis" "true": the path integrator with the direct-light estimate
+                                          MULTIPLE-IMPORTANCE-SAMPLED as pbrt-v3's path integrator does (power heuristic between the
+                                          one light sample and the BSDF-sampled bounce ray: DESIGN.md 3.14; integrator 0 is SURVEY A8's
+                                          "no MIS in v1").  Default filter, no counter flags */
 #define PBRT_HIP_FLAG_COUNTERS 1u    /* count nodes visited / triangles tested of the canonical walk:
                                         runs the exact-order instantiation of the kernel, equal to the oracle's counters */
 #define PBRT_HIP_FLAG_WALK_COUNTERS 2u /* count what the production kernel itself does instead: nodes_visited = 64-byte

@@ -310,8 +310,8 @@ struct RayStats {
 // -------- Integrator --------
 class PathIntegrator {
  public:
-  PathIntegrator(const Scene &s, uint32_t max_depth, bool direct_only)
-      : scene(s), max_depth_(max_depth), direct_only_(direct_only) {}
+  PathIntegrator(const Scene &s, uint32_t max_depth, bool direct_only, bool mis = false)
+      : scene(s), max_depth_(max_depth), direct_only_(direct_only), mis_(mis && !direct_only) {}
 
   // PathIntegrator::Li.  `direct_only_` turns it into the direct-lighting
   // integrator: first non-specular vertex gets its one-light estimate and the path ends.
@@ -319,11 +319,13 @@ class PathIntegrator {
     if (g_debug_li) std::fprintf(stderr, "ORC sample begins\n");
     Vec3 L = {0, 0, 0}, beta = {1, 1, 1};
     bool specular = false;
+    float pb = 0.f;  // MIS: the solid-angle density with which the ray in flight was drawn from the BSDF (cos / pi)
     const uint32_t nL = (uint32_t)scene.lights.size();
     const float nLf = (float)nL;
     for (uint32_t bounces = 0;; bounces++) {
-      // a ray at the depth limit can only collect emission, and only after a specular bounce
-      if (bounces > 0 && bounces >= max_depth_ && !specular) break;
+      // a ray at the depth limit can only collect emission, and only after a specular bounce -- or, with MIS, as the BSDF-sampled
+      // half of the last vertex's direct-light estimate
+      if (bounces > 0 && bounces >= max_depth_ && !specular && !mis_) break;
       if (bounces == 0) st.camera++; else st.bounce++;
       Hit h = scene.Intersect(ray, &st.c);
       bool hit = h.prim != 0xffffffffu;
@@ -359,6 +361,25 @@ class PathIntegrator {
         } else if (scene.has_infinite) {
           L = L + beta * scene.le_infinite;
         }
+      } else if (mis_) {
+        // the ray was drawn from the BSDF with density pb; the light-sampling strategy would have drawn this direction
+        // with pl -- an emissive triangle (picked with 1 / nL, a uniform point of it): (t^2 / (cos_l A)) / nL; the constant
+        // environment (picked with 1 / nL, cosine-sampled): pb / nL.  Power heuristic: w = pb^2 / (pb^2 + pl^2).
+        if (hit && h.prim < scene.n_tris()) {
+          Vec3 le = v3(m->le[0], m->le[1], m->le[2]);
+          const float cl = dot(ng, wo);
+          if ((le.x > 0.f || le.y > 0.f || le.z > 0.f) && cl > 0.f) {
+            Vec3 p0, p1, p2;
+            scene.tri_verts(h.prim, &p0, &p1, &p2);
+            const float area = 0.5f * length(cross(p1 - p0, p2 - p0));
+            const float pl = ((h.t * h.t) / (cl * area)) / nLf;
+            const float w = (pb * pb) / (pb * pb + pl * pl);
+            L = L + (beta * le) * w;
+          }
+        } else if (!hit && scene.has_infinite) {
+          const float w = (nLf * nLf) / (nLf * nLf + 1.0f);
+          L = L + (beta * scene.le_infinite) * w;
+        }
       }
       if (!hit || bounces >= max_depth_) break;
       Vec3 nf = dot(ng, wo) < 0.f ? -ng : ng;
@@ -386,7 +407,7 @@ class PathIntegrator {
           if (li > nL - 1) li = nL - 1;
           Vec3 Ld;
           Ray sh;
-          if (sample_light(scene.lights[li], po, nf, k, u1, u2, nLf, &Ld, &sh)) {
+          if (sample_light(scene.lights[li], po, nf, k, u1, u2, nLf, &Ld, &sh, mis_)) {
             st.shadow++;
             const bool occ = scene.IntersectP(sh, &st.c);
             if (g_debug_li) { uint32_t a; std::memcpy(&a, &Ld.x, 4); std::fprintf(stderr, "ORC   light %u Ld %08x occluded %d tmax %a\n", li, a, (int)occ, sh.tmax); }
@@ -404,6 +425,7 @@ class PathIntegrator {
         if (z == 0.f) break;
         beta = beta * k;
         specular = false;
+        pb = z * kInvPi;
       } else {  // mirror
         float c = dot(wo, nf);
         wi = -wo + nf * (2.0f * c);
@@ -426,8 +448,10 @@ class PathIntegrator {
 
   // UniformSampleOneLight's per-light part.  Returns false when geometry rules the
   // light out (no shadow ray is cast then).
+  // mis: the estimate is weighted with the power heuristic pl^2 / (pl^2 + pb^2) -- pl the density of this
+  // strategy for the direction (light picked with 1 / nL), pb = cos / pi the BSDF's; delta lights keep weight 1.
   static bool sample_light(const LightRec &l, Vec3 po, Vec3 nf, Vec3 kd, float u1, float u2, float nLf,
-                           Vec3 *Ld, Ray *sh) {
+                           Vec3 *Ld, Ray *sh, bool mis = false) {
     Vec3 f = kd * kInvPi;
     sh->o = po;
     if (l.type == 0) {  // point
@@ -457,6 +481,7 @@ class PathIntegrator {
       float z = cosine_sample_about(nf, u1, u2, &wi);
       if (z == 0.f) return false;
       *Ld = (kd * l.c) * nLf;
+      if (mis) *Ld = *Ld * (1.0f / (1.0f + nLf * nLf));  // pl = pb / nL
       sh->d = wi;
       sh->tmax = kInf;
       return true;
@@ -476,6 +501,10 @@ class PathIntegrator {
       float cl = -dot(wi, l.n);
       if (!(cl > 0.f)) return false;
       float scale = (((cs * cl) * l.area) / dist2) * nLf;
+      if (mis) {
+        const float pl = (dist2 / (cl * l.area)) / nLf, pbl = cs * kInvPi;
+        scale = scale * ((pl * pl) / (pl * pl + pbl * pbl));
+      }
       *Ld = (f * l.c) * scale;
       sh->d = wi;
       sh->tmax = dist * kShadowShrink;
@@ -488,6 +517,7 @@ class PathIntegrator {
  private:
   uint32_t max_depth_;
   bool direct_only_;
+  bool mis_;  // integrator 2: the direct-light estimate with multiple importance sampling
 };
 
 // pbrt-v3 SamplerIntegrator::Render's radiance sanitising before FilmTile::AddSample
@@ -772,7 +802,7 @@ void orc_camera_ray(const orc_scene *sc, float fx, float fy, float o[3], float d
 }
 void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int y, float *out) {
   orc::g_debug_li = std::getenv("ORC_DEBUG_LI") != nullptr;
-  PathIntegrator integ(sc->s, r->max_depth, r->integrator == 1);
+  PathIntegrator integ(sc->s, r->max_depth, r->integrator == 1, r->integrator == 2);
   RayStats st;
   float px[4];
   render_pixel(sc->s, integ, *r, x, y, px, out, st);
@@ -783,9 +813,9 @@ void orc_pixel_samples(const orc_scene *sc, const orc_render_desc *r, int x, int
 // fixed-point accumulators of DESIGN.md 3.11 over the sample bounds
 static int render_any(const orc_scene *sc, const orc_render_desc *r, float *film, int64_t *acc, orc_stats *out, int n_threads) {
   const Scene &s = sc->s;
-  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 3) return -1;
+  if (r->spp_x == 0 || r->spp_y == 0 || r->world_size == 0 || r->rank >= r->world_size || r->sampler > 3 || r->integrator > 2) return -1;
   if (!(filter_radius(r->filter_xwidth) > 0.f) || !(filter_radius(r->filter_ywidth) > 0.f)) return -1;
-  PathIntegrator integ(s, r->max_depth, r->integrator == 1);
+  PathIntegrator integ(s, r->max_depth, r->integrator == 1, r->integrator == 2);
   const WideFilter wf = wide_filter(s, *r);
   // the 64x64 super-tiles cover the SAMPLE bounds (= the cropped window for the default filter)
   const int x0 = acc ? wf.sb[0] : s.cropped[0], y0 = acc ? wf.sb[1] : s.cropped[1];

@@ -13,7 +13,7 @@ from ._lib import Light, Material, RenderDesc, SceneDesc, Sphere, Stats, Texture
 
 MATTE, MIRROR = 0, 1
 LIGHT_POINT, LIGHT_DISTANT, LIGHT_INFINITE = 0, 1, 2
-INTEGRATOR_PATH, INTEGRATOR_DIRECT = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_DIRECT, INTEGRATOR_PATH_MIS = 0, 1, 2  # 2: the path integrator with MIS
 FLAG_COUNTERS = 1
 FLAG_WALK_COUNTERS = 2
 SCENE_GPU_BUILD = 1  # pbrt_hip_scene_create_ex flags

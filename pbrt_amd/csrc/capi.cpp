@@ -1056,7 +1056,7 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (!s || !r) return fail(PBRT_HIP_ERR_INVALID, "render: null argument");
   if (r->spp_x == 0 || r->spp_y == 0) return fail(PBRT_HIP_ERR_INVALID, "render: spp_x and spp_y must be >= 1");
   if (r->world_size == 0 || r->rank >= r->world_size) return fail(PBRT_HIP_ERR_INVALID, "render: rank must be < world_size");
-  if (r->integrator > 1) return fail(PBRT_HIP_ERR_INVALID, "render: unknown integrator");
+  if (r->integrator > PBRT_HIP_INTEGRATOR_PATH_MIS) return fail(PBRT_HIP_ERR_INVALID, "render: unknown integrator");
   if (r->sampler > PBRT_HIP_SAMPLER_HALTON) return fail(PBRT_HIP_ERR_INVALID, "render: unknown sampler");
   // (samplers 2 and 3 -- Sobol' proper and Halton -- share one instantiation of the kernel: "the table samplers")
   const bool table_sampler = r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND || r->sampler == PBRT_HIP_SAMPLER_HALTON;
@@ -1073,8 +1073,8 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (fx > 16.f || fy > 16.f) return fail(PBRT_HIP_ERR_LIMIT, "render: filter radius above 16 pixels");
   if ((fx != 0.5f || fy != 0.5f) && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
     return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags need the default box filter (radius 0.5)");
-  if (s->textured && ((r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)) || fx != 0.5f || fy != 0.5f))
-    return fail(PBRT_HIP_ERR_LIMIT, "render: a scene with textured materials renders with the default filter and no counter flags (the variants are not combined)");
+  if ((s->textured || r->integrator == PBRT_HIP_INTEGRATOR_PATH_MIS) && ((r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)) || fx != 0.5f || fy != 0.5f))
+    return fail(PBRT_HIP_ERR_LIMIT, "render: textured materials / the MIS integrator render with the default filter and no counter flags (the variants are not combined)");
   if ((fx != 0.5f || fy != 0.5f) && table_sampler)
     return fail(PBRT_HIP_ERR_LIMIT, "render: the Sobol' / Halton samplers (2, 3) with a box filter radius other than 0.5 are not instantiated");
   if (!(r->max_sample_luminance >= 0.f)) return fail(PBRT_HIP_ERR_INVALID, "render: max_sample_luminance must be >= 0 (0 = none)");
@@ -1231,7 +1231,7 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     HIP_TRY(hipEventRecord(s->ev0, st));
     // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order (a wide
     // filter has no partial sums: its samples go straight into the accumulators)
-    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, sobol_nd, st, false, s->textured));
+    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, sobol_nd, st, r->integrator == PBRT_HIP_INTEGRATOR_PATH_MIS, s->textured));
     if (!fg.wide) HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;

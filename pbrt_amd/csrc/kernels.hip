@@ -599,8 +599,10 @@ __device__ __forceinline__ void trav_spheres(const DevScene &S, Trav &T) {
 }
 
 // One light of UniformSampleOneLight.  false: geometry rules the light out.
+// mis: the estimate weighted with the power heuristic pl^2 / (pl^2 + pb^2), pl = this strategy's density for the
+// direction (light picked with 1 / nL), pb = cos / pi the BSDF's; delta lights keep weight 1
 __device__ __forceinline__ bool sample_light(const DevScene &S, uint32_t li, V3 po, V3 nf, V3 kd, float u1, float u2,
-                                             float nLf, V3 &Ld, V3 &wi, float &tmax) {
+                                             float nLf, V3 &Ld, V3 &wi, float &tmax, const bool mis = false) {
   const float4 l0 = S.lights[5 * li];
   const float4 l3 = S.lights[5 * li + 3];
   const uint32_t type = __float_as_uint(l0.x);
@@ -631,6 +633,7 @@ __device__ __forceinline__ bool sample_light(const DevScene &S, uint32_t li, V3 
     float z = cosine_about(nf, u1, u2, wi);
     if (z == 0.f) return false;
     Ld = (kd * lc) * nLf;
+    if (mis) Ld = Ld * (1.0f / (1.0f + nLf * nLf));  // pl = pb / nL
     tmax = kInf;
     return true;
   } else {
@@ -652,6 +655,10 @@ __device__ __forceinline__ bool sample_light(const DevScene &S, uint32_t li, V3 
     float cl = -dot(wi, xyz(l4));
     if (!(cl > 0.f)) return false;
     float scale = (((cs * cl) * l1.w) / dist2) * nLf;
+    if (mis) {
+      const float pl = (dist2 / (cl * l1.w)) / nLf, pbl = cs * kInvPi;
+      scale = scale * ((pl * pl) / (pl * pl + pbl * pbl));
+    }
     Ld = (f * lc) * scale;
     tmax = dist * kShadowShrink;
     return true;

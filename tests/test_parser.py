@@ -194,3 +194,14 @@ def test_sampler_names():
     assert loader.load_string("WorldBegin\nWorldEnd\n").sampler == 3  # no Sampler directive: the default name is "halton" (api.rs:235)
     ls = loader.load_string('Sampler "stratified" "integer xsamples" 3 "integer ysamples" 5')
     assert ls.sampler == 0 and ls.spp == (3, 5)
+
+
+def test_integrator_mis_switch():
+    """Integrator "path" "bool mis" "true" selects integrator 2; the default stays the estimator BASELINE's configs are
+    pinned on; with a wide box filter the switch is dropped with a warning (the variants are not combined)."""
+    assert loader.load_string('Integrator "path"').integrator == 0
+    ls = loader.load_string('Integrator "path" "bool mis" "true" "integer maxdepth" 7')
+    assert ls.integrator == 2 and ls.max_depth == 7 and not ls.warnings
+    assert loader.load_string('Integrator "directlighting" "bool mis" "true"').integrator == 1
+    ls = loader.load_string('PixelFilter "box" "float xwidth" 2 "float ywidth" 2\nIntegrator "path" "bool mis" "true"\nWorldBegin\nWorldEnd\n')
+    assert ls.integrator == 0 and any("without MIS" in w for w in ls.warnings)
