@@ -13,7 +13,8 @@ fn main() {
 // ---------------------------------------------------------------- src/core/hip.rs
 use std::os::raw::{c_char, c_int, c_void};
 
-#[repr(C)] pub struct HipMaterial { pub kind: u32, pub k: [f32; 3], pub le: [f32; 3], pub pad: f32 }
+#[repr(C)] pub struct HipMaterial { pub kind: u32, pub k: [f32; 3], pub le: [f32; 3], pub kd_tex: u32 }  // kd_tex: 0, or 1 + the index of the checkerboard that is the matte Kd
+#[repr(C)] pub struct HipTexture  { pub kind: u32, pub tex1: [f32; 3], pub tex2: [f32; 3], pub su: f32, pub sv: f32, pub du: f32, pub dv: f32, pub pad: [u32; 5] }  // Texture "..." "spectrum" "checkerboard" (check-sphere.pbrt:24-25)
 #[repr(C)] pub struct HipLight    { pub kind: u32, pub p: [f32; 3], pub c: [f32; 3], pub pad: f32 }
 #[repr(C)] pub struct HipSphere   { pub c: [f32; 3], pub r: f32, pub mat: u32, pub pad: [u32; 3] }
 #[repr(C)] pub struct HipSceneDesc {
@@ -21,11 +22,13 @@ use std::os::raw::{c_char, c_int, c_void};
     pub mats: *const HipMaterial, pub lights: *const HipLight, pub spheres: *const HipSphere,
     pub n_verts: u32, pub n_tris: u32, pub n_mats: u32, pub n_lights: u32, pub n_spheres: u32,
     pub cam_to_world: [f32; 16], pub fov: f32, pub xres: i32, pub yres: i32, pub crop: [f32; 4],
+    pub tri_uv: *const f32,           // 6 per triangle: corner (u, v) ("float st" / "uv"); NULL unless a triangle's material is textured
+    pub textures: *const HipTexture, pub n_textures: u32,
 }
 #[repr(C)] pub struct HipRenderDesc {
     pub integrator: u32, pub max_depth: u32, pub spp_x: u32, pub spp_y: u32,
     pub seed: u64, pub rank: u32, pub world_size: u32, pub flags: u32,
-    pub sampler: u32,                                // 0 stratified, 1 the (0,2)-sequence sampler
+    pub sampler: u32,                                // 0 stratified, 1 the (0,2)-sequence sampler, 2 Sobol' proper, 3 Halton proper (the default NAME, api.rs:235)
     pub filter_xwidth: f32, pub filter_ywidth: f32,  // box filter radii (box.rs:57-61); 0 = 0.5; any radius in (0, 16]
     pub max_sample_luminance: f32,                   // Film "maxsampleluminance" (film.rs:75,279); 0 = no bound
 }
@@ -81,7 +84,7 @@ fn world_end(&mut self) {
     let rd = HipRenderDesc { integrator: if ro.integrator_name == "directlighting" { 1 } else { 0 },
                              max_depth: ro.integrator_params.find_one_int("maxdepth", 5) as u32,
                              spp_x, spp_y, seed: 0, rank: 0, world_size: 1, flags: 0,
-                             sampler: if ro.sampler_name == "stratified" { 0 } else { 1 },
+                             sampler: match ro.sampler_name.as_str() { "stratified" => 0, "sobol" => 2, "halton" => 3, _ => 1 },
                              filter_xwidth: filter.radius.x, filter_ywidth: filter.radius.y,
                              max_sample_luminance: if max_lum.is_finite() { max_lum } else { 0. } };
     let n_gpus = unsafe { pbrt_hip_device_count() };   // all of them: 8 on an MI355X node
