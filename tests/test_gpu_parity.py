@@ -311,13 +311,18 @@ def test_golden_fixture(gpu):
     """tests/golden/render_golden.npz: films the oracle produced when the fixtures were made
     (tests/golden/make_golden.py); the HIP path must reproduce them bit for bit."""
     import os
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_golden.npz"))
-    for key in g.files:
-        name, integ, depth, sx, sy, seed, sampler = key.split("-")
-        sd = SMALL_SCENES[name]()
-        with gpu.Scene(sd) as sc:
-            film, _ = sc.render(integrator=int(integ), max_depth=int(depth), spp=(int(sx), int(sy)), seed=int(seed), sampler=int(sampler))
-        assert_bit_equal(film, g[key], key)
+    from util import checker_plane_scene
+    every = dict(SMALL_SCENES, checker=lambda: checker_plane_scene(40)[0])
+    # (render_golden_r05.npz: what round 5 added beside the default path -- samplers 2 / 3, integrator 2, a checkerboard Kd)
+    for fixture, n in (("render_golden.npz", 6), ("render_golden_r05.npz", 9)):
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+        assert len(g.files) == n
+        for key in g.files:
+            name, integ, depth, sx, sy, seed, sampler = key.split("-")
+            sd = every[name]()
+            with gpu.Scene(sd) as sc:
+                film, _ = sc.render(integrator=int(integ), max_depth=int(depth), spp=(int(sx), int(sy)), seed=int(seed), sampler=int(sampler))
+            assert_bit_equal(film, g[key], f"{fixture}: {key}")
 
 
 def test_ranks_partition_and_crop(gpu, oracle):
