@@ -737,6 +737,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     for (uint32_t s = 0; s < d->n_spheres; s++)
       if (d->spheres[s].mat >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere material id out of range");
     bool textured = false;  // a triangle whose material's Kd is a texture
+    if (d->n_textures && !d->textures) return fail(PBRT_HIP_ERR_INVALID, "scene_create: n_textures > 0 but no texture table");
     for (uint32_t i = 0; i < d->n_mats; i++) {
       if (d->mats[i].kd_tex > d->n_textures) return fail(PBRT_HIP_ERR_INVALID, "scene_create: material texture number out of range");
       if (d->mats[i].kd_tex && !d->textures) return fail(PBRT_HIP_ERR_INVALID, "scene_create: textured material but no texture table");

@@ -181,6 +181,19 @@ def test_bad_arguments_are_rejected_before_any_device_work():
         pbrt_amd.Scene(sd)
     with pytest.raises(ValueError):
         pbrt_amd.slab_pixel_index(64, 64, (0, 1, 0, 1), 2, 2)
+    # textured materials: a texture number beyond the table, a textured triangle without corner (u, v), non-finite (u, v)
+    # or mapping, an unknown texture type
+    from util import checker_plane_scene
+    for breakit, what in ((lambda sd: setattr(sd, "mat_tex", np.array([2], np.uint32)), "texture number"),
+                          (lambda sd: setattr(sd, "tri_uv", np.zeros((0, 6), np.float32)), "tri_uv is NULL"),
+                          (lambda sd: sd.tri_uv.__setitem__((1, 3), np.inf), "tri_uv is not finite"),
+                          (lambda sd: sd.textures.__setitem__((0, 7), np.nan), "mapping is not finite"),
+                          (lambda sd: sd.textures.__setitem__((0, 0), 5), "unknown texture type")):
+        sd, _ = checker_plane_scene(8)
+        breakit(sd)
+        with pytest.raises(_lib.PbrtHipError) as e:
+            pbrt_amd.Scene(sd)
+        assert e.value.code == -1 and what in str(e.value), (what, str(e.value))
 
 
 @pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere"])
