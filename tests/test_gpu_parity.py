@@ -975,7 +975,8 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     """Triangle counts 0..300 (with duplicates and degenerate triangles), random materials (mirrors, emitters),
     0-3 lights of every kind, 0-2 spheres, random camera / resolution / crop / strata / depth / integrator /
     seed / rank split; odd seeds use the Sobol sampler, every fourth a tiny grid of persistent waves, every third
-    builds the tree on the device."""
+    builds the tree on the device.  Then the film paths of round 3 (random wide box filter, luminance clamp) and samplers 2 / 3, and
+    round 5's variants: random checkerboard textures and integrator 2 (MIS) on the same scene."""
     sd, rng = _random_scene(seed)
     integ = INTEGRATOR_DIRECT if seed % 5 == 4 else INTEGRATOR_PATH
     depth, spp, rseed = int(rng.integers(0, 12)), (int(rng.integers(1, 7)), int(rng.integers(1, 6))), int(rng.integers(0, 1 << 20))
@@ -1014,6 +1015,19 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     assert np.array_equal(parts, o.render_acc(fw, **kw)[0]), f"random scene {seed}: accumulators, box filter {fw}, {world} ranks, clamp {ml}"
     assert_bit_equal(nd, o.render(**dict(kw, sampler="sobol_nd"))[0], f"random scene {seed}: sampler 2")
     assert_bit_equal(hal, o.render(**dict(kw, sampler="halton"))[0], f"random scene {seed}: sampler 3")
+    # round 5's variants on the same random scene: random checkerboards as the Kd of some matte materials over random corner (u, v),
+    # integrator 2 (MIS) on even seeds, any of the four samplers, the device-built tree on every other seed
+    import dataclasses
+    from pbrt_amd import INTEGRATOR_PATH_MIS
+    n_tex = int(rng.integers(1, 4))
+    tex = np.concatenate([np.zeros((n_tex, 1)), rng.uniform(0.05, 0.95, (n_tex, 6)), rng.uniform(-9, 9, (n_tex, 2)), rng.uniform(-2, 2, (n_tex, 2))], 1)
+    mat_tex = np.where((sd.materials[:, 0] == 0) & (rng.random(len(sd.materials)) < 0.7), rng.integers(1, n_tex + 1, len(sd.materials)), 0).astype(np.uint32)
+    tsd = dataclasses.replace(sd, textures=tex.astype(np.float32), mat_tex=mat_tex, tri_uv=rng.uniform(-1.5, 2.5, (len(sd.idx), 6)).astype(np.float32)).normalized()
+    vkw = dict(integrator=INTEGRATOR_PATH_MIS if seed % 2 == 0 else INTEGRATOR_PATH, max_depth=depth, spp=spp, seed=rseed,
+               sampler=("stratified", "sobol", "sobol_nd", "halton")[seed % 4])
+    with gpu.Scene(tsd, builder="gpu" if seed % 2 else "host") as sc:
+        var = sum(sc.render(rank=r, world_size=world, **vkw)[0] for r in range(world))
+    assert_bit_equal(var, oracle.OracleScene(tsd).render(**vkw)[0], f"random scene {seed}: textures {mat_tex.tolist()}, {vkw}")
 
 
 @pytest.mark.timeout(900)
