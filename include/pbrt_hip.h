@@ -151,7 +151,8 @@ typedef struct pbrt_hip_scene pbrt_hip_scene;
 /* number of visible HIP devices (0 when there is none; never fails) */
 int pbrt_hip_device_count(void);
 const char *pbrt_hip_last_error(void);
-const char *pbrt_hip_version(void);
+const char *pbrt_hip_version(void); /* "pbrt_hip 0.5 (gfx950)": 0.5 = round 5's ABI (pbrt_hip_scene_desc gained tri_uv / textures / n_textures at its
+                                       end, pbrt_hip_material.pad became kd_tex, flags 0 of scene_create_ex = the device builder) */
 /* identity of the build: a hash of the library's sources and kernel-shaping flags (pbrt_amd/build.py source_id).  A
  * profile taken on one build must not price another: bench.py compares this with the id stored beside the counters */
 const char *pbrt_hip_build_id(void);

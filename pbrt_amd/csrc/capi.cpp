@@ -645,7 +645,7 @@ int pbrt_hip_device_count(void) {
 }
 
 const char *pbrt_hip_last_error(void) { return pbrt_hip::last_error_message(); }
-const char *pbrt_hip_version(void) { return "pbrt_hip 0.3 (gfx950)"; }
+const char *pbrt_hip_version(void) { return "pbrt_hip 0.5 (gfx950)"; }
 #ifndef PBRT_HIP_BUILD_ID
 #define PBRT_HIP_BUILD_ID "unknown"
 #endif
