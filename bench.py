@@ -69,6 +69,8 @@ def launch_mode(gpus, single_process, env):
     if gpus < 1:
         raise SystemExit(f"--gpus {gpus}")
     if single_process and gpus > 1:
+        if world > 1:  # (every rank of a launcher would drive all the GPUs)
+            raise SystemExit(f"--single-process under a launcher with WORLD_SIZE={world}: start it as ONE process")
         return "in-process", 1
     if world == gpus:
         return ("ranks", world) if ("RANK" in env or world > 1) else ("single", 1)

@@ -58,7 +58,8 @@ def test_bench_gpus_n_picks_a_launch_path_however_it_is_started():
         assert bench.launch_mode(n, False, {}) == ("in-process", 1)                       # bare: the in-library path
         assert bench.launch_mode(n, True, {}) == ("in-process", 1)                        # --single-process
         assert bench.launch_mode(n, False, {"WORLD_SIZE": str(n), "RANK": "1"}) == ("ranks", n)  # the driver's launch
-        assert bench.launch_mode(n, True, {"WORLD_SIZE": str(n), "RANK": "1"}) == ("in-process", 1)
+        with pytest.raises(SystemExit):  # --single-process inside a multi-rank launch: every rank would drive all the GPUs
+            bench.launch_mode(n, True, {"WORLD_SIZE": str(n), "RANK": "1"})
     for env in ({"WORLD_SIZE": "4", "RANK": "0"}, {"WORLD_SIZE": "1", "RANK": "0"}):  # a launcher that disagrees with --gpus
         with pytest.raises(SystemExit):
             bench.launch_mode(8, False, env)
