@@ -93,16 +93,20 @@ def test_struct_layouts_match_header(tmp_path):
     """include/pbrt_hip.h compiles as plain C, and the ctypes mirrors have the C sizes."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "pbrt_hip.h"\n#include "pbrt_hip_debug.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pbrt_hip.h"\n#include "pbrt_hip_debug.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(pbrt_hip_material),sizeof(pbrt_hip_light),sizeof(pbrt_hip_sphere),sizeof(pbrt_hip_scene_desc),"
-                   "sizeof(pbrt_hip_render_desc),sizeof(pbrt_hip_stats));return 0;}\n")
+                   "sizeof(pbrt_hip_render_desc),sizeof(pbrt_hip_stats),sizeof(pbrt_hip_texture),offsetof(pbrt_hip_scene_desc,tri_uv),"
+                   "offsetof(pbrt_hip_material,kd_tex));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    mirrors = [_lib.Material, _lib.Light, _lib.Sphere, _lib.SceneDesc, _lib.RenderDesc, _lib.Stats]
-    assert sizes == [C.sizeof(m) for m in mirrors]
-    assert sizes[:3] == [32, 32, 32]
+    mirrors = [_lib.Material, _lib.Light, _lib.Sphere, _lib.SceneDesc, _lib.RenderDesc, _lib.Stats, _lib.Texture]
+    assert sizes[:7] == [C.sizeof(m) for m in mirrors]
+    assert sizes[:3] == [32, 32, 32] and sizes[6] == 64
+    assert sizes[7] == _lib.SceneDesc.tri_uv.offset and sizes[8] == _lib.Material.kd_tex.offset == 28
+    from oracle import binding as ob  # the oracle's independent mirrors have the same layout (a test hands both the same bytes)
+    assert [C.sizeof(m) for m in (ob.Material, ob.Light, ob.Sphere, ob.SceneDesc, ob.RenderDesc, ob.Texture)] == sizes[:5] + [64]
 
 
 @pytest.mark.skipif(pbrt_amd.device_count() > 0, reason="checks the no-device behaviour")
