@@ -111,7 +111,8 @@ def lib(native=False):
         l.orc_sobol_dims.restype = C.c_int
         l.orc_sobol_matrix.argtypes = [C.c_int, C.c_void_p]
         l.orc_sobol_points.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
-        l.orc_halton_points.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        l.orc_halton_points.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        l.orc_halton_points.restype = C.c_uint32
         l.orc_quad_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
         _libs[native] = l
     return _libs[native]
@@ -146,9 +147,12 @@ def sobol_matrices():
     return out
 
 
-def halton_points(d, key, n):
-    """(u float32[n], v uint32[n]): the Halton sampler's dimension d (base = the d-th prime) at point indices 0 .. n - 1 under `key`"""
-    u = np.zeros(n, np.float32); v = np.zeros(n, np.uint32); lib().orc_halton_points(d, key, n, _p(u), _p(v)); return u, v
+def halton_points(d, key, n, spp_mask=None):
+    """(u float32[n], head uint32[n], b^D): the Halton sampler's dimension d (base b = the d-th prime) at point indices 0 .. n - 1 under
+    `key`, in a frame whose largest sample index is spp_mask (default: n rounded up to 2^k, minus 1)"""
+    if spp_mask is None:
+        spp_mask = (1 << max(n - 1, 0).bit_length()) - 1
+    u = np.zeros(n, np.float32); v = np.zeros(n, np.uint32); pw = lib().orc_halton_points(d, key, spp_mask, n, _p(u), _p(v)); return u, v, pw
 
 
 def sobol_points(n):

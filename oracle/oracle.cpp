@@ -207,14 +207,15 @@ class SobolNdSampler : public SobolSampler {
 
 // Halton sampler proper (Sampler "halton", the reference's default sampler NAME, api.rs:235 -- it has no sampler
 // code): request j < 64 of a sample takes the dimensions (2j, 2j + 1), dimension d the radical inverse of the sample's number in
-// the pixel in base p_d (the d-th prime, 2 .. 719), every digit position scrambled per pixel and dimension.  Integer arithmetic
-// up to the last step:
+// the pixel in base p_d (the d-th prime, 2 .. 719), every digit scrambled per pixel and dimension, the digits no sample of the frame
+// has drawn together as one random tail.  Integer arithmetic up to the last step:
 //   base 2 (d = 0):  v = bit-reversal of the index, XOR mix32(key + 0x9e3779b9);  u = v * 2^-32
-//   base b > 2:      K = the largest K with b^K < 2^32 digits a_0 .. a_{K-1} of the index (least significant first; the index is
-//                    below 2^20, higher digits are zeros and are scrambled like any other);
-//                    a'_k = (a_k m_k + c_k) mod b with h = mix32(key + (d + 1) 0x9e3779b9 + k 0x85ebca6b),
-//                    m_k = 1 + (((h & 0xffff) (b - 1)) >> 16), c_k = ((h >> 16) b) >> 16   (a random linear bijection of Z_b);
-//                    v = sum a'_k b^(K-1-k);  u = (float)v * (1 / (float)b^K)
+//   base b > 2:      D = the digits the frame's largest sample index can have: the smallest D with b^D > spp_mask (spp_mask =
+//                    2^ceil(log2 spp) - 1);  h_0 = mix32(key + (d + 1) 0x9e3779b9), h_{k+1} = h_k 0x9e3779b1 + 0x7f4a7c15;
+//                    digits a_0 .. a_{D-1} of the index (least significant first; leading zeros are digits like any other):
+//                    m_k = 1 + (((h_{k+1} >> 16) (b - 1)) >> 16), c_k = ((h_{k+1} & 0xffff) b) >> 16, a'_k = (a_k m_k + c_k) mod b
+//                    (a random linear bijection of Z_b per digit position); head = sum a'_k b^(D-1-k);
+//                    u = ((float)head + (float)h_{D+1} * 2^-32) * (1 / (float)b^D)
 //   u = min(u, 1 - eps).  Requests j >= 64 are the padded requests of 3.10 (as for sampler 2).
 static const uint32_t *halton_primes() {
   static uint32_t p[128];
@@ -231,38 +232,40 @@ static const uint32_t *halton_primes() {
 class HaltonSampler : public SobolSampler {
  public:
   HaltonSampler(uint32_t nx, uint32_t ny, uint64_t seed, const Scene &s, int pad_x = 0, int pad_y = 0) : SobolSampler(nx, ny, seed, s, pad_x, pad_y) {}
-  static uint32_t scrambled_radical_inverse(uint32_t d, uint32_t index, uint32_t key, float *u) {
+  // -> the integer head (base 2: the scrambled 32-bit value); *pw_out = b^D (base 2: 0)
+  static uint32_t scrambled_radical_inverse(uint32_t d, uint32_t index, uint32_t key, uint32_t spp_mask, float *u, uint32_t *pw_out = nullptr) {
     const float one_minus_eps = 1.0f - std::numeric_limits<float>::epsilon();
     const uint32_t b = halton_primes()[d];
-    uint32_t v = 0;
+    uint32_t v = 0, pw = 0;
     float f;
     if (b == 2u) {
       for (uint32_t k = 0; k < 32; k++) v |= ((index >> k) & 1u) << (31 - k);
       v ^= mix32(key + (d + 1u) * 0x9e3779b9u);
       f = (float)v * 2.3283064365386963e-10f;
     } else {
-      uint32_t K = 0;
-      uint64_t bk = 1;
-      while (bk * b < (1ull << 32)) { bk *= b; K++; }
-      uint32_t n = index;
-      for (uint32_t k = 0; k < K; k++) {
+      uint32_t h = mix32(key + (d + 1u) * 0x9e3779b9u), n = index;
+      pw = 1u;
+      do {
+        pw *= b;
         const uint32_t a = n % b;
         n /= b;
-        const uint32_t h = mix32(key + (d + 1u) * 0x9e3779b9u + k * 0x85ebca6bu);
-        const uint32_t m = 1u + (((h & 0xffffu) * (b - 1u)) >> 16), c = ((h >> 16) * b) >> 16;
+        h = h * 0x9e3779b1u + 0x7f4a7c15u;
+        const uint32_t m = 1u + (((h >> 16) * (b - 1u)) >> 16), c = ((h & 0xffffu) * b) >> 16;
         v = v * b + (a * m + c) % b;
-      }
-      f = (float)v * (1.0f / (float)(uint32_t)bk);
+      } while (pw <= spp_mask);
+      h = h * 0x9e3779b1u + 0x7f4a7c15u;
+      f = ((float)v + (float)h * 2.3283064365386963e-10f) * (1.0f / (float)pw);
     }
     *u = f > one_minus_eps ? one_minus_eps : f;
+    if (pw_out) *pw_out = pw;
     return v;
   }
   void Get2D(float *u1, float *u2) override {
     if (j_ >= 64u) { SobolSampler::Get2D(u1, u2); return; }
-    const uint32_t d0 = 2u * j_;
+    const uint32_t d0 = 2u * j_, mask = (1u << log2_) - 1u;
     j_++;
-    scrambled_radical_inverse(d0, s_, key_, u1);
-    scrambled_radical_inverse(d0 + 1u, s_, key_, u2);
+    scrambled_radical_inverse(d0, s_, key_, mask, u1);
+    scrambled_radical_inverse(d0 + 1u, s_, key_, mask, u2);
   }
 };
 
@@ -642,9 +645,12 @@ struct orc_scene {
 extern "C" {
 
 int orc_sobol_dims(void) { return kSobolDims; }
-// Halton sampler: u and the integer numerator of dimension d for indices 0 .. n - 1 under `key` (tests of the radical inverse)
-void orc_halton_points(uint32_t d, uint32_t key, uint32_t n, float *u, uint32_t *v) {
-  for (uint32_t i = 0; i < n; i++) v[i] = HaltonSampler::scrambled_radical_inverse(d, i, key, &u[i]);
+// Halton sampler: u and the integer head of dimension d for indices 0 .. n - 1 under `key` in a frame whose largest sample index is
+// spp_mask (tests of the radical inverse); returns b^D, the head's modulus (0 for base 2)
+uint32_t orc_halton_points(uint32_t d, uint32_t key, uint32_t spp_mask, uint32_t n, float *u, uint32_t *v) {
+  uint32_t pw = 0;
+  for (uint32_t i = 0; i < n; i++) v[i] = HaltonSampler::scrambled_radical_inverse(d, i, key, spp_mask, &u[i], &pw);
+  return pw;
 }
 void orc_sobol_matrix(int dim, uint32_t *out52) { sobol_matrix(dim, out52); }
 void orc_sobol_points(uint32_t key_seed, uint32_t n, float *out2n) {

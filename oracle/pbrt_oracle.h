@@ -98,8 +98,9 @@ typedef struct orc_scene orc_scene;
 int orc_sobol_dims(void);
 void orc_sobol_matrix(int dim, uint32_t *out52);
 void orc_sobol_points(uint32_t key_seed, uint32_t n, float *out2n);
-/* Halton sampler (sampler 3): value u[i] and integer numerator v[i] of dimension d (base = the d-th prime) for point indices 0 .. n - 1 */
-void orc_halton_points(uint32_t d, uint32_t key, uint32_t n, float *u, uint32_t *v);
+/* Halton sampler (sampler 3): value u[i] and integer head v[i] of dimension d (base b = the d-th prime) for point indices 0 .. n - 1 of a
+ * frame whose largest sample index is spp_mask; returns b^D, the modulus of the head (0 for base 2) */
+uint32_t orc_halton_points(uint32_t d, uint32_t key, uint32_t spp_mask, uint32_t n, float *u, uint32_t *v);
 
 /* ---- reference-pinned primitives ---- */
 void orc_rng_default_u32(uint32_t *out, int n);

@@ -740,29 +740,29 @@ __device__ __forceinline__ uint32_t mix32(uint32_t v) {  // lowbias32
 // SND (sampler 2): requests 0 .. 15 of a sample take their own Sobol' dimensions (2j, 2j + 1) from the
 // generator matrices in `mat` at point index s, XOR-scrambled per dimension; later requests are the padded ones below.
 // Sampler 3: dimension d of the Halton sampler at point index i under the pixel's key: the radical inverse of i in
-// base b = the d-th prime with every digit scrambled by a random linear bijection of Z_b.  tab = {b, K, ceil(2^32 / b), bits of
-// 1 / b^K} (host_math.hpp halton_table); n / b by the reciprocal: the estimate is the quotient or one more.
-__device__ __forceinline__ float halton_dim(const uint32_t *tab, uint32_t d, uint32_t i, uint32_t key) {
+// base b = the d-th prime, the D digits the frame's largest sample index can have (b^D > spp_mask) each scrambled by a random linear
+// bijection of Z_b, all higher digits -- zeros for every sample of the frame -- as one random tail.  tab = {b, K, ceil(2^32 / b), bits of
+// 1 / b^K} (host_math.hpp halton_table; b and the reciprocal are used): n / b by the reciprocal, the estimate is the quotient or one more.
+__device__ __forceinline__ float halton_dim(const uint32_t *tab, uint32_t d, uint32_t i, uint32_t key, uint32_t spp_mask) {
   const uint4 t = reinterpret_cast<const uint4 *>(tab)[d];
-  const uint32_t b = t.x, salt = key + (d + 1u) * 0x9e3779b9u;
-  uint32_t v = 0u;
-  if (b == 2u) {
-    v = __builtin_bitreverse32(i) ^ mix32(salt);
-  } else {
-    uint32_t n = i;
-    for (uint32_t k = 0u; k < t.y; k++) {
-      uint32_t q = __umulhi(n, t.z);
-      if (q * b > n) q--;
-      const uint32_t a = n - q * b;
-      n = q;
-      const uint32_t h = mix32(salt + k * 0x85ebca6bu);
-      const uint32_t w = a * (1u + (((h & 0xffffu) * (b - 1u)) >> 16)) + (((h >> 16) * b) >> 16);  // a m + c < b^2
-      uint32_t wq = __umulhi(w, t.z);
-      if (wq * b > w) wq--;
-      v = v * b + (w - wq * b);
-    }
-  }
-  return fminf(kOneMinusEps, (float)v * __uint_as_float(t.w));
+  const uint32_t b = t.x;
+  uint32_t h = mix32(key + (d + 1u) * 0x9e3779b9u);
+  if (b == 2u) return fminf(kOneMinusEps, (float)(__builtin_bitreverse32(i) ^ h) * 2.3283064365386963e-10f);
+  uint32_t v = 0u, n = i, pw = 1u;
+  do {
+    pw *= b;
+    uint32_t q = __umulhi(n, t.z);
+    if (q * b > n) q--;
+    const uint32_t a = n - q * b;
+    n = q;
+    h = h * 0x9e3779b1u + 0x7f4a7c15u;
+    const uint32_t w = a * (1u + (((h >> 16) * (b - 1u)) >> 16)) + (((h & 0xffffu) * b) >> 16);  // a m + c < b^2
+    uint32_t wq = __umulhi(w, t.z);
+    if (wq * b > w) wq--;
+    v = v * b + (w - wq * b);
+  } while (pw <= spp_mask);
+  h = h * 0x9e3779b1u + 0x7f4a7c15u;
+  return fminf(kOneMinusEps, ((float)v + (float)h * 2.3283064365386963e-10f) * (1.0f / (float)pw));
 }
 // HAL (with SND): the table sampler in use is the Halton one (sampler 3), `mat` its table
 template <bool SND = false>
@@ -776,8 +776,8 @@ __device__ __forceinline__ void sample_2d(PathState &P, const bool sobol, const 
   if (SND && halton && (uint32_t)(P.rng.state >> 32) < kSobolNdRequests) {
     const uint32_t key = (uint32_t)P.rng.state, d0 = 2u * (uint32_t)(P.rng.state >> 32);
     P.rng.state += 1ull << 32;  // next request
-    u1 = halton_dim(mat, d0, P.s, key);
-    u2 = halton_dim(mat, d0 + 1u, P.s, key);
+    u1 = halton_dim(mat, d0, P.s, key, spp_mask);
+    u2 = halton_dim(mat, d0 + 1u, P.s, key, spp_mask);
     return;
   }
   if (SND && (uint32_t)(P.rng.state >> 32) < kSobolNdRequests) {
@@ -816,7 +816,7 @@ template <bool SND = false>
 __device__ __forceinline__ float sample_1d(PathState &P, const bool sobol, const uint32_t spp_mask, const uint32_t *mat = nullptr, const bool halton = false) {
   if (!sobol) return pcg_float(P.rng);
   if (SND && halton && (uint32_t)(P.rng.state >> 32) < kSobolNdRequests) {  // (a 1-D request takes the first coordinate of its pair)
-    const float u = halton_dim(mat, 2u * (uint32_t)(P.rng.state >> 32), P.s, (uint32_t)P.rng.state);
+    const float u = halton_dim(mat, 2u * (uint32_t)(P.rng.state >> 32), P.s, (uint32_t)P.rng.state, spp_mask);
     P.rng.state += 1ull << 32;
     return u;
   }
