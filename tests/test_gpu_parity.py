@@ -222,6 +222,20 @@ def test_render_limits(gpu):
         sc.render_wait()
 
 
+def test_maximum_sample_count_matches_oracle(gpu, oracle):
+    """The largest sample count the boundary takes -- PBRT_HIP_MAX_SPP = 2^20 = 1024 x 1024 strata -- on a one-pixel crop window of
+    the Cornell-style box: 16 chunks of 65 536 samples, the 20-bit sample index full, the longest RNG streams and (Halton) the most
+    digits any frame can have (13 in base 3); bit-equal to the oracle, weight 2^20."""
+    sd = scenes.cornell_scene(64, 64, crop=(0.5, 0.5 + 1 / 64, 0.25, 0.25 + 1 / 64))
+    o = oracle.OracleScene(sd)
+    with gpu.Scene(sd) as sc:
+        for sampler in ("stratified", "halton"):
+            kw = dict(max_depth=5, spp=(1024, 1024), seed=1, sampler=sampler)
+            film, st = sc.render(**kw)
+            assert film.shape == (1, 1, 4) and film[0, 0, 3] == float(1 << 20) and st["samples"] == 1 << 20
+            assert_bit_equal(film, o.render(**kw)[0], f"one pixel at 2^20 spp, {sampler}")
+
+
 @pytest.mark.parametrize("n_gpus", [1, 2])
 def test_multi_gpu_render_in_one_process(gpu, oracle, n_gpus):
     """pbrt_hip_multi_*: the scene replicated device to device, one stream per GPU, ONE RCCL gather (a group call of
