@@ -102,7 +102,7 @@ typedef struct {
 #define PBRT_HIP_INTEGRATOR_PATH_MIS 2 /* Integrator "path" "bool mis" "true": the path integrator with the direct-light estimate
                                           MULTIPLE-IMPORTANCE-SAMPLED as pbrt-v3's path integrator does (power heuristic between the
                                           one light sample and the BSDF-sampled bounce ray: DESIGN.md 3.14; integrator 0 is SURVEY A8's
-                                          "no MIS in v1").  Default filter, no counter flags */
+                                          "no MIS in v1").  Not with the counter flags */
 #define PBRT_HIP_FLAG_COUNTERS 1u    /* count nodes visited / triangles tested of the canonical walk:
                                         runs the exact-order instantiation of the kernel, equal to the oracle's counters */
 #define PBRT_HIP_FLAG_WALK_COUNTERS 2u /* count what the production kernel itself does instead: nodes_visited = 64-byte
@@ -115,10 +115,10 @@ typedef struct {
 #define PBRT_HIP_SAMPLER_SOBOL_ND 2   /* Sampler "sobol": Sobol' proper -- request j of a sample takes its own dimensions (2j, 2j + 1)
                                          of the first 128 of the reference's table (sobolmatrices.rs:81): 64 requests, every one a
                                          path of maxdepth 16 can make; later requests the padded scheme of sampler 1 (DESIGN.md
-                                         3.12).  Not with the counter flags, not with a box filter radius other than 0.5 */
+                                         3.12).  Not with the counter flags */
 #define PBRT_HIP_SAMPLER_HALTON 3     /* Sampler "halton" -- the reference's DEFAULT sampler name (api.rs:235): scrambled radical
                                          inverses in the prime bases 2 .. 719, request j of a sample on the dimensions (2j, 2j + 1)
-                                         for 64 requests.  Same restrictions as sampler 2 */
+                                         for 64 requests.  Not with the counter flags */
 #define PBRT_HIP_MAX_SPP (1u << 20)   /* spp_x * spp_y: the kernels pack the sample index into 20 bits */
 #define PBRT_HIP_MAX_DEPTH 1023u      /* max_depth: the bounce count is packed into 10 bits */
 

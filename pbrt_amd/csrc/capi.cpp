@@ -1074,10 +1074,10 @@ static int check_render_desc(const pbrt_hip_scene *s, const pbrt_hip_render_desc
   if (fx > 16.f || fy > 16.f) return fail(PBRT_HIP_ERR_LIMIT, "render: filter radius above 16 pixels");
   if ((fx != 0.5f || fy != 0.5f) && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
     return fail(PBRT_HIP_ERR_INVALID, "render: the counter flags need the default box filter (radius 0.5)");
-  if ((s->textured || r->integrator == PBRT_HIP_INTEGRATOR_PATH_MIS) && ((r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)) || fx != 0.5f || fy != 0.5f))
-    return fail(PBRT_HIP_ERR_LIMIT, "render: textured materials / the MIS integrator render with the default filter and no counter flags (the variants are not combined)");
-  if ((fx != 0.5f || fy != 0.5f) && table_sampler)
-    return fail(PBRT_HIP_ERR_LIMIT, "render: the Sobol' / Halton samplers (2, 3) with a box filter radius other than 0.5 are not instantiated");
+  // (textures, the MIS integrator, the table samplers and a wide box filter combine freely -- render_kernel_x --; only the counting
+  // instantiations exist for the default path alone)
+  if ((s->textured || r->integrator == PBRT_HIP_INTEGRATOR_PATH_MIS) && (r->flags & (PBRT_HIP_FLAG_COUNTERS | PBRT_HIP_FLAG_WALK_COUNTERS)))
+    return fail(PBRT_HIP_ERR_LIMIT, "render: the counter flags are not available for textured materials / the MIS integrator");
   if (!(r->max_sample_luminance >= 0.f)) return fail(PBRT_HIP_ERR_INVALID, "render: max_sample_luminance must be >= 0 (0 = none)");
   if (fx != 0.5f || fy != 0.5f) {
     // the fixed-point film: a sample adds at most 2^39 units to a pixel's int64 accumulator, and a pixel receives

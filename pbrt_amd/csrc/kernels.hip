@@ -865,11 +865,11 @@ __global__ void __launch_bounds__(64, (COUNT ? 1 : (SPH ? 3 : PBRT_RENDER_WAVES_
 }
 // The variants of the path that BASELINE's configs do not use, in a kernel of their own name so that the instantiations above keep
 // theirs (and their machine code): MIS = multiple importance sampling of the direct-light estimate, TEX = materials
-// whose Kd is a checkerboard texture (3.15); with the stratified / (0,2) samplers or (SND) the table samplers 2 and 3.  Default filter,
-// no counters.
-template <bool SPH, int STACK, bool MIS, bool TEX, bool SND>
+// whose Kd is a checkerboard texture (3.15) -- and every combination of the two with the table samplers (SND: 3.12, 3.13) and a box
+// filter radius other than 0.5 (WIDE: 3.11), which render_kernel instantiates one at a time.  No counters.
+template <bool SPH, int STACK, bool MIS, bool TEX, bool SND, bool WIDE>
 __global__ void __launch_bounds__(64, (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD)) render_kernel_x(const DevScene S, const RenderParams R) {
-  constexpr bool COUNT = false, EXACT = false, WIDE = false;
+  constexpr bool COUNT = false, EXACT = false;
   constexpr int STEPS = PBRT_STEPS_PER_CHECK;
 #include "render_body.inc"
 }
@@ -1058,31 +1058,38 @@ static hipError_t launch_render_t(const DevScene &S, const RenderParams &R, uint
   }
 }
 
-template <bool SPH, bool MIS, bool TEX, bool SND>
+template <bool SPH, bool MIS, bool TEX, bool SND, bool WIDE>
 static hipError_t launch_render_x(const DevScene &S, const RenderParams &R, hipStream_t st) {
   const dim3 grid(R.n_workgroups), block(64);
   const RenderStackPlan plan = render_stack_plan(S.quad_stack_need, render_force_overflow(), render_prefer_lds());
   const uint32_t lds = plan.rows * 256u;
-  if (plan.overflow) hipLaunchKernelGGL((render_kernel_x<SPH, (int)kQuadLdsStackOvf, MIS, TEX, SND>), grid, block, lds, st, S, R);
-  else hipLaunchKernelGGL((render_kernel_x<SPH, 0, MIS, TEX, SND>), grid, block, lds, st, S, R);
+  if (plan.overflow) hipLaunchKernelGGL((render_kernel_x<SPH, (int)kQuadLdsStackOvf, MIS, TEX, SND, WIDE>), grid, block, lds, st, S, R);
+  else hipLaunchKernelGGL((render_kernel_x<SPH, 0, MIS, TEX, SND, WIDE>), grid, block, lds, st, S, R);
   return hipGetLastError();
 }
+// (mis, tex, snd, wide) -> the instantiation: every combination render_kernel does not cover itself
+template <bool SPH, bool MIS, bool TEX>
+static hipError_t launch_render_x_sw(const DevScene &S, const RenderParams &R, bool snd, bool wide, hipStream_t st) {
+  if (snd) return wide ? launch_render_x<SPH, MIS, TEX, true, true>(S, R, st) : launch_render_x<SPH, MIS, TEX, true, false>(S, R, st);
+  return wide ? launch_render_x<SPH, MIS, TEX, false, true>(S, R, st) : launch_render_x<SPH, MIS, TEX, false, false>(S, R, st);
+}
 template <bool SPH>
-static hipError_t launch_render_x_pick(const DevScene &S, const RenderParams &R, bool mis, bool tex, bool snd, hipStream_t st) {
-  if (mis && tex) return snd ? launch_render_x<SPH, true, true, true>(S, R, st) : launch_render_x<SPH, true, true, false>(S, R, st);
-  if (mis) return snd ? launch_render_x<SPH, true, false, true>(S, R, st) : launch_render_x<SPH, true, false, false>(S, R, st);
-  return snd ? launch_render_x<SPH, false, true, true>(S, R, st) : launch_render_x<SPH, false, true, false>(S, R, st);
+static hipError_t launch_render_x_pick(const DevScene &S, const RenderParams &R, bool mis, bool tex, bool snd, bool wide, hipStream_t st) {
+  if (mis && tex) return launch_render_x_sw<SPH, true, true>(S, R, snd, wide, st);
+  if (mis) return launch_render_x_sw<SPH, true, false>(S, R, snd, wide, st);
+  if (tex) return launch_render_x_sw<SPH, false, true>(S, R, snd, wide, st);
+  return launch_render_x<SPH, false, false, true, true>(S, R, st);  // (a table sampler under a wide filter: the one pair left)
 }
 
 hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_local_super, uint32_t bvh_depth,
                          int counters, bool wide_filter, bool sobol_nd, hipStream_t stream, bool mis, bool textured) {
   if (n_local_super == 0) return hipSuccess;
   const bool sph = S.n_spheres > 0;
-  if (mis || textured) {  // the variants (render_kernel_x): default filter, no counters -- refused otherwise by check_render_desc
-    if (wide_filter || counters != 0) return hipErrorInvalidValue;
-    return sph ? launch_render_x_pick<true>(S, R, mis, textured, sobol_nd, stream) : launch_render_x_pick<false>(S, R, mis, textured, sobol_nd, stream);
+  if (mis || textured || (wide_filter && sobol_nd)) {  // the variants (render_kernel_x): no counters -- refused by check_render_desc
+    if (counters != 0) return hipErrorInvalidValue;
+    return sph ? launch_render_x_pick<true>(S, R, mis, textured, sobol_nd, wide_filter, stream)
+               : launch_render_x_pick<false>(S, R, mis, textured, sobol_nd, wide_filter, stream);
   }
-  if (wide_filter && sobol_nd) return hipErrorInvalidValue;  // (not instantiated: refused by check_render_desc)
   if (wide_filter) return sph ? launch_render_variant<true, true, false>(S, R, stream) : launch_render_variant<false, true, false>(S, R, stream);
   if (sobol_nd) return sph ? launch_render_variant<true, false, true>(S, R, stream) : launch_render_variant<false, false, true>(S, R, stream);
   if (counters == 0 && kExperimentLaunch) {  // (ray log / phase probe builds: experiments.inc)

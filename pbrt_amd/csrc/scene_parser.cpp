@@ -870,25 +870,6 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     }
   }
   if (p.err != ParseError::None) return fin(false);
-  // A box filter radius other than 0.5 takes the fixed-point film path, which is instantiated for the stratified and
-  // the (0,2)-sequence sampler only: a scene that asks for the Halton sampler (or leaves the default) or for Sobol' with such a filter
-  // is rendered with the (0,2)-sequence sampler -- said, not refused (api.rs:291-332: log and continue).
-  if ((out->sampler == PBRT_HIP_SAMPLER_HALTON || out->sampler == PBRT_HIP_SAMPLER_SOBOL_ND) &&
-      !((out->filter_radius[0] == 0.5f || out->filter_radius[0] == 0.f) && (out->filter_radius[1] == 0.5f || out->filter_radius[1] == 0.f))) {
-    api.warn("Sampler \"" + out->sampler_name + "\" with a box filter radius other than 0.5: served by the (0,2)-sequence (Sobol') sampler");
-    out->sampler = PBRT_HIP_SAMPLER_SOBOL;
-  }
-  const bool wide_filter = !((out->filter_radius[0] == 0.5f || out->filter_radius[0] == 0.f) && (out->filter_radius[1] == 0.5f || out->filter_radius[1] == 0.f));
-  if (wide_filter && out->integrator == PBRT_HIP_INTEGRATOR_PATH_MIS) {
-    api.warn("Integrator \"path\" \"bool mis\" with a box filter radius other than 0.5: rendered without MIS");
-    out->integrator = PBRT_HIP_INTEGRATOR_PATH;
-  }
-  if (wide_filter && !out->textures.empty()) {
-    // (the fixed-point film path of DESIGN.md 3.11 is not instantiated with textures: the pattern gives way to its mean colour)
-    bool any = false;
-    for (pbrt_hip_material &m : out->mats) { any = any || m.kd_tex != 0u; m.kd_tex = 0u; }
-    if (any) api.warn("a textured Kd with a box filter radius other than 0.5: the texture's mean colour is used");
-  }
   {  // corner (u, v) travel only when some triangle's material is textured
     bool textured = false;
     for (uint16_t m : out->mat_id) textured = textured || out->mats[m].kd_tex != 0u;

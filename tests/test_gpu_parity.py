@@ -565,10 +565,13 @@ def test_checkerboard_texture(gpu, oracle):
                 assert_bit_equal(film, o.render(**kw)[0], f"textured plane + mirror sphere, {sampler}, builder {builder}")
             kw = dict(max_depth=5, spp=(3, 2), seed=4)
             assert_bit_equal(sum(sc.render(rank=r, world_size=3, **kw)[0] for r in range(3)), o.render(**kw)[0], "three ranks")
-            for bad in (dict(counters=True), dict(counters="walk"), dict(filter_width=(1.5, 1.5))):
+            for bad in (dict(counters=True), dict(counters="walk")):
                 with pytest.raises(_lib.PbrtHipError) as e:
                     sc.render(**dict(kw, **bad))
                 assert e.value.code == -4
+            for extra in (dict(filter_width=(1.5, 1.5)), dict(filter_width=(2.0, 0.75), sampler="halton", integrator=2)):  # every variant at once
+                wkw = dict(kw, **extra)
+                assert_bit_equal(sc.render(**wkw)[0], o.render(**wkw)[0], f"textured plane under a wide box filter: {extra}")
     # a textured material without corner (u, v) is an invalid scene, not a silent constant colour
     sd.tri_uv = np.zeros((0, 6), np.float32)
     with pytest.raises(_lib.PbrtHipError) as e:
@@ -595,10 +598,11 @@ def test_mis_integrator_matches_oracle(gpu, oracle, name, depth, spp, seed):
         plain, _ = sc.render(**dict(kw, integrator=INTEGRATOR_PATH))
         if name in ("cornell", "check_sphere"):
             assert not np.array_equal(plain, film)
-        for bad in (dict(counters=True), dict(filter_width=(1.5, 1.5))):
-            with pytest.raises(_lib.PbrtHipError) as e:
-                sc.render(**dict(kw, **bad))
-            assert e.value.code == -4
+        with pytest.raises(_lib.PbrtHipError) as e:
+            sc.render(**dict(kw, counters=True))
+        assert e.value.code == -4
+        wkw = dict(kw, filter_width=(1.5, 1.5), sampler="sobol_nd")
+        assert_bit_equal(sc.render(**wkw)[0], o.render(**wkw)[0], f"{name}, MIS + sampler 2 under a wide box filter")
 
 
 def test_mis_closes_the_heavy_tail_of_the_emitting_box_on_the_gpu(gpu):
@@ -1041,7 +1045,10 @@ def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
                sampler=("stratified", "sobol", "sobol_nd", "halton")[seed % 4])
     with gpu.Scene(tsd, builder="gpu" if seed % 2 else "host") as sc:
         var = sum(sc.render(rank=r, world_size=world, **vkw)[0] for r in range(world))
+        wvar = sc.render(filter_width=fw, **vkw)[0] if seed % 3 == 0 else None  # ... and all of it under the random wide box filter
     assert_bit_equal(var, oracle.OracleScene(tsd).render(**vkw)[0], f"random scene {seed}: textures {mat_tex.tolist()}, {vkw}")
+    if wvar is not None:
+        assert_bit_equal(wvar, oracle.OracleScene(tsd).render(filter_width=fw, **vkw)[0], f"random scene {seed}: the variants under box filter {fw}")
 
 
 @pytest.mark.timeout(900)
@@ -1293,12 +1300,13 @@ def test_sobol_nd_sampler_matches_oracle(gpu, oracle, name, integrator, depth, s
         film, _ = sc.render(**kw)
         acc = sum(sc.render(rank=r, world_size=3, **kw)[0] for r in range(3))
         from pbrt_amd import _lib
-        for bad, code in ((dict(counters=True), -1), (dict(filter_width=(1.5, 1.5)), -4)):
-            with pytest.raises(_lib.PbrtHipError) as e:
-                sc.render(**dict(kw, **bad))
-            assert e.value.code == code
+        with pytest.raises(_lib.PbrtHipError) as e:
+            sc.render(**dict(kw, counters=True))
+        assert e.value.code == -1
+        wide, _ = sc.render(**dict(kw, filter_width=(1.5, 1.25)))  # (the table samplers under a wide box filter: render_kernel_x)
         other, _ = sc.render(**dict(kw, sampler="sobol"))
     assert_bit_equal(film, ref, f"{name} film, sampler {sampler}")
+    assert_bit_equal(wide, oracle.OracleScene(sd).render(**dict(kw, filter_width=(1.5, 1.25)))[0], f"{name}, sampler {sampler}, box filter 1.5 x 1.25")
     assert_bit_equal(acc, ref, "three ranks")
     assert not np.array_equal(other, film)
 

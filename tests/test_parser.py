@@ -198,10 +198,11 @@ def test_sampler_names():
 
 def test_integrator_mis_switch():
     """Integrator "path" "bool mis" "true" selects integrator 2; the default stays the estimator BASELINE's configs are
-    pinned on; with a wide box filter the switch is dropped with a warning (the variants are not combined)."""
+    pinned on.  The variants combine freely with a wide box filter, the Halton sampler and textures (render_kernel_x): nothing is
+    dropped, nothing warned about."""
     assert loader.load_string('Integrator "path"').integrator == 0
     ls = loader.load_string('Integrator "path" "bool mis" "true" "integer maxdepth" 7')
     assert ls.integrator == 2 and ls.max_depth == 7 and not ls.warnings
     assert loader.load_string('Integrator "directlighting" "bool mis" "true"').integrator == 1
-    ls = loader.load_string('PixelFilter "box" "float xwidth" 2 "float ywidth" 2\nIntegrator "path" "bool mis" "true"\nWorldBegin\nWorldEnd\n')
-    assert ls.integrator == 0 and any("without MIS" in w for w in ls.warnings)
+    ls = loader.load_string('PixelFilter "box" "float xwidth" 2 "float ywidth" 2\nSampler "halton"\nIntegrator "path" "bool mis" "true"\nWorldBegin\nWorldEnd\n')
+    assert ls.integrator == 2 and ls.sampler == 3 and ls.filter_width == (2.0, 2.0) and not ls.warnings
