@@ -84,6 +84,19 @@ def test_kernel_isa_ids():
     assert any(k.startswith("intersect_kernel<") for k in ids) and "merge_kernel" in " ".join(ids)
 
 
+def test_committed_profiles_price_the_built_kernel():
+    """profiles/pmc_<workload>.json carry the id of the kernel their counters were taken on; bench.py withholds roofline.frac when the
+    loaded library's kernel of that name has another one.  The tree as committed must not be in that state: the production instantiation
+    built from these sources IS the one the committed counters belong to (a kernel change without a new measurement set fails here
+    before it ships a bench line without its roofline)."""
+    import json
+    from pbrt_amd import isa_id
+    for wl in ("c3", "big"):
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{wl}.json")))
+        assert pmc.get("kernel_isa_id"), wl
+        assert isa_id.kernel_id(_lib.LIB_PATH, pmc["kernel"]) == pmc["kernel_isa_id"], (wl, isa_id.normalise(pmc["kernel"]))
+
+
 def test_library_holds_gfx950_code_object():
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"render_kernel" in blob
