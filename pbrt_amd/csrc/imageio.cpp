@@ -1,15 +1,19 @@
 // imageio.cpp -- imageio::write_image of the reference (core/imageio.rs:235-283) for the two
 // formats it implements: 8-bit RGB PNG through to_byte (imageio.rs:66-68, :245-271) and PFM
 // (imageio.rs:186-213: "PF\n{w} {h}\n{scale}\n", rows bottom to top, host-endian floats, scale -1 on
-// little-endian hosts).  The PNG stream uses stored (uncompressed) deflate blocks: the reference
-// delegates compression to the `png` crate, which carries no arithmetic of the path, and any
-// conforming decoder returns the same bytes.
+// little-endian hosts).  The PNG stream is compressed here (round 5; stored blocks until then): adaptive row filters (the
+// minimum-sum-of-absolute-differences heuristic over None / Sub / Up / Paeth) and deflate with LZ77 matches (32 KB window, hash
+// chains, lazy matching) in blocks coded the cheapest of stored / fixed Huffman / dynamic Huffman (RFC 1951 3.2.4-3.2.7).  The reference delegates compression to the `png` crate, which carries no
+// arithmetic of the path: any conforming decoder returns the same bytes, and the tests decode with this file's own inflate AND with an
+// independent one (PIL).
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pbrt_hip.h"
@@ -43,26 +47,271 @@ void chunk(std::vector<uint8_t> &out, const char type[4], const std::vector<uint
   be32(out, crc32(td.data(), td.size()) ^ 0xffffffffu);
 }
 
-bool write_png(const char *name, const float *rgb, int w, int h) {
-  std::vector<uint8_t> raw;  // filter byte 0 + RGB8 per row
-  raw.reserve((size_t)h * (3 * (size_t)w + 1));
-  for (int y = 0; y < h; y++) {
-    raw.push_back(0);
-    for (int x = 0; x < 3 * w; x++) raw.push_back(pbrt_hip::to_byte(rgb[(size_t)y * 3 * w + x]));
+// ---- deflate (RFC 1951): LZ77 over hash chains with one-step lazy matching; per block the cheapest of stored, fixed-Huffman and
+// dynamic-Huffman coding ----
+struct BitWriter {
+  std::vector<uint8_t> &out;
+  uint64_t acc = 0;
+  int n = 0;
+  explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+  void bits(uint32_t v, int k) {  // k <= 16 bits, least significant first
+    acc |= (uint64_t)v << n;
+    n += k;
+    while (n >= 8) { out.push_back((uint8_t)acc); acc >>= 8; n -= 8; }
   }
-  std::vector<uint8_t> z = {0x78, 0x01};
+  void code(uint32_t c, int k) {  // a Huffman code: most significant bit first
+    uint32_t r = 0;
+    for (int i = 0; i < k; i++) r |= ((c >> i) & 1u) << (k - 1 - i);
+    bits(r, k);
+  }
+  void flush() { if (n > 0) { out.push_back((uint8_t)acc); acc = 0; n = 0; } }
+};
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+inline int len_symbol(uint32_t len) { int i = 28; while (kLenBase[i] > len) i--; return i; }
+inline int dist_symbol(uint32_t dist) { int i = 29; while (kDistBase[i] > dist) i--; return i; }
+
+// Code lengths (<= limit) of a prefix code for `freq`: Huffman's algorithm, then the over-long codes folded back by moving leaves until
+// the Kraft sum is 1 again, the longest lengths going to the rarest symbols.  Fewer than two used symbols get two codes of one bit, so
+// that the code is complete for every decoder.
+void huff_lengths(const uint32_t *freq, int n, int limit, uint8_t *len) {
+  std::vector<int> sym;
+  for (int i = 0; i < n; i++) { len[i] = 0; if (freq[i]) sym.push_back(i); }
+  if (sym.size() < 2) {
+    const int only = sym.empty() ? 0 : sym[0];
+    len[only] = 1;
+    len[only == 0 ? 1 : 0] = 1;
+    return;
+  }
+  std::stable_sort(sym.begin(), sym.end(), [&](int x, int y) { return freq[x] < freq[y]; });
+  const int m = (int)sym.size();
+  std::vector<uint64_t> w(2 * m - 1);
+  std::vector<int> parent(2 * m - 1, -1);
+  for (int i = 0; i < m; i++) w[i] = freq[sym[i]];
+  int leaf = 0, inner = m, made = m;  // two queues: the sorted leaves and the interior nodes in the order they were made
+  auto take = [&]() { return (leaf < m && (inner >= made || w[leaf] <= w[inner])) ? leaf++ : inner++; };
+  while (made < 2 * m - 1) {
+    const int x = take(), y = take();
+    w[made] = w[x] + w[y];
+    parent[x] = parent[y] = made;
+    made++;
+  }
+  std::vector<int> depth(2 * m - 1, 0), count(64, 0);
+  for (int i = 2 * m - 3; i >= 0; i--) depth[i] = depth[parent[i]] + 1;
+  for (int i = 0; i < m; i++) count[depth[i] > limit ? limit : depth[i]]++;
+  uint64_t kraft = 0;
+  for (int l = 1; l <= limit; l++) kraft += (uint64_t)count[l] << (limit - l);
+  while (kraft > (1ull << limit)) {  // one code of the greatest length pairs up with a shorter one pushed down a level
+    count[limit]--;
+    for (int l = limit - 1; l >= 1; l--)
+      if (count[l]) { count[l]--; count[l + 1] += 2; break; }
+    kraft--;
+  }
+  int at = 0;
+  for (int l = limit; l >= 1; l--)
+    for (int k = 0; k < count[l]; k++) len[sym[at++]] = (uint8_t)l;
+}
+void canonical_codes(const uint8_t *len, int n, uint16_t *code) {  // RFC 1951 3.2.2
+  int count[16] = {0}, next[16] = {0};
+  for (int i = 0; i < n; i++) count[len[i]]++;
+  count[0] = 0;
+  for (int l = 1, c = 0; l < 16; l++) { c = (c + count[l - 1]) << 1; next[l] = c; }
+  for (int i = 0; i < n; i++) code[i] = len[i] ? (uint16_t)next[len[i]]++ : 0;
+}
+
+struct Token { uint16_t len_or_lit, dist; };  // dist == 0: a literal
+
+void write_tokens(BitWriter &bw, const Token *t, size_t n, const uint8_t *ll_len, const uint16_t *ll_code, const uint8_t *d_len, const uint16_t *d_code) {
+  for (size_t i = 0; i < n; i++) {
+    if (t[i].dist == 0) { bw.code(ll_code[t[i].len_or_lit], ll_len[t[i].len_or_lit]); continue; }
+    const int li = len_symbol(t[i].len_or_lit), di = dist_symbol(t[i].dist);
+    bw.code(ll_code[257 + li], ll_len[257 + li]);
+    if (kLenExtra[li]) bw.bits(t[i].len_or_lit - kLenBase[li], kLenExtra[li]);
+    bw.code(d_code[di], d_len[di]);
+    if (kDistExtra[di]) bw.bits(t[i].dist - kDistBase[di], kDistExtra[di]);
+  }
+  bw.code(ll_code[256], ll_len[256]);
+}
+
+// one deflate block for tokens [t, t + n) that cover raw[from, to)
+void write_block(BitWriter &bw, const Token *t, size_t n, const uint8_t *raw, size_t from, size_t to, bool final_block) {
+  uint32_t ll_freq[288] = {0}, d_freq[30] = {0};
+  uint64_t extra_bits = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (t[i].dist == 0) { ll_freq[t[i].len_or_lit]++; continue; }
+    const int li = len_symbol(t[i].len_or_lit), di = dist_symbol(t[i].dist);
+    ll_freq[257 + li]++; d_freq[di]++;
+    extra_bits += kLenExtra[li] + kDistExtra[di];
+  }
+  ll_freq[256] = 1;
+  uint8_t fix_ll[288], fix_d[30], dyn_ll[288], dyn_d[30];
+  for (int i = 0; i < 288; i++) fix_ll[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+  for (int i = 0; i < 30; i++) fix_d[i] = 5;
+  huff_lengths(ll_freq, 286, 15, dyn_ll);
+  huff_lengths(d_freq, 30, 15, dyn_d);
+  int hlit = 286, hdist = 30;
+  while (hlit > 257 && dyn_ll[hlit - 1] == 0) hlit--;
+  while (hdist > 1 && dyn_d[hdist - 1] == 0) hdist--;
+  // the code lengths, run-length coded with 16 (repeat previous 3-6), 17 (zeros 3-10), 18 (zeros 11-138)   (RFC 1951 3.2.7)
+  std::vector<uint8_t> all(dyn_ll, dyn_ll + hlit);
+  all.insert(all.end(), dyn_d, dyn_d + hdist);
+  std::vector<std::pair<uint8_t, uint8_t>> rle;  // {symbol, extra value}
+  for (size_t i = 0; i < all.size();) {
+    size_t run = 1;
+    while (i + run < all.size() && all[i + run] == all[i]) run++;
+    if (all[i] == 0 && run >= 3) {
+      const size_t r = run > 138 ? 138 : run;
+      if (r >= 11) rle.push_back({18, (uint8_t)(r - 11)}); else rle.push_back({17, (uint8_t)(r - 3)});
+      i += r;
+    } else if (run >= 4) {
+      rle.push_back({all[i], 0});
+      size_t r = run - 1 > 6 ? 6 : run - 1;
+      rle.push_back({16, (uint8_t)(r - 3)});
+      i += 1 + r;
+    } else {
+      rle.push_back({all[i], 0});
+      i++;
+    }
+  }
+  uint32_t cl_freq[19] = {0};
+  for (auto &e : rle) cl_freq[e.first]++;
+  uint8_t cl_len[19];
+  uint16_t cl_code[19];
+  huff_lengths(cl_freq, 19, 7, cl_len);
+  canonical_codes(cl_len, 19, cl_code);
+  static const uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  int hclen = 19;
+  while (hclen > 4 && cl_len[kOrder[hclen - 1]] == 0) hclen--;
+  uint64_t head_bits = 5 + 5 + 4 + 3 * (uint64_t)hclen;
+  for (auto &e : rle) head_bits += cl_len[e.first] + (e.first == 16 ? 2 : e.first == 17 ? 3 : e.first == 18 ? 7 : 0);
+  uint64_t dyn_bits = head_bits + extra_bits, fix_bits = extra_bits;
+  for (int i = 0; i < 286; i++) { dyn_bits += (uint64_t)ll_freq[i] * dyn_ll[i]; fix_bits += (uint64_t)ll_freq[i] * fix_ll[i]; }
+  for (int i = 0; i < 30; i++) { dyn_bits += (uint64_t)d_freq[i] * dyn_d[i]; fix_bits += (uint64_t)d_freq[i] * fix_d[i]; }
+  const uint64_t n_stored = (to - from + 65534) / 65535 + (to == from ? 1 : 0);
+  const uint64_t stored_bits = 8 * (uint64_t)(to - from) + n_stored * 40;  // 3 header bits, up to 7 of padding, LEN and NLEN
+  if (stored_bits < dyn_bits && stored_bits < fix_bits) {
+    size_t at = from;
+    do {
+      const size_t k = to - at < 65535 ? to - at : 65535;
+      bw.bits(final_block && at + k == to ? 1 : 0, 1);
+      bw.bits(0, 2);
+      bw.flush();
+      bw.bits((uint32_t)k, 16);
+      bw.bits((uint32_t)k ^ 0xffffu, 16);
+      bw.out.insert(bw.out.end(), raw + at, raw + at + k);
+      at += k;
+    } while (at < to);
+    return;
+  }
+  bw.bits(final_block ? 1 : 0, 1);
+  if (fix_bits <= dyn_bits) {
+    uint16_t ll_code[288], d_code[30];
+    canonical_codes(fix_ll, 288, ll_code);
+    canonical_codes(fix_d, 30, d_code);
+    bw.bits(1, 2);
+    write_tokens(bw, t, n, fix_ll, ll_code, fix_d, d_code);
+    return;
+  }
+  uint16_t ll_code[288], d_code[30];
+  canonical_codes(dyn_ll, 286, ll_code);
+  canonical_codes(dyn_d, 30, d_code);
+  bw.bits(2, 2);
+  bw.bits((uint32_t)(hlit - 257), 5);
+  bw.bits((uint32_t)(hdist - 1), 5);
+  bw.bits((uint32_t)(hclen - 4), 4);
+  for (int i = 0; i < hclen; i++) bw.bits(cl_len[kOrder[i]], 3);
+  for (auto &e : rle) {
+    bw.code(cl_code[e.first], cl_len[e.first]);
+    if (e.first == 16) bw.bits(e.second, 2);
+    else if (e.first == 17) bw.bits(e.second, 3);
+    else if (e.first == 18) bw.bits(e.second, 7);
+  }
+  write_tokens(bw, t, n, dyn_ll, ll_code, dyn_d, d_code);
+}
+
+// zlib stream (RFC 1950) of `raw`
+void zlib_deflate(const std::vector<uint8_t> &raw, std::vector<uint8_t> *z) {
+  z->clear();
+  z->push_back(0x78); z->push_back(0x9c);
+  BitWriter bw(*z);
+  const size_t n = raw.size();
+  constexpr uint32_t kHashBits = 15, kWindow = 32768, kMaxChain = 64, kNil = 0xffffffffu;
+  constexpr size_t kBlockTokens = 1u << 16;
+  std::vector<uint32_t> head(1u << kHashBits, kNil), prev(n ? n : 1, kNil);
+  auto hash3 = [&](size_t i) { return (((uint32_t)raw[i] | (uint32_t)raw[i + 1] << 8 | (uint32_t)raw[i + 2] << 16) * 0x9e3779b1u) >> (32 - kHashBits); };
+  auto enter = [&](size_t i) { if (i + 3 <= n) { const uint32_t hsh = hash3(i); prev[i] = head[hsh]; head[hsh] = (uint32_t)i; } };
+  auto longest = [&](size_t i, uint32_t *dist) -> uint32_t {  // the longest earlier occurrence of raw[i ...] inside the window (0 if under 3 bytes)
+    if (i + 3 > n) return 0;
+    const size_t max_len = n - i < 258 ? n - i : 258;
+    uint32_t best = 0, cand = head[hash3(i)], chain = 0;
+    while (cand != kNil && i - cand <= kWindow && chain++ < kMaxChain) {
+      if (raw[cand + best] == raw[i + best]) {
+        size_t l = 0;
+        while (l < max_len && raw[cand + l] == raw[i + l]) l++;
+        if (l > best) { best = (uint32_t)l; *dist = (uint32_t)(i - cand); if (l == max_len) break; }
+      }
+      cand = prev[cand];
+    }
+    return best >= 3 ? best : 0;
+  };
+  std::vector<Token> tok;
+  tok.reserve(kBlockTokens);
+  size_t i = 0, block_from = 0;
+  while (i < n) {
+    uint32_t dist = 0, len = longest(i, &dist);
+    enter(i);
+    if (len && len < 32 && i + 1 < n) {  // lazy: a longer match one byte on wins, this byte goes out as a literal
+      uint32_t dist2 = 0;
+      if (longest(i + 1, &dist2) > len) len = 0;
+    }
+    if (len) {
+      tok.push_back({(uint16_t)len, (uint16_t)dist});  // 32768 fits 16 bits
+      for (size_t k = 1; k < len; k++) enter(i + k);
+      i += len;
+    } else {
+      tok.push_back({raw[i], 0});
+      i++;
+    }
+    if (tok.size() == kBlockTokens && i < n) {
+      write_block(bw, tok.data(), tok.size(), raw.data(), block_from, i, false);
+      tok.clear();
+      block_from = i;
+    }
+  }
+  write_block(bw, tok.data(), tok.size(), raw.data(), block_from, n, true);
+  bw.flush();
   uint32_t a = 1, b = 0;
   for (uint8_t v : raw) { a = (a + v) % 65521u; b = (b + a) % 65521u; }
-  size_t pos = 0;
-  do {
-    size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
-    z.push_back(pos + n == raw.size() ? 1 : 0);
-    z.push_back(n & 0xff); z.push_back(n >> 8);
-    z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
-    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
-    pos += n;
-  } while (pos < raw.size());
-  be32(z, (b << 16) | a);
+  be32(*z, (b << 16) | a);
+}
+
+bool write_png(const char *name, const float *rgb, int w, int h) {
+  // scanlines with the row filter that leaves the smallest sum of absolute (signed-byte) residuals: None, Sub, Up or Paeth (PNG 9.2, 12.8)
+  const size_t stride = 3 * (size_t)w;
+  std::vector<uint8_t> raw, cur(stride), up(stride, 0), cand[4];
+  for (auto &c : cand) c.resize(stride);
+  raw.reserve((size_t)h * (stride + 1));
+  static const uint8_t kType[4] = {0, 1, 2, 4};
+  for (int y = 0; y < h; y++) {
+    for (size_t x = 0; x < stride; x++) cur[x] = pbrt_hip::to_byte(rgb[(size_t)y * stride + x]);
+    uint64_t cost[4] = {0, 0, 0, 0};
+    for (size_t x = 0; x < stride; x++) {
+      const int a = x >= 3 ? cur[x - 3] : 0, b = up[x], c = x >= 3 ? up[x - 3] : 0;
+      const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+      const int paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+      const uint8_t v[4] = {cur[x], (uint8_t)(cur[x] - a), (uint8_t)(cur[x] - b), (uint8_t)(cur[x] - paeth)};
+      for (int k = 0; k < 4; k++) { cand[k][x] = v[k]; cost[k] += (uint64_t)std::abs((int)(int8_t)v[k]); }
+    }
+    int best = 0;
+    for (int k = 1; k < 4; k++) if (cost[k] < cost[best]) best = k;
+    raw.push_back(kType[best]);
+    raw.insert(raw.end(), cand[best].begin(), cand[best].end());
+    up.swap(cur);
+  }
+  std::vector<uint8_t> z;
+  zlib_deflate(raw, &z);
   std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
   std::vector<uint8_t> ihdr;
   be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h);

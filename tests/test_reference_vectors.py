@@ -201,6 +201,56 @@ def test_roundtrip_pfm(tmp_path):  # imageio.rs:363-390
     assert np.array_equal(got, img)
 
 
+def _png_idat(path):
+    import struct
+    b, at, out, kinds = open(path, "rb").read(), 8, b"", []
+    while at < len(b):
+        n, = struct.unpack(">I", b[at:at + 4])
+        kinds.append(b[at + 4:at + 8])
+        if kinds[-1] == b"IDAT":
+            out += b[at + 8:at + 8 + n]
+        at += 12 + n
+    assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND"
+    return out
+
+
+def test_png_writer_compresses_and_other_decoders_agree(tmp_path, oracle):
+    """The writer's deflate stream (row filters, LZ77, stored / fixed / dynamic blocks -- imageio.cpp zlib_deflate) read by two decoders
+    that share no code with it: the zlib of the Python standard library on the IDAT payload, and PIL on the file.  Pixels are
+    to_byte(p) (imageio.rs:345-356) whatever the coding; sizes stay within a few per cent of zlib level 6 on the same filtered rows."""
+    import zlib
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:200, 0:300]
+    cases = {
+        "noise": rng.random((97, 131, 3), dtype=np.float32),                      # incompressible: stored blocks
+        "flat": np.full((64, 64, 3), 0.25, np.float32),                           # one long run
+        "grad": np.stack([xx / 300, yy / 200, xx / 300], -1).astype(np.float32),  # Sub / Up / Paeth rows of constants
+        "one": np.zeros((1, 1, 3), np.float32),                                   # a handful of symbols: the fixed code
+        "wide": rng.random((2, 3, 3), dtype=np.float32),
+        "render": (0.5 + 0.02 * rng.standard_normal((300, 260, 3))).astype(np.float32),  # small residuals: dynamic codes, > 64 K tokens
+        "tiles": np.kron(rng.random((12, 12, 3)), np.ones((25, 25, 1))).astype(np.float32),  # matches at distances up to the window
+        "dark": (rng.random((150, 150, 3)) ** 8).astype(np.float32),
+    }
+    block_kinds = set()
+    for name, img in cases.items():
+        img = np.ascontiguousarray(img)
+        path = tmp_path / f"{name}.png"
+        pbrt_amd.write_image(path, img)
+        h, w, _ = img.shape
+        want = np.vectorize(oracle.to_byte, otypes=[np.uint8])(img)
+        z = _png_idat(path)
+        block_kinds.add((z[2] >> 1) & 3)  # BTYPE of the first block
+        rows = np.frombuffer(zlib.decompress(z), np.uint8).reshape(h, 1 + 3 * w)
+        assert set(rows[:, 0].tolist()) <= {0, 1, 2, 4}, name
+        assert np.array_equal(np.asarray(Image.open(path)), want), name
+        assert np.array_equal(pbrt_amd.read_image(path), want.astype(np.float32) / np.float32(255)), name
+        assert len(z) <= len(zlib.compress(rows.tobytes(), 6)) * 1.05 + 64, (name, len(z))
+        assert len(z) <= rows.size + 5 * (rows.size // 65535 + 1) + 6, name  # never worse than stored blocks
+    assert block_kinds == {0, 1, 2}, block_kinds
+    assert (tmp_path / "grad.png").stat().st_size < 2000  # 180 KB of scanlines
+
+
 def test_png_reader_decodes_compressed_filtered_files(tmp_path):
     """Files from another encoder (PIL: dynamic Huffman blocks, all five row filters), RGB / RGBA / grey."""
     from PIL import Image
