@@ -1097,18 +1097,36 @@ namespace {
 // the launches of a frame.
 struct RenderScratch {
   uint32_t n_workgroups = 0, chunk_shift = 0;
+  uint32_t passes = 1;  // partials_passes
   RenderStackPlan plan{};
 };
+// The partial film sums cost 16 K bytes per pixel of the rank's share (one float4 per item, K <= 16 chunks per pixel): 1.07 GB for C3, 4.3 GB
+// for C4's 4096^2 on one GPU, and growing with the resolution.  A frame whose sums would pass the cap (2 GiB; PBRT_HIP_PARTIALS_CAP_KB for the
+// tests) is rendered in P passes over the same buffer: pass p takes the rank's super-tiles j = p + P * j', which is exactly the share of rank
+// `rank + world * p` of `world * P` ranks -- so the render kernel runs unchanged -- and the merge puts tile j' of the pass at tile j of the
+// rank's slab.  Every pixel keeps its samples, chunks and order of additions: the film is the one-pass film bit for bit.  Passes also keep
+// the item numbers of a launch inside 32 bits.
+uint32_t partials_passes(uint32_t n_local, uint32_t n_chunks) {
+  if (n_local == 0) return 1;
+  const uint64_t cap_bytes = (uint64_t)std::max<uint32_t>(1u, tuning("PBRT_HIP_PARTIALS_CAP_KB", 2u << 20, 1l << 30)) << 10;
+  const uint64_t per_tile = 4096ull * n_chunks * 16ull;
+  uint64_t tiles = std::max<uint64_t>(1, cap_bytes / per_tile);
+  tiles = std::min<uint64_t>(tiles, ((1ull << 32) - 1) / (4096ull * n_chunks));
+  return (uint32_t)((n_local + tiles - 1) / tiles);
+}
 int ensure_render_scratch(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, const FilmGeom &fg, const Shard &sh, RenderScratch *out) {
   const uint32_t spp = r->spp_x * r->spp_y;
   out->chunk_shift = sample_chunk_shift(spp);
   const uint32_t n_chunks = 1u << out->chunk_shift;  // K: DESIGN.md 3.1
-  if ((uint64_t)sh.n_local * 4096u * n_chunks >= (1ull << 32)) return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for 32-bit item numbers");
+  out->passes = fg.wide ? 1u : partials_passes(sh.n_local, n_chunks);
+  const uint32_t n_pass_tiles = (sh.n_local + out->passes - 1) / out->passes;  // of pass 0, the largest
+  if ((uint64_t)n_pass_tiles * 4096u * n_chunks >= (1ull << 32)) return fail(PBRT_HIP_ERR_LIMIT, "render: film too large for 32-bit item numbers");
+  if ((uint64_t)r->world_size * out->passes >= (1ull << 32)) return fail(PBRT_HIP_ERR_LIMIT, "render: world_size x passes does not fit 32 bits");
   // (scenes with spheres run a kernel with a bigger register budget, 3 waves per SIMD: kernels.hip)
   out->plan = render_stack_plan(s->dev.quad_stack_need, render_force_overflow(), render_prefer_lds());
   // (the instantiations for another filter radius and for the Sobol' sampler fit the 96 VGPRs of 5 waves per SIMD like the default one)
   const uint32_t waves_per_cu = s->dev.n_spheres ? std::min(kRenderWavesPerCuSpheres, out->plan.waves_per_cu) : out->plan.waves_per_cu;
-  out->n_workgroups = std::min<uint32_t>(sh.n_local * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
+  out->n_workgroups = std::min<uint32_t>(n_pass_tiles * 64u * n_chunks, std::max<uint32_t>(1u, tuning("PBRT_HIP_RENDER_WORKGROUPS", s->n_cu * waves_per_cu, 1 << 20)));
   if (r->sampler == PBRT_HIP_SAMPLER_SOBOL_ND && s->d_sobol.n == 0) {
     static_assert(kSobolNdDims == 2 * (int)kSobolNdRequests, "sampler 2: two dimensions per request");
     std::vector<uint32_t> mat((size_t)kSobolNdDims * 32);
@@ -1130,9 +1148,9 @@ int ensure_render_scratch(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, cons
     if (s->d_lane_state.n < need) { s->d_lane_state.release(); HIP_TRY(s->d_lane_state.alloc(need)); }
   }
   if (!fg.wide) {
-    const size_t need = (size_t)sh.n_local * 4096u * n_chunks;  // one float4 per item
-    // (one float4 per item = 16 K bytes per pixel of the rank's share: C3 1.07 GB, C4's 4096^2 x 16 chunks 4.3 GB on one
-    // GPU; the buffer follows the frame: released when a later render needs less than a quarter of it)
+    const size_t need = (size_t)n_pass_tiles * 4096u * n_chunks;  // one float4 per item of a pass
+    // (C3 1.07 GB in one pass; C4's 4096^2 x 16 chunks on one GPU: 3 passes over 1.43 GB; the buffer follows the frame: released when a
+    // later render needs less than a quarter of it)
     if (s->d_partials.n < need || s->d_partials.n / 4 > need) { s->d_partials.release(); HIP_TRY(s->d_partials.alloc(need)); }
   }
   {
@@ -1211,7 +1229,6 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     // An item is one CHUNK (a K-th of the samples, K <= 16 with at least 32 samples per chunk) of one pixel: DESIGN.md 3.1.
     R.chunk_shift = rs.chunk_shift;
     const uint32_t n_chunks = 1u << R.chunk_shift;  // K: DESIGN.md 3.1
-    R.n_items = sh.n_local * 4096u * n_chunks;
     R.n_workgroups = rs.n_workgroups;
     R.next_item = reinterpret_cast<uint32_t *>(s->d_counters.p + 8);  // 8 counters, 64 bytes apart
     R.n_regions = std::min<uint32_t>(8u, std::max<uint32_t>(1u, tuning("PBRT_HIP_REGIONS", 8u, 8)));
@@ -1230,10 +1247,19 @@ int pbrt_hip_render_device(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, voi
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, 80 * sizeof(unsigned long long), st));
     if (fg.wide && fg.crop_px()) HIP_TRY(hipMemsetAsync(d_slab, 0, fg.crop_px() * 32, st));  // this rank's accumulators start at zero
     HIP_TRY(hipEventRecord(s->ev0, st));
-    // one launch renders every item of the rank; the merge adds each pixel's K partial sums in chunk order (a wide
-    // filter has no partial sums: its samples go straight into the accumulators)
-    HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, sh.n_local, s->bvh.depth, counters, fg.wide, sobol_nd, st, r->integrator == PBRT_HIP_INTEGRATOR_PATH_MIS, s->textured));
-    if (!fg.wide) HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, r->rank, r->world_size, sh.n_local, spp, st));
+    // one launch per pass (one pass unless the partial sums would pass the cap: partials_passes) renders every item of the pass; the merge
+    // adds each pixel's K partial sums in chunk order (a wide filter has no partial sums: its samples go straight into the accumulators)
+    for (uint32_t pass = 0; pass < rs.passes; pass++) {
+      const uint32_t n_pass = sh.n_local > pass ? (sh.n_local - pass + rs.passes - 1) / rs.passes : 0;
+      if (n_pass == 0 && pass > 0) break;
+      R.rank = r->rank + r->world_size * pass;
+      R.world = r->world_size * rs.passes;
+      R.n_items = n_pass * 4096u * n_chunks;
+      if (pass > 0)  // the hand-out positions start again; the ray counters (the first 64 bytes) run on
+        HIP_TRY(hipMemsetAsync(s->d_counters.p + 8, 0, 72 * sizeof(unsigned long long), st));
+      HIP_TRY(launch_render(counters == 1 ? s->dev_exact : s->dev, R, n_pass, s->bvh.depth, counters, fg.wide, sobol_nd, st, r->integrator == PBRT_HIP_INTEGRATOR_PATH_MIS, s->textured));
+      if (!fg.wide) HIP_TRY(launch_merge(R.partials, (float4 *)d_slab, sh.w, sh.h, R.rank, R.world, n_pass, spp, st, pass, rs.passes));
+    }
     HIP_TRY(hipEventRecord(s->ev1, st));
     s->pending = true;
     s->pending_counters = counters != 0;

@@ -202,7 +202,7 @@ hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t 
 hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n_tris, float2 *out, hipStream_t stream);
 // adds the K partial sums of every pixel of a rank's slab in chunk order and converts to XYZ (Film::merge_film_tile)
 hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
-                        uint32_t n_local_super, uint32_t spp, hipStream_t stream);
+                        uint32_t n_local_super, uint32_t spp, hipStream_t stream, uint32_t j0 = 0, uint32_t jstride = 1);
 // bvh_gpu.hip: the accelerator built on the device.  d_order (n_tris) and d_quads (>= n_tris nodes of 4 uint4) are outputs.
 struct GpuBuildInfo {
   uint32_t n_quads, stack_need, levels;

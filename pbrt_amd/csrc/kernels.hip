@@ -971,8 +971,10 @@ __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int
 
 // Film::merge_film_tile (core/film.rs:313-326) for one pixel of a rank's slab: contrib_sum = the K = 2^kb partial sums of
 // its chunks added in chunk order, xyz = rgb_to_xyz(contrib_sum) (spectrum.rs:139-145), weight = spp.
+// (rank, world, n_local_super) are those of the LAUNCH that wrote `partials`: a frame rendered in P passes (capi.cpp partials_passes) hands the
+// rank's super-tiles j = pass + P * j' to pass `pass`, which is rank + world * pass of world * P; its tile j' lands at slab tile j0 + jstride * j'.
 __global__ void merge_kernel(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
-                             uint32_t n_local_super, float weight, uint32_t kb) {
+                             uint32_t n_local_super, float weight, uint32_t kb, uint32_t j0, uint32_t jstride) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_local_super * 4096u) return;
   const uint32_t j = i >> 12, pys = (i >> 6) & 63u, pxs = i & 63u;
@@ -991,7 +993,7 @@ __global__ void merge_kernel(const float4 *partials, float4 *slab, int32_t w, in
     o.z = 0.019334f * sum.x + 0.119193f * sum.y + 0.950227f * sum.z;
     o.w = weight;
   }
-  slab[i] = o;
+  slab[((size_t)(j0 + jstride * j) << 12) + (i & 4095u)] = o;
 }
 
 // fixed-point accumulators {r, g, b, samples} -> Film pixel {XYZ of the radiance sum, weight} (film.rs:313-326)
@@ -1145,11 +1147,11 @@ hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n
 }
 
 hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
-                        uint32_t n_local_super, uint32_t spp, hipStream_t stream) {
+                        uint32_t n_local_super, uint32_t spp, hipStream_t stream, uint32_t j0, uint32_t jstride) {
   if (n_local_super == 0) return hipSuccess;
   const uint32_t n = n_local_super * 4096u;
   hipLaunchKernelGGL(merge_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partials, slab, w, h, rank, world, n_local_super,
-                     (float)spp, sample_chunk_shift(spp));
+                     (float)spp, sample_chunk_shift(spp), j0, jstride);
   return hipGetLastError();
 }
 

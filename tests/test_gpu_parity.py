@@ -149,6 +149,29 @@ def test_item_handout_is_scheduling_only(gpu, oracle, monkeypatch):
         assert st[k] == rst[k], f"{k}: {st[k]} vs oracle {rst[k]}"
 
 
+def test_partial_sum_cap_renders_in_passes(gpu, oracle, monkeypatch):
+    """The partial film sums (16 K bytes per pixel) are capped (2 GiB; capi.cpp partials_passes): a frame beyond the cap renders in P
+    passes over one buffer, pass p taking the rank's super-tiles p, p + P, ... as rank `rank + world * p` of `world * P`.  With the cap
+    turned down to one, two and five super-tiles per pass (12, 6 and 3 passes over this film's 4 x 3 super-tiles), alone and as one of
+    three ranks: the one-pass film and the oracle's, bit for bit, and the canonical counters summed over the passes."""
+    sd = scenes.cornell_scene(200, 136)
+    kw = dict(max_depth=4, spp=(8, 9), seed=5)  # 72 spp: K = 2 chunks, 128 KB of partial sums per super-tile
+    ref, rst = oracle.OracleScene(sd).render(**kw)
+    with gpu.Scene(sd) as sc:
+        for cap_kb in (128, 300, 700):
+            monkeypatch.setenv("PBRT_HIP_PARTIALS_CAP_KB", str(cap_kb))
+            film, st = sc.render(counters=True, **kw)
+            assert_bit_equal(film, ref, f"film in passes of {cap_kb} KB")
+            for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+                assert st[k] == rst[k], f"{k} at {cap_kb} KB: {st[k]} vs oracle {rst[k]}"
+            assert st["samples"] == 200 * 136 * 72
+            acc = np.zeros_like(film)
+            for r in range(3):
+                acc += sc.render(rank=r, world_size=3, **kw)[0]
+            assert_bit_equal(acc, ref, f"union of 3 ranks in passes of {cap_kb} KB")
+        monkeypatch.delenv("PBRT_HIP_PARTIALS_CAP_KB")
+
+
 @pytest.mark.parametrize("spp", [(1, 1), (7, 1), (5, 5), (9, 7), (8, 8), (13, 5), (16, 8), (17, 15), (16, 16), (32, 16), (25, 21)])
 def test_sample_chunks(gpu, oracle, spp):
     """K = sample_chunks(spp) chunks per pixel -- 1 below 64 spp, then 2, 4, 8, 16 (at least 32 samples per chunk) -- with
@@ -733,6 +756,26 @@ def test_c4_window_at_full_spp(gpu, oracle, builder):
     assert_bit_equal(film, ref, "C4 window")
     for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
         assert st[k] == rst[k]
+
+
+def test_c4_frame_beyond_the_scratch_cap(gpu, oracle, monkeypatch):
+    """C4's film at full size (4096 x 4096) with 32 x 16 = 512 spp: 16 chunks per pixel = 4.3 GB of partial sums, over the 2 GiB cap, so
+    the frame renders in two passes (capi.cpp partials_passes) -- the default behaviour, no knob.  The same frame with the cap lifted (one
+    pass, the round-4 code path) is the same film bit for bit, and an 8 x 8 window of it is the oracle's."""
+    sd = scenes.cornell_scene(4096, 4096)
+    kw = dict(max_depth=16, spp=(32, 16), seed=0)
+    with gpu.Scene(sd) as sc:
+        two, st = sc.render(**kw)
+        monkeypatch.setenv("PBRT_HIP_PARTIALS_CAP_KB", str(8 << 20))
+        one, _ = sc.render(**kw)
+        monkeypatch.delenv("PBRT_HIP_PARTIALS_CAP_KB")
+    assert st["samples"] == 4096 * 4096 * 512
+    assert_bit_equal(two, one, "C4 frame: two passes vs one")
+    del one
+    x0, y0 = 2048, 1024
+    crop = (x0 / 4096, (x0 + 8) / 4096, y0 / 4096, (y0 + 8) / 4096)
+    ref, _ = oracle_render(oracle, "c4-window-512", lambda: scenes.cornell_scene(4096, 4096, crop=crop), **kw)
+    assert_bit_equal(two[y0:y0 + 8, x0:x0 + 8], ref, "C4 frame in passes, window vs oracle")
 
 
 # ---- closed forms on the HIP path itself: anchors of the path loop that do not route through the oracle (VERDICT r03) ----
