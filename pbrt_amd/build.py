@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.abspath(os.environ.get("PBRT_HIP_LIB_DIR") or os.path.join(HERE, "lib"))
 LIB_PATH = os.path.join(LIB_DIR, "libpbrt_hip.so")
 CLI_PATH = os.path.join(LIB_DIR, "pbrt")  # the C++ command line (csrc/pbrt_main.cpp)
-SOURCES = ["capi.cpp", "multi_gpu.cpp", "bvh_build.cpp", "reinsert_batch.cpp", "imageio.cpp", "scene_parser.cpp", "kernels.hip", "bvh_gpu.hip"]
+SOURCES = ["capi.cpp", "multi_gpu.cpp", "bvh_build.cpp", "reinsert_batch.cpp", "imageio.cpp", "scene_parser.cpp", "ply_reader.cpp", "kernels.hip", "bvh_gpu.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

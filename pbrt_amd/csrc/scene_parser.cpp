@@ -12,6 +12,7 @@
 #include <tuple>
 
 #include "host_math.hpp"
+#include "ply_reader.hpp"
 
 namespace pbrt_hip {
 
@@ -253,6 +254,26 @@ struct Api {
   std::map<std::string, MaterialDef> named_materials;
   std::map<std::tuple<uint32_t, float, float, float, float, float, float, uint32_t>, uint16_t> material_ids;
   bool camera_set = false;
+  std::string cur_dir;  // directory of the file being parsed: resolves Shape "plymesh" "string filename" like Include
+  // ObjectBegin "name" ... ObjectEnd / ObjectInstance "name" (pbrt-v3 api.cpp pbrtObjectBegin / pbrtObjectInstance; NotImplemented in the
+  // reference, parser.rs:283-289).  An object's shapes are kept in world space as of their own CTM (their ObjectToWorld); an instance
+  // appends a copy moved by the CTM at the ObjectInstance (InstanceToWorld): the BVH is over flattened geometry, instances cost memory.
+  struct ObjectDef {
+    std::vector<float> P, tri_uv;
+    std::vector<uint32_t> idx;
+    std::vector<uint16_t> mat_id;
+    std::vector<pbrt_hip_sphere> spheres;
+  };
+  std::map<std::string, ObjectDef> objects;
+  bool in_object = false;
+  std::string object_name;
+  ObjectDef stash;  // the scene's own arrays while an object is being defined (shape() always appends to out->...)
+  bool warned_object_light = false;
+  // instancing multiplies geometry (instances x the object's triangles): a bound on what a small file can ask for (the tests lower it)
+  const size_t kMaxSceneTriangles = [] {
+    const char *on = std::getenv("PBRT_HIP_DEBUG_KNOBS"), *v = std::getenv("PBRT_HIP_MAX_SCENE_TRIANGLES");
+    return (on && *on && !(on[0] == '0' && !on[1]) && v && *v) ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)1 << 28;
+  }();
 
   explicit Api(LoadedScene *o) : out(o) {
     ctm[0] = ctm[1] = xf_identity();
@@ -388,9 +409,37 @@ struct Api {
     report_unused("Texture", ps);
   }
 
+  // vertices (object space) + triangles of one mesh shape, through the CTM, into the scene's arrays
+  void add_mesh(const float *P, uint32_t nv, const uint32_t *tri, size_t n_tri, const float *uv, uint16_t mid) {
+    const float *M = ctm[0].m;
+    const uint32_t base = (uint32_t)(out->P.size() / 3);
+    for (uint32_t v = 0; v < nv; v++) {
+      float q[3];
+      xf_point(M, P + 3 * (size_t)v, q);
+      out->P.insert(out->P.end(), q, q + 3);
+    }
+    const bool flip = gs.reverse_orientation ^ swaps_handedness(M);
+    for (size_t t = 0; t < n_tri; t++) {
+      uint32_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+      if (a >= nv || b >= nv || c >= nv) { warn("triangle mesh index out of range: triangle skipped"); continue; }
+      if (flip) std::swap(b, c);
+      out->idx.push_back(base + a); out->idx.push_back(base + b); out->idx.push_back(base + c);
+      out->mat_id.push_back(mid);
+      // per-vertex (u, v) if the mesh has them, else Triangle::GetUVs' (0,0) (1,0) (1,1)
+      const uint32_t corner[3] = {a, b, c};
+      const float dflt[6] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};
+      for (int v = 0; v < 3; v++)
+        for (int k = 0; k < 2; k++) out->tri_uv.push_back(uv ? uv[2 * (size_t)corner[v] + k] : dflt[2 * (flip && v ? 3 - v : v) + k]);
+    }
+  }
+
   void shape(const std::string &name, const ParamSet &ps) {
     const float zero[3] = {0, 0, 0};
-    const float *le = gs.has_area_light ? gs.area_le : zero;
+    if (in_object && gs.has_area_light && !warned_object_light) {
+      warned_object_light = true;
+      warn("Area lights not supported with object instancing");  // pbrt-v3 api.cpp pbrtShape: the shape is kept, its emission is not
+    }
+    const float *le = (gs.has_area_light && !in_object) ? gs.area_le : zero;
     if (out->mats.size() >= 65535) { warn("more than 65535 materials: shape skipped"); return; }
     const uint16_t mid = material_id(gs.material, le);
     const float *M = ctm[0].m;
@@ -405,42 +454,99 @@ struct Api {
       s.r = r * std::sqrt(sx[0] * sx[0] + sx[1] * sx[1] + sx[2] * sx[2]);  // uniform scale assumed
       s.mat = mid;
       out->spheres.push_back(s);
-      if (gs.has_area_light) warn("sphere area lights emit but are not sampled by the direct-light estimate");
+      if (gs.has_area_light && !in_object) warn("sphere area lights emit but are not sampled by the direct-light estimate");
       if (gs.material.kd_tex) warn("a textured Kd on a sphere: the texture's mean colour is used (a sphere's (u, v) is not computed on this path)");
     } else if (name == "trianglemesh") {
       const ParamItem *pi = ps.find("indices", "integer");
       const ParamItem *pp = ps.find("P", "point3");
       if (!pi || !pp || pi->nums.size() % 3 || pp->nums.size() % 3) { warn("trianglemesh without valid indices / P: skipped"); return; }
-      const uint32_t base = (uint32_t)(out->P.size() / 3), nv = (uint32_t)(pp->nums.size() / 3);
-      for (uint32_t v = 0; v < nv; v++) {
-        const float p[3] = {(float)pp->nums[3 * v], (float)pp->nums[3 * v + 1], (float)pp->nums[3 * v + 2]};
-        float q[3];
-        xf_point(M, p, q);
-        out->P.insert(out->P.end(), q, q + 3);
-      }
-      const bool flip = gs.reverse_orientation ^ swaps_handedness(M);
-      // per-vertex (u, v): "uv" or "st" (pbrt-v3 CreateTriangleMeshShape; floats or point2s), else Triangle::GetUVs' (0,0) (1,0) (1,1)
+      const uint32_t nv = (uint32_t)(pp->nums.size() / 3);
+      std::vector<float> P(pp->nums.begin(), pp->nums.end());
+      // per-vertex (u, v): "uv" or "st" (pbrt-v3 CreateTriangleMeshShape; floats or point2s)
       const ParamItem *puv = ps.find("uv", "float", "point2");
       if (!puv) puv = ps.find("st", "float", "point2");
       else ps.find("st", "float", "point2");
       if (puv && puv->nums.size() != 2 * (size_t)nv) { warn("trianglemesh: \"uv\" / \"st\" does not hold two numbers per vertex: ignored"); puv = nullptr; }
-      for (size_t t = 0; t + 2 < pi->nums.size(); t += 3) {
-        uint32_t a = (uint32_t)pi->nums[t], b = (uint32_t)pi->nums[t + 1], c = (uint32_t)pi->nums[t + 2];
-        if (a >= nv || b >= nv || c >= nv) { warn("trianglemesh index out of range: triangle skipped"); continue; }
-        if (flip) std::swap(b, c);
-        out->idx.push_back(base + a); out->idx.push_back(base + b); out->idx.push_back(base + c);
-        out->mat_id.push_back(mid);
-        const uint32_t corner[3] = {a, b, c};
-        const float dflt[6] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};
-        for (int v = 0; v < 3; v++)
-          for (int k = 0; k < 2; k++) out->tri_uv.push_back(puv ? (float)puv->nums[2 * (size_t)corner[v] + k] : dflt[2 * (flip && v ? 3 - v : v) + k]);
-      }
+      std::vector<float> uv;
+      if (puv) uv.assign(puv->nums.begin(), puv->nums.end());
+      std::vector<uint32_t> tri(pi->nums.size());
+      for (size_t i = 0; i < tri.size(); i++)  // (a negative or huge index becomes one that is out of range)
+        tri[i] = (pi->nums[i] >= 0 && pi->nums[i] < 4294967295.0) ? (uint32_t)pi->nums[i] : 0xffffffffu;
+      add_mesh(P.data(), nv, tri.data(), tri.size() / 3, puv ? uv.data() : nullptr, mid);
       ps.find("N", "normal"); ps.find("S", "vector3");
+    } else if (name == "plymesh") {  // pbrt-v3 CreatePLYMesh (plymesh.cpp): the mesh of a PLY file, relative names against the scene file's directory
+      const std::string fn = ps.one_string("filename", "");
+      if (fn.empty()) { warn("plymesh without a \"string filename\": skipped"); return; }
+      const std::string path = (fn[0] == '/' || cur_dir.empty()) ? fn : cur_dir + "/" + fn;
+      PlyMesh mesh;
+      std::string perr;
+      if (!read_ply(path, &mesh, &perr)) { warn("plymesh \"" + fn + "\": " + perr + ": shape skipped"); return; }  // (pbrt-v3 logs the error and goes on)
+      if (mesh.skipped_faces) warn("plymesh \"" + fn + "\": " + std::to_string(mesh.skipped_faces) + " faces with other than 3 or 4 vertices ignored");
+      if (mesh.idx.empty()) { warn("plymesh \"" + fn + "\": no faces: skipped"); return; }
+      if (out->idx.size() / 3 + mesh.idx.size() / 3 > kMaxSceneTriangles) { warn("plymesh \"" + fn + "\": scene would pass 2^28 triangles: skipped"); return; }
+      add_mesh(mesh.P.data(), (uint32_t)(mesh.P.size() / 3), mesh.idx.data(), mesh.idx.size() / 3, mesh.uv.empty() ? nullptr : mesh.uv.data(), mid);
+      if (ps.find("alpha", "texture", "float") || ps.find("shadowalpha", "texture", "float")) warn("plymesh: alpha / shadowalpha are not supported (opaque)");
     } else {
       warn("Shape \"" + name + "\" is not supported by this path: skipped");
       return;
     }
     report_unused("Shape", ps);
+  }
+
+  void swap_geometry(ObjectDef &d) {
+    out->P.swap(d.P); out->tri_uv.swap(d.tri_uv); out->idx.swap(d.idx); out->mat_id.swap(d.mat_id); out->spheres.swap(d.spheres);
+  }
+  void object_begin(const std::string &name) {  // pbrtObjectBegin: an AttributeBegin, then shapes go to the named object
+    if (in_object) { warn("ObjectBegin called inside of instance definition"); return; }
+    in_object = true;
+    object_name = name;
+    stash = ObjectDef();
+    swap_geometry(stash);  // out->... is empty now and collects the object's shapes; stash holds the scene
+  }
+  void object_end() {
+    if (!in_object) { warn("ObjectEnd called outside of instance definition"); return; }
+    ObjectDef def;
+    swap_geometry(def);    // def = the object's shapes
+    swap_geometry(stash);  // the scene is back
+    stash = ObjectDef();
+    objects[object_name] = std::move(def);
+    in_object = false;
+  }
+  bool object_instance(const std::string &name) {  // false: the scene would pass kMaxSceneTriangles
+    if (in_object) { warn("ObjectInstance can't be called inside instance definition"); return true; }
+    auto it = objects.find(name);
+    if (it == objects.end()) { warn("Unable to find instance named \"" + name + "\""); return true; }
+    const ObjectDef &d = it->second;
+    if (out->idx.size() / 3 + d.idx.size() / 3 > kMaxSceneTriangles || out->spheres.size() + d.spheres.size() > kMaxSceneTriangles) return false;
+    const float *M = ctm[0].m;
+    const uint32_t base = (uint32_t)(out->P.size() / 3);
+    for (size_t v = 0; v + 2 < d.P.size(); v += 3) {
+      float q[3];
+      xf_point(M, d.P.data() + v, q);
+      out->P.insert(out->P.end(), q, q + 3);
+    }
+    // a mirroring instance transform turns the winding round: the geometric normal must stay the transformed normal
+    const bool flip = swaps_handedness(M);
+    for (size_t t = 0; t + 2 < d.idx.size(); t += 3) {
+      const int o1 = flip ? 2 : 1, o2 = flip ? 1 : 2;
+      out->idx.push_back(base + d.idx[t]); out->idx.push_back(base + d.idx[t + o1]); out->idx.push_back(base + d.idx[t + o2]);
+      const float *uv = d.tri_uv.data() + 2 * t;
+      const float c[6] = {uv[0], uv[1], uv[2 * o1], uv[2 * o1 + 1], uv[2 * o2], uv[2 * o2 + 1]};
+      out->tri_uv.insert(out->tri_uv.end(), c, c + 6);
+    }
+    out->mat_id.insert(out->mat_id.end(), d.mat_id.begin(), d.mat_id.end());
+    const float ex[3] = {1, 0, 0};
+    float sx[3];
+    xf_vector(M, ex, sx);
+    const float scale = std::sqrt(sx[0] * sx[0] + sx[1] * sx[1] + sx[2] * sx[2]);  // uniform scale assumed, as for a sphere's own CTM
+    for (pbrt_hip_sphere s : d.spheres) {
+      float c[3];
+      xf_point(M, s.c, c);
+      for (int i = 0; i < 3; i++) s.c[i] = c[i];
+      s.r *= scale;
+      out->spheres.push_back(s);
+    }
+    return true;
   }
 
   void light_source(const std::string &name, const ParamSet &ps) {  // replaces make_light's todo!()s, api.rs:334-351
@@ -640,6 +746,7 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
   };
   std::string tok;
   while (p.next(&tok, false)) {
+    api.cur_dir = p.files.empty() ? base_dir : p.files.back()->dir;
     std::string name;
     ParamSet ps;
     float v[16];
@@ -857,19 +964,41 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
       }
     } else if (tok == "WorldEnd") {  // api.rs:432-473: the render call site
       if (in_world("WorldEnd")) {
+        if (api.in_object) { api.warn("Missing end to ObjectBegin"); api.object_end(); }
         if (!api.pushed_gs.empty() || !api.pushed_ctm.empty()) api.warn("Missing end to AttributeBegin / TransformBegin");
         api.state = ApiState::OptionsBlock;
         out->world_ended = true;
         break;  // one render per file (the reference would continue to a next frame, api.rs:458)
       }
-    } else if (tok == "MakeNamedMedium" || tok == "MediumInterface" || tok == "ObjectBegin" || tok == "ObjectEnd" ||
-               tok == "ObjectInstance" || tok == "TransformTimes") {
+    } else if (tok == "ObjectBegin") {  // pbrt-v3 pbrtObjectBegin = pbrtAttributeBegin + the named instance collects the shapes
+      if (!p.quoted(&name)) return fin(false);
+      if (in_world("ObjectBegin")) {
+        api.pushed_gs.push_back(api.gs);
+        api.pushed_ctm.emplace_back(api.ctm[0], api.ctm[1]);
+        api.pushed_bits.push_back(api.active_bits);
+        api.object_begin(name);
+      }
+    } else if (tok == "ObjectEnd") {
+      if (in_world("ObjectEnd")) {
+        api.object_end();
+        if (!api.pushed_gs.empty() && !api.pushed_ctm.empty()) {  // pbrtAttributeEnd
+          api.gs = api.pushed_gs.back(); api.pushed_gs.pop_back();
+          api.ctm[0] = api.pushed_ctm.back().first; api.ctm[1] = api.pushed_ctm.back().second; api.pushed_ctm.pop_back();
+          api.active_bits = api.pushed_bits.back(); api.pushed_bits.pop_back();
+        }
+      }
+    } else if (tok == "ObjectInstance") {
+      if (!p.quoted(&name)) return fin(false);
+      if (in_world("ObjectInstance") && !api.object_instance(name))
+        return fin(p.fail(ParseError::Syntax, "ObjectInstance \"" + name + "\": the scene would pass 2^28 triangles"));
+    } else if (tok == "MakeNamedMedium" || tok == "MediumInterface" || tok == "TransformTimes") {
       return fin(p.fail(ParseError::NotImplemented, tok));  // parser.rs:270-310: out of scope here too
     } else {
       return fin(p.fail(ParseError::Syntax, tok));  // parser.rs:313
     }
   }
   if (p.err != ParseError::None) return fin(false);
+  if (api.in_object) { api.warn("Missing end to ObjectBegin"); api.object_end(); }  // (the file ended inside an object: the scene's arrays come back)
   {  // corner (u, v) travel only when some triangle's material is textured
     bool textured = false;
     for (uint16_t m : out->mat_id) textured = textured || out->mats[m].kd_tex != 0u;

@@ -25,7 +25,7 @@ enum class ParseError {
   MixedParameters,     // strings and numbers mixed in one parameter list
   Unquoted,            // a quoted string was required
   Syntax,              // unknown directive / malformed number
-  NotImplemented,      // directive the render path does not cover (objects, media, ...)
+  NotImplemented,      // directive the render path does not cover (media, animated transforms)
   Io,
 };
 
