@@ -869,6 +869,22 @@ def test_mirror_furnace_is_exact_up_to_three_bounces_on_the_gpu(gpu, max_depth):
     assert exact.mean() >= 0.99 and (rgb <= want * (1 + 3e-6)).all(), (max_depth, exact.mean(), rgb.min(), rgb.max(), want)
 
 
+def test_c1_at_full_size_equals_the_analytic_image_on_the_gpu(gpu):
+    """BASELINE config C1 as written (1024 x 1024, 64 spp, direct lighting) against the image computed from first principles in float64
+    numpy (util.c1_analytic_image; no oracle): camera model, sphere root, I / r^2, Kd / pi and the terminator, over 140 000 smooth pixels."""
+    from util import check_c1_against_analytic
+    rgb = _hip_rgb_direct(gpu, scenes.sphere_scene(1024, 1024))
+    check_c1_against_analytic(rgb)
+    rgb = _hip_rgb_direct(gpu, scenes.sphere_scene(640, 360))  # a wide frame: the fov spans the shorter axis
+    check_c1_against_analytic(rgb)
+
+
+def _hip_rgb_direct(gpu, sd):
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(integrator=INTEGRATOR_DIRECT, max_depth=5, spp=(8, 8), seed=0)
+    return pbrt_amd.film_to_rgb(film)
+
+
 @pytest.mark.parametrize("kind", ["distant", "infinite"])
 @pytest.mark.parametrize("max_depth", [1, 5])
 def test_lit_plane_closed_forms_on_the_gpu(gpu, kind, max_depth):

@@ -445,3 +445,15 @@ def test_mis_is_unbiased_on_the_cornell_box_and_with_an_environment(oracle):
         b = oracle.film_write_rgb(o.render(integrator=2, max_depth=depth, spp=(32, 32), seed=2)[0])
         assert abs(a.mean() - b.mean()) < 4e-3 * a.mean(), (a.mean(), b.mean())
         assert np.abs(a - b).mean() < 0.03 * a.mean()
+
+
+@pytest.mark.parametrize("res", [(128, 128), (160, 96), (96, 160)])
+def test_c1_image_equals_the_analytic_image(oracle, res):
+    """BASELINE config C1 (sphere + point light, direct lighting, 8 x 8 samples) against an image computed from first principles in
+    float64 numpy (tests/util.py c1_analytic_image: pbrt's perspective camera incl. both aspect-ratio cases, the sphere's nearer root,
+    I / r^2, Kd / pi, the terminator): every smooth pixel within 1e-2 (6e-4 on average), black background, the image's sum within 2e-3.
+    An anchor of SURVEY A2 / A6 / A8 that shares no code with the oracle or the library; the GPU twin of this test runs at C1's full size."""
+    from pbrt_amd import scenes, INTEGRATOR_DIRECT
+    from util import check_c1_against_analytic
+    film, _ = oracle.OracleScene(scenes.sphere_scene(*res)).render(integrator=INTEGRATOR_DIRECT, max_depth=5, spp=(8, 8), seed=0)
+    check_c1_against_analytic(oracle.film_write_rgb(film))

@@ -228,3 +228,61 @@ def check_checker_plane(render_rgb, camera_ray, res=64):
     agree = (np.abs(rgb - want).max(-1) < 3e-6).mean()
     assert agree > 0.9, agree
     return agree
+
+
+def c1_analytic_image(xres, yres, sub=8):
+    """BASELINE config C1's image from first principles, in float64 numpy, sharing no code with the oracle or the library: pbrt's
+    perspective camera (fov on the shorter axis, raster y down, left-handed look-at: right = up x dir), the sphere's nearer root, a point
+    light's I / r^2, Lambert's Kd / pi, the sphere's own shadow (n . wi <= 0).  Returns (img[y, x], interior[y, x]): the mean of
+    sub x sub points per pixel (the regular grid of stratum centres), and the pixels all of whose points (and their neighbours') hit the sphere with n . wi > 0.05 --
+    where the image is smooth and a jittered 64-sample mean lies within a few 1e-4 of this one on average."""
+    eye, look, up = np.array([3.0, 4.0, 1.5]), np.array([0.5, 0.5, 0.0]), np.array([0.0, 0.0, 1.0])
+    fov, light, inten, kd, radius = 45.0, np.array([2.0, 2.0, 3.0]), 10.0, 0.5, 1.0
+    fwd = (look - eye) / np.linalg.norm(look - eye)
+    right = np.cross(up / np.linalg.norm(up), fwd)
+    right /= np.linalg.norm(right)
+    new_up = np.cross(fwd, right)
+    aspect = xres / yres
+    wx, wy = (aspect, 1.0) if aspect >= 1 else (1.0, 1.0 / aspect)  # screen window half extents; the fov spans the shorter axis
+    t = np.tan(np.radians(fov) / 2)
+    fx = (np.arange(xres * sub) + 0.5) / sub  # continuous raster coordinates of the sub-pixel centres
+    sx = (2 * fx / xres - 1) * wx * t
+    img, lit_all, miss_all = np.empty((yres, xres)), np.empty((yres, xres), bool), np.empty((yres, xres), bool)
+    for y0 in range(0, yres, 32):  # bands of 32 pixel rows (a 1024^2 frame at 8 x 8 points per pixel is 67 M rays)
+        y1 = min(yres, y0 + 32)
+        fy = (np.arange(y0 * sub, y1 * sub) + 0.5) / sub
+        sy = (1 - 2 * fy / yres) * wy * t
+        d = sx[None, :, None] * right + sy[:, None, None] * new_up + fwd  # [Y, X, 3]
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        b = 2 * (d @ eye)
+        c = eye @ eye - radius * radius
+        disc = b * b - 4 * c
+        hit = disc > 0
+        tt = np.where(hit, (-b - np.sqrt(np.where(hit, disc, 0))) / 2, 0)  # the nearer root (the camera is outside)
+        p = eye + tt[..., None] * d
+        n = p / radius
+        to_l = light - p
+        r2 = (to_l * to_l).sum(-1)
+        cos = (n * to_l).sum(-1) / np.sqrt(r2)
+        val = np.where(hit & (cos > 0), kd / np.pi * inten / r2 * cos, 0.0)
+        img[y0:y1] = val.reshape(y1 - y0, sub, xres, sub).mean((1, 3))
+        lit_all[y0:y1] = (hit & (cos > 0.05)).reshape(y1 - y0, sub, xres, sub).all((1, 3))
+        miss_all[y0:y1] = (~hit).reshape(y1 - y0, sub, xres, sub).all((1, 3))
+
+    def eroded(m):  # the pixel and its eight neighbours: a jittered sample may fall where the regular grid does not
+        q = np.pad(m, 1, constant_values=False)
+        return np.logical_and.reduce([q[1 + dy:1 + dy + yres, 1 + dx:1 + dx + xres] for dy in (-1, 0, 1) for dx in (-1, 0, 1)])
+    return img, eroded(lit_all), eroded(miss_all)
+
+
+def check_c1_against_analytic(rgb, sub=8):
+    """rgb[y, x, 3]: a direct-lighting render of scenes.sphere_scene at 64 jittered samples per pixel."""
+    yres, xres, _ = rgb.shape
+    img, interior, outside = c1_analytic_image(xres, yres, sub)
+    assert interior.mean() > 0.02 and outside.mean() > 0.5  # the lit cap and the background are both in the frame
+    assert (rgb[outside] == 0).all(), "background pixels must be black"
+    assert np.allclose(rgb[..., 0], rgb[..., 1], rtol=2e-5, atol=1e-7) and np.allclose(rgb[..., 2], rgb[..., 1], rtol=2e-5, atol=1e-7)  # grey light, grey sphere (through RGB -> XYZ -> RGB)
+    rel = np.abs(rgb[..., 1][interior] / img[interior] - 1)
+    assert rel.max() < 1e-2 and rel.mean() < 6e-4, (rel.max(), rel.mean())  # (64 jittered samples against the regular grid, worst at the coarsest resolutions)
+    # what the whole image integrates to (edges included: a pixel crossed by the silhouette or the terminator averages the same function)
+    assert abs(rgb[..., 1].sum() / img.sum() - 1) < 2e-3, (rgb[..., 1].sum(), img.sum())
