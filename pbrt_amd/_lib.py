@@ -114,6 +114,28 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP / HSA runtime per process.  The PyTorch-ROCm wheel carries its own libamdhip64.so / libhsa-runtime64.so (torch/lib, sonames
+    libamdhip64.so.7 / libhsa-runtime64.so.1); libpbrt_hip.so names the same sonames and finds /opt/rocm's.  Whichever copy is loaded first
+    serves both -- unless this library comes first and torch is imported afterwards: then torch's own HSA runtime opens the device a second
+    time and torch reports "No HIP GPUs are available" (seen on the MI355X box when a test that uses torch ran before anything imported
+    it).  So when torch is installed but not imported yet, its copy of the runtime is loaded before libpbrt_hip.so -- by path, without
+    importing torch (seconds) -- and a later `import torch` finds the runtime it expects.  PBRT_HIP_NO_TORCH_RUNTIME=1 skips this."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("PBRT_HIP_NO_TORCH_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)  # (its RPATH $ORIGIN brings torch's libhsa-runtime64.so with it)
+    except (OSError, ImportError, ValueError):
+        pass  # no torch, or a torch without a bundled runtime: /opt/rocm's serves this library alone
+
+
 def lib():
     """The loaded libpbrt_hip.so; raises if it was not built (run `python -m pbrt_amd.build`)."""
     global _lib
@@ -122,6 +144,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with __graft_entry__.build() or `python pbrt_amd/build.py`. "
                 "pbrt_amd has no CPU fallback.")
+        _share_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError here = header and library disagree

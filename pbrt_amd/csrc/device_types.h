@@ -195,6 +195,7 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
                          bool mis = false, bool textured = false);
 // fixed-point accumulators -> film pixels {X, Y, Z, weight}
 hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, size_t n_px, hipStream_t stream);
+hipError_t launch_acc_add(unsigned long long *dst, const unsigned long long *src, size_t n, hipStream_t stream);  // dst[i] += src[i]
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
                             uint32_t n_tris, float4 *tris, hipStream_t stream);

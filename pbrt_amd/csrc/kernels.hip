@@ -1012,6 +1012,17 @@ __global__ void film_from_acc_kernel(const unsigned long long *acc, float4 *film
 
 }  // namespace
 
+// the fixed-point accumulators of two ranks on one device added (multi_gpu.cpp's loopback exchange; with one rank per device ncclReduce adds them)
+__global__ void acc_add_kernel(unsigned long long *dst, const unsigned long long *src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+hipError_t launch_acc_add(unsigned long long *dst, const unsigned long long *src, size_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(acc_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, size_t n_px, hipStream_t stream) {
   if (n_px == 0) return hipSuccess;
   hipLaunchKernelGGL(film_from_acc_kernel, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, stream, acc, film, n_px);

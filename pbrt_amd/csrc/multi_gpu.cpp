@@ -99,6 +99,13 @@ struct pbrt_hip_multi {
   size_t max_slab = 0, n_px = 0;
   int32_t w = 0, h = 0;
   bool broken = false;                   // a collective failed and the communicators were aborted
+  // PBRT_HIP_MULTI_LOOPBACK (a debug knob, for boxes with fewer GPUs than ranks -- the test pool has one): rank g lives on device
+  // g mod <visible devices>, and since RCCL refuses two ranks on one device the frame's one exchange is made of device-to-device copies
+  // (gather) or an adding kernel (wide filter) ordered by events.  Everything else -- replication, the ranks' shares, the launches on
+  // their own streams, the gathered layout, the assembly, the statistics, the error paths -- is the code N real GPUs run.
+  bool loopback = false;
+  std::vector<int> dev;                  // [g]: the device rank g lives on (g itself unless loopback)
+  std::vector<hipEvent_t> done;          // loopback: rank g's slab is in place
 
   ~pbrt_hip_multi() {
     DeviceRestore keep;
@@ -110,6 +117,7 @@ struct pbrt_hip_multi {
       if (g < (int)slabs.size()) slabs[g].release();
       if (g < (int)streams.size() && streams[g]) (void)hipStreamDestroy(streams[g]);
       if (g == 0) { gathered.release(); film.release(); }
+      if (g < (int)done.size() && done[g]) (void)hipEventDestroy(done[g]);
       delete scenes[g];
     }
   }
@@ -182,33 +190,41 @@ int multi_create(const pbrt_hip_scene_desc *d, int n_gpus, uint32_t flags, pbrt_
     const int64_t tiles = (int64_t)((w + 63) / 64) * (int64_t)((h + 63) / 64);
     n_gpus = (int)std::max<int64_t>(1, std::min<int64_t>(ndev, tiles));
   }
-  if (n_gpus > ndev) return fail(PBRT_HIP_ERR_INVALID, "multi_create: " + std::to_string(n_gpus) + " GPUs asked for, " + std::to_string(ndev) + " visible");
-  if (n_gpus > 1) {  // (one GPU: no collective, RCCL is not needed and not loaded)
+  const char *lb = debug_knob("PBRT_HIP_MULTI_LOOPBACK");
+  const bool loopback = lb && *lb && !(lb[0] == '0' && !lb[1]);
+  if (n_gpus > ndev && !loopback) return fail(PBRT_HIP_ERR_INVALID, "multi_create: " + std::to_string(n_gpus) + " GPUs asked for, " + std::to_string(ndev) + " visible");
+  if (n_gpus > 64) return fail(PBRT_HIP_ERR_INVALID, "multi_create: more than 64 ranks");
+  if (n_gpus > 1 && !loopback) {  // (one GPU: no collective, RCCL is not needed and not loaded)
     Rccl &rc = rccl();
     if (!rc.why.empty()) return fail(PBRT_HIP_ERR_INTERNAL, "multi_create: " + rc.why);
   }
   std::unique_ptr<pbrt_hip_multi> m(new pbrt_hip_multi());
   m->n = n_gpus;
+  m->loopback = loopback && n_gpus > 1;
+  m->dev.resize(n_gpus);
+  for (int g = 0; g < n_gpus; g++) m->dev[g] = loopback ? g % ndev : g;
   m->scenes.assign(n_gpus, nullptr);
   m->streams.assign(n_gpus, nullptr);
   m->slabs.resize(n_gpus);
   int rcode = pbrt_hip_scene_create_ex(d, 0, flags, &m->scenes[0]);
   if (rcode) return rcode;
   for (int g = 1; g < n_gpus; g++) {
-    rcode = clone_scene(m->scenes[0], g, &m->scenes[g]);
+    rcode = clone_scene(m->scenes[0], m->dev[g], &m->scenes[g]);
     if (rcode) return rcode;
   }
   m->w = w;
   m->h = h;
   m->n_px = (size_t)w * (size_t)h;
   m->max_slab = shard_pixels(d->xres, d->yres, d->crop, 0, (uint32_t)n_gpus);  // rank 0 owns the most super-tiles
+  if (m->loopback) m->done.assign(n_gpus, nullptr);
   for (int g = 0; g < n_gpus; g++) {
-    HIP_TRY(hipSetDevice(g));
+    HIP_TRY(hipSetDevice(m->dev[g]));
     HIP_TRY(hipStreamCreate(&m->streams[g]));
+    if (m->loopback) HIP_TRY(hipEventCreateWithFlags(&m->done[g], hipEventDisableTiming));
   }
   HIP_TRY(hipSetDevice(0));
   HIP_TRY(m->film.alloc(m->n_px ? m->n_px : 1));
-  if (n_gpus > 1) {
+  if (n_gpus > 1 && !m->loopback) {
     std::vector<int> devs(n_gpus);
     for (int g = 0; g < n_gpus; g++) devs[g] = g;
     m->comms.assign(n_gpus, nullptr);
@@ -224,7 +240,7 @@ int ensure_buffers(pbrt_hip_multi *m, size_t count, bool gather) {
   count = count ? count : 1;
   for (int g = 0; g < m->n; g++) {
     if (m->slabs[g].n >= count) continue;
-    HIP_TRY(hipSetDevice(g));
+    HIP_TRY(hipSetDevice(m->dev[g]));
     m->slabs[g].release();
     HIP_TRY(m->slabs[g].alloc(count));
     HIP_TRY(hipMemsetAsync(m->slabs[g].p, 0, count * sizeof(float4), m->streams[g]));  // (a rank without tiles sends zeros)
@@ -269,16 +285,32 @@ int multi_render(pbrt_hip_multi *m, const pbrt_hip_render_desc *r, float *film, 
   }
   auto drain = [&]() {  // leave no render "in flight" behind an error
     for (int g = 0; g < n; g++)
-      if (started[g]) { (void)hipSetDevice(g); (void)hipStreamSynchronize(m->streams[g]); (void)pbrt_hip_render_wait(m->scenes[g], nullptr); }
+      if (started[g]) { (void)hipSetDevice(m->dev[g]); (void)hipStreamSynchronize(m->streams[g]); (void)pbrt_hip_render_wait(m->scenes[g], nullptr); }
   };
   if (code) { drain(); return fail(code, "multi_render: " + err); }  // (known before any collective is enqueued: nobody waits in one)
   // ---- the frame's one exchange, then the film on GPU 0 ----
   const float4 *result = m->slabs[0].p;  // n == 1: GPU 0's own slab / accumulators
-  if (n > 1) {
+  if (n > 1 && m->loopback) {
+    // the exchange without RCCL (ranks share devices): rank g's slab to its place in `gathered` on its own stream -- for a wide filter rank
+    // 0's accumulators, the others added to them on stream 0 once they are complete (integers: any order gives the same sums)
+    const size_t slab_f4 = m->max_slab ? m->max_slab : 1;
+    for (int g = 0; g < n; g++) {
+      HIP_TRY(hipSetDevice(m->dev[g]));
+      if (!wide) HIP_TRY(hipMemcpyPeerAsync(m->gathered.p + (size_t)g * slab_f4, 0, m->slabs[g].p, m->dev[g], slab_f4 * sizeof(float4), m->streams[g]));
+      else if (g == 0) HIP_TRY(hipMemcpyAsync(m->gathered.p, m->slabs[0].p, 2 * m->n_px * sizeof(float4), hipMemcpyDeviceToDevice, m->streams[0]));
+      HIP_TRY(hipEventRecord(m->done[g], m->streams[g]));
+    }
+    HIP_TRY(hipSetDevice(0));
+    for (int g = 1; g < n; g++) {
+      HIP_TRY(hipStreamWaitEvent(m->streams[0], m->done[g], 0));
+      if (wide) HIP_TRY(launch_acc_add((unsigned long long *)m->gathered.p, (const unsigned long long *)m->slabs[g].p, 4 * m->n_px, m->streams[0]));
+    }
+    result = m->gathered.p;
+  } else if (n > 1) {
     Rccl &rc = rccl();
     ncclResult_t nr = rc.GroupStart();
     for (int g = 0; g < n && nr == 0; g++) {
-      if (hipSetDevice(g) != hipSuccess) { nr = -1; break; }
+      if (hipSetDevice(m->dev[g]) != hipSuccess) { nr = -1; break; }
       nr = wide ? rc.Reduce(m->slabs[g].p, g == 0 ? m->gathered.p : nullptr, 4 * m->n_px, kNcclInt64, kNcclSum, 0, m->comms[g], m->streams[g])
                 : rc.Gather(m->slabs[g].p, g == 0 ? m->gathered.p : nullptr, 4 * (m->max_slab ? m->max_slab : 1), kNcclFloat, 0, m->comms[g], m->streams[g]);
     }
@@ -286,7 +318,7 @@ int multi_render(pbrt_hip_multi *m, const pbrt_hip_render_desc *r, float *film, 
     if (nr == 0) nr = ne;
     if (nr != 0) {
       // some ranks may sit in a collective the others never joined: abort every communicator (that releases them)
-      for (int g = 0; g < n; g++) { (void)hipSetDevice(g); (void)rc.CommAbort(m->comms[g]); m->comms[g] = nullptr; }
+      for (int g = 0; g < n; g++) { (void)hipSetDevice(m->dev[g]); (void)rc.CommAbort(m->comms[g]); m->comms[g] = nullptr; }
       m->broken = true;
       drain();
       return fail(PBRT_HIP_ERR_HIP, std::string("multi_render: RCCL ") + (wide ? "reduce: " : "gather: ") + (nr > 0 ? rc.GetErrorString(nr) : "hipSetDevice failed"));
@@ -305,7 +337,7 @@ int multi_render(pbrt_hip_multi *m, const pbrt_hip_render_desc *r, float *film, 
   if (!code && film && m->n_px) e = hipMemcpyAsync(film, m->film.p, m->n_px * sizeof(float4), hipMemcpyDeviceToHost, m->streams[0]);
   std::vector<pbrt_hip_stats> stats(n);
   for (int g = 0; g < n; g++) {
-    (void)hipSetDevice(g);
+    (void)hipSetDevice(m->dev[g]);
     const hipError_t es = hipStreamSynchronize(m->streams[g]);
     if (es != hipSuccess && e == hipSuccess) e = es;
     const int c3 = pbrt_hip_render_wait(m->scenes[g], &stats[g]);

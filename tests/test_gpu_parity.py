@@ -291,6 +291,43 @@ def test_multi_gpu_render_in_one_process(gpu, oracle, n_gpus):
         gpu.MultiScene(sd, gpu.device_count() + 1)
 
 
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
+def test_multi_gpu_code_path_with_more_ranks_than_devices(gpu, oracle, monkeypatch, n_ranks):
+    """The in-library multi-GPU path at N > 1 on a box with one GPU (PBRT_HIP_MULTI_LOOPBACK: rank g on device g mod <devices>; the
+    frame's one exchange made of device-to-device copies / an adding kernel, because RCCL refuses two ranks on one device).  Everything
+    but the ncclGather / ncclReduce calls themselves is the code eight real GPUs run: the scene replicated, the ranks' shares launched on
+    their own streams, the gathered layout, the assembly, per-rank statistics, a wide filter's integer sums, a rank without tiles, a
+    failing rank.  Films equal the oracle's bit for bit."""
+    monkeypatch.setenv("PBRT_HIP_MULTI_LOOPBACK", "1")
+    sd = scenes.cornell_scene(200, 136)  # 4 x 3 super-tiles, ragged edges
+    kw = dict(max_depth=4, spp=(3, 2), seed=8)
+    o = oracle.OracleScene(sd)
+    ref, _ = o.render(**kw)
+    with gpu.MultiScene(sd, n_ranks) as ms:
+        assert ms.n_gpus == n_ranks
+        film, stats = ms.render(**kw)
+        again, _ = ms.render(**dict(kw, sampler="halton"))
+        wide, _ = ms.render(filter_width=(1.5, 0.75), **kw)
+        back, _ = ms.render(**kw)  # after a wide frame: the gathered buffer changes its role and back
+        monkeypatch.setenv("PBRT_HIP_MULTI_FAIL_RANK", str(n_ranks - 1))
+        with pytest.raises(gpu.api._lib.PbrtHipError) as e:
+            ms.render(**kw)
+        assert "injected" in str(e.value)
+        monkeypatch.delenv("PBRT_HIP_MULTI_FAIL_RANK")
+        after, _ = ms.render(**kw)  # nobody was left waiting: the handle renders on
+    assert_bit_equal(film, ref, f"film of {n_ranks} ranks")
+    assert_bit_equal(again, o.render(**dict(kw, sampler="halton"))[0], "Halton frame of the same handle")
+    assert_bit_equal(wide, o.render(filter_width=(1.5, 0.75), **kw)[0], f"wide box filter, {n_ranks} ranks' accumulators added")
+    assert_bit_equal(back, ref, "default filter after a wide frame")
+    assert_bit_equal(after, ref, "frame after a failed launch")
+    assert len(stats) == n_ranks and sum(s["samples"] for s in stats) == 200 * 136 * 6
+    assert all(s["samples"] > 0 and s["kernel_ms"] > 0 for s in stats)  # 12 super-tiles: every one of up to 8 ranks owns some
+    tiny = scenes.cornell_scene(100, 60)  # 2 x 1 super-tiles: ranks 2 .. own nothing and send zeros
+    one, st = gpu.render_multi(tiny, n_ranks, **kw)
+    assert_bit_equal(one, oracle.OracleScene(tiny).render(**kw)[0], "pbrt_hip_render_multi with idle ranks")
+    assert [s["samples"] > 0 for s in st] == [True, True] + [False] * (n_ranks - 2)
+
+
 def test_render_prepare_leaves_nothing_to_allocate(gpu, oracle):
     """pbrt_hip_render_prepare (what pbrt_hip_multi_render calls for every GPU before the first launch of a frame, so that no
     hipMalloc separates the launches): the scene's device footprint does not change between a prepared render's launch and its

@@ -587,3 +587,33 @@ def test_sobol_nd_generator_matrices(oracle):
                 break
         table = np.array(vals, np.uint64).reshape(128, 52)[:, :32].astype(np.uint32)
         assert np.array_equal(m, table)
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """The PyTorch-ROCm wheel carries its own HIP / HSA runtime; libpbrt_hip.so names /opt/rocm's by the same sonames.  Loaded in the order
+    library -> torch, the process used to hold two HSA runtimes and torch found "No HIP GPUs" (seen on the MI355X box with a test subset
+    that imported torch late).  pbrt_amd._lib loads torch's copy first when torch is installed: one libamdhip64 and one libhsa-runtime64
+    in the process, both before and after `import torch`, in either order."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, os
+order = sys.argv[1]
+def runtimes():
+    libs = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l}
+    return sorted(os.path.realpath(p) for p in libs)
+if order == 'torch_first':
+    import torch
+import pbrt_amd
+pbrt_amd.device_count()
+before = runtimes()
+import torch
+torch.cuda.is_available()
+after = runtimes()
+assert before == after and len(after) == 2, (before, after)
+assert all(os.sep + 'torch' + os.sep in p for p in after), after
+print('ok')
+"""
+    for order in ("library_first", "torch_first"):
+        r = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, cwd=ROOT, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (order, r.stdout, r.stderr[-2000:])
