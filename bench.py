@@ -291,7 +291,10 @@ def main():
     t0 = time.time()
     sd = make_scene_data(kind, n, res)
     if in_process:
-        if pbrt_amd.device_count() < args.gpus:
+        # (PBRT_HIP_MULTI_LOOPBACK, a debug knob of multi_gpu.cpp: more ranks than devices, the exchange made of device-to-device copies --
+        # the N-rank code path on a one-GPU box; its line says so in "dist" and is no scaling measurement)
+        loopback = os.environ.get("PBRT_HIP_DEBUG_KNOBS", "0") not in ("", "0") and os.environ.get("PBRT_HIP_MULTI_LOOPBACK", "0") not in ("", "0")
+        if pbrt_amd.device_count() < args.gpus and not loopback:
             raise SystemExit(f"--gpus {args.gpus} but {pbrt_amd.device_count()} HIP device(s) visible")
         scene = pbrt_amd.MultiScene(sd, args.gpus, builder=args.builder)
         args.no_counters = True
@@ -342,7 +345,9 @@ def main():
     dist_info = {"backend": "none (one process, no process group)", "world_size": 1, "ranks_on_distinct_gpus": 1}
     if in_process:
         dist_info = {"backend": "rccl inside the library (pbrt_hip_multi_*: ncclCommInitAll, one group call per frame)", "world_size": 1,
-                     "gpus_in_process": scene.n_gpus, "ranks_on_distinct_gpus": scene.n_gpus}
+                     "gpus_in_process": scene.n_gpus, "ranks_on_distinct_gpus": min(scene.n_gpus, pbrt_amd.device_count())}
+        if dist_info["ranks_on_distinct_gpus"] < scene.n_gpus:
+            dist_info["backend"] = "loopback inside the library (PBRT_HIP_MULTI_LOOPBACK: ranks share devices, device-to-device copies instead of RCCL) -- NOT a scaling measurement"
     if use_pg:
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_on_distinct_gpus": None,
                      "nccl_is_rccl": bool(getattr(torch.version, "hip", None))}
