@@ -906,6 +906,26 @@ def test_mirror_furnace_is_exact_up_to_three_bounces_on_the_gpu(gpu, max_depth):
     assert exact.mean() >= 0.99 and (rgb <= want * (1 + 3e-6)).all(), (max_depth, exact.mean(), rgb.min(), rgb.max(), want)
 
 
+@pytest.mark.parametrize("max_depth", [2, 5])
+def test_path_integrator_agrees_with_an_independent_estimator_on_the_gpu(gpu, max_depth):
+    """The HIP path against tests/independent_mc.py (float64 numpy, own random numbers, no light sampling: the emitter is collected only
+    by running into it; no oracle involved): the closed box with a mirror wall at 1024 samples per pixel, integrators 0 and 2, the
+    stratified and the Halton sampler: every 8 x 8 block within 5 standard errors (+ 0.4 %) of the independent estimate, the image's
+    sum within 0.6 %; one bounce fewer is seen (8-11 standard errors, 3-4 % of the sum)."""
+    import independent_mc as im
+    from pbrt_amd import INTEGRATOR_PATH_MIS
+    mean, se = im.block_means(64, 64, 8, max_depth, 4_000_000)
+    sd = im.furnished_box_scene(64, 64)
+    with gpu.Scene(sd) as sc:
+        for kw in (dict(), dict(integrator=INTEGRATOR_PATH_MIS), dict(sampler="halton"), dict(sampler="sobol_nd", integrator=INTEGRATOR_PATH_MIS)):
+            film, _ = sc.render(max_depth=max_depth, spp=(32, 32), seed=2, **kw)
+            z, rel = im.compare_with_blocks(pbrt_amd.film_to_rgb(film), mean, se, 8)
+            assert z < 5.0 and abs(rel) < 6e-3, (kw, z, rel)
+        film, _ = sc.render(max_depth=max_depth - 1, spp=(32, 32), seed=2)
+        z, rel = im.compare_with_blocks(pbrt_amd.film_to_rgb(film), mean, se, 8)
+        assert z > 6 and rel < -0.02, (z, rel)
+
+
 def test_c1_at_full_size_equals_the_analytic_image_on_the_gpu(gpu):
     """BASELINE config C1 as written (1024 x 1024, 64 spp, direct lighting) against the image computed from first principles in float64
     numpy (util.c1_analytic_image; no oracle): camera model, sphere root, I / r^2, Kd / pi and the terminator, over 140 000 smooth pixels."""
