@@ -906,6 +906,20 @@ def test_mirror_furnace_is_exact_up_to_three_bounces_on_the_gpu(gpu, max_depth):
     assert exact.mean() >= 0.99 and (rgb <= want * (1 + 3e-6)).all(), (max_depth, exact.mean(), rgb.min(), rgb.max(), want)
 
 
+@pytest.mark.parametrize("builder", [None, "host"])
+@pytest.mark.parametrize("name", ["mesh1k", "cornell", "mesh20k"])
+def test_closest_hits_equal_a_float64_brute_force_on_the_gpu(gpu, name, builder):
+    """pbrt_hip_intersect (the production walk over the quantised 4-wide tree, either builder) against every ray x every triangle in
+    float64 numpy (util.brute_force_hits_f64; no oracle, no BVH): the same triangle and the same distance for every ray whose answer
+    cannot depend on rounding."""
+    from util import check_hits_against_brute_force
+    sd = SMALL_SCENES[name]()
+    o, d, tmax = random_rays(1500 if name == "mesh20k" else 3000, 11, inside=1.5)
+    with gpu.Scene(sd, builder=builder) as sc:
+        t, prim = sc.intersect(o, d, tmax)[:2]
+    check_hits_against_brute_force(sd, o, d, tmax, t, prim)
+
+
 @pytest.mark.parametrize("max_depth", [2, 5])
 def test_path_integrator_agrees_with_an_independent_estimator_on_the_gpu(gpu, max_depth):
     """The HIP path against tests/independent_mc.py (float64 numpy, own random numbers, no light sampling: the emitter is collected only

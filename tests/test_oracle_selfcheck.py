@@ -476,3 +476,15 @@ def test_path_integrator_agrees_with_an_independent_estimator(oracle):
     film, _ = oracle.OracleScene(sd).render(max_depth=4, spp=(16, 16), seed=1)  # the check can see one bounce
     z, rel = im.compare_with_blocks(oracle.film_write_rgb(film), mean, se, 8)
     assert z > 6 and rel < -0.03, (z, rel)
+
+
+@pytest.mark.parametrize("name", ["mesh1k", "cornell"])
+def test_closest_hits_equal_a_float64_brute_force(oracle, name):
+    """SURVEY A4 / A5 against tests/util.py brute_force_hits_f64: every ray against every triangle in float64 numpy, the textbook's
+    Moeller-Trumbore written there (no BVH, nothing shared).  Every ray whose answer cannot depend on rounding -- 99 % of them -- has the
+    same triangle and the same distance to 3e-5; the rest agree on 99.5 %."""
+    from util import check_hits_against_brute_force
+    sd = SMALL_SCENES[name]()
+    o, d, tmax = random_rays(3000, 11, inside=1.5)
+    t, prim = oracle.OracleScene(sd).intersect(o, d, tmax)[:2]
+    check_hits_against_brute_force(sd, o, d, tmax, t, prim)

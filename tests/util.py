@@ -286,3 +286,62 @@ def check_c1_against_analytic(rgb, sub=8):
     assert rel.max() < 1e-2 and rel.mean() < 6e-4, (rel.max(), rel.mean())  # (64 jittered samples against the regular grid, worst at the coarsest resolutions)
     # what the whole image integrates to (edges included: a pixel crossed by the silhouette or the terminator averages the same function)
     assert abs(rgb[..., 1].sum() / img.sum() - 1) < 2e-3, (rgb[..., 1].sum(), img.sum())
+
+
+def brute_force_hits_f64(sd, o, d, tmax):
+    """Closest hit of every ray against every triangle of sd, in float64 numpy (Moeller-Trumbore from the textbook, written here: no code
+    shared with the oracle or the library).  -> (t, prim, robust): prim -1 for a miss; `robust` marks rays whose answer cannot depend on
+    rounding -- a hit well inside its triangle and its (tmin, tmax) interval with no other triangle near the same distance, or a miss with
+    nothing close to an edge."""
+    P = sd.P.astype(np.float64)[sd.idx.astype(np.int64)]  # [T, 3, 3]
+    p0, e1, e2 = P[:, 0], P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]
+    n = o.shape[0]
+    t_best = np.full(n, np.inf)
+    prim = np.full(n, -1, np.int64)
+    robust = np.ones(n, bool)
+    step = max(16, 262144 // max(1, P.shape[0]))  # rays per pass: a few hundred thousand (ray, triangle) pairs at a time
+    for a in range(0, n, step):
+        _brute_force_pass(slice(a, min(n, a + step)), o, d, tmax, p0, e1, e2, t_best, prim, robust)
+    return t_best, prim, robust
+
+
+def _brute_force_pass(sl, o, d, tmax, p0, e1, e2, t_best, prim, robust):
+    with np.errstate(all="ignore"):
+        oo, dd = o[sl].astype(np.float64)[:, None, :], d[sl].astype(np.float64)[:, None, :]
+        tm = tmax[sl].astype(np.float64)[:, None]
+        pv = np.cross(dd, e2[None])
+        det = (e1[None] * pv).sum(-1)
+        inv = 1.0 / det
+        tv = oo - p0[None]
+        u = (tv * pv).sum(-1) * inv
+        qv = np.cross(tv, e1[None])
+        v = (dd * qv).sum(-1) * inv
+        t = (e2[None] * qv).sum(-1) * inv
+        ok = (np.abs(det) >= 1e-8) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 1e-4) & (t < tm)
+        tt = np.where(ok, t, np.inf)
+        k = np.argmin(tt, axis=1)
+        r = np.arange(tt.shape[0])
+        best = tt[r, k]
+        t_best[sl] = best
+        prim[sl] = np.where(np.isfinite(best), k, -1)
+        # how close anything comes to changing the answer
+        edge = np.minimum(np.minimum(u, v), 1 - u - v)  # > 0 inside
+        ahead = t < (best * (1 + 1e-5) + 1e-5)[:, None]  # (what lies behind the closest hit cannot change it)
+        near_edge = (np.abs(edge) < 1e-4) & (np.abs(det) >= 1e-9) & (t > 0.9e-4) & (t < tm * 1.0001 + 1e-4) & ahead
+        near_limit = ok & ((t < 1.2e-4) | (t > tm * 0.9999))
+        small_det = (np.abs(det) < 1e-7) & (np.abs(det) > 0) & ahead & (t > 0)
+        tt2 = tt.copy()
+        tt2[r, k] = np.inf
+        fragile = (near_edge | near_limit | small_det).any(1) | (np.isfinite(best) & (tt2.min(1) - best < 1e-5 * np.maximum(1, best)))
+        robust[sl] = ~fragile
+
+
+def check_hits_against_brute_force(sd, o, d, tmax, t, prim):
+    """(t, prim) from pbrt_hip_intersect / the oracle (float32; a miss has prim 0xffffffff)."""
+    bt, bp, robust = brute_force_hits_f64(sd, o, d, tmax)
+    got = np.where(prim == 0xffffffff, -1, prim.astype(np.int64))
+    assert robust.mean() > 0.9, robust.mean()
+    assert (got[robust] == bp[robust]).all(), np.nonzero(robust & (got != bp))[0][:10]
+    hit = robust & (bp >= 0)
+    assert hit.sum() > 100 and np.allclose(t[hit], bt[hit], rtol=3e-5, atol=1e-6)
+    assert (got == bp).mean() > 0.995  # the fragile ones still mostly agree
