@@ -397,10 +397,10 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // its next node gets its loads out before the other waves' decode and slab tests.  With the same around the leaf
       // pass's triangle fetch and 1 for the service stage: C3 +3.5 %, C2 +0.7 % (tools/experiments/README.md).
       wave_prio(PBRT_PRIO_FETCH);
-      const uint4 W0 = *reinterpret_cast<const uint4 *>(quads + off);
-      const uint4 W1 = *reinterpret_cast<const uint4 *>(quads + off + 16u);
-      const uint4 W2 = *reinterpret_cast<const uint4 *>(quads + off + 32u);
-      const uint4 W3 = *reinterpret_cast<const uint4 *>(quads + off + 48u);
+      const uint4 W0 = EXP_NODE_LOAD(reinterpret_cast<const uint4 *>(quads + off));
+      const uint4 W1 = EXP_NODE_LOAD(reinterpret_cast<const uint4 *>(quads + off + 16u));
+      const uint4 W2 = EXP_NODE_LOAD(reinterpret_cast<const uint4 *>(quads + off + 32u));
+      const uint4 W3 = EXP_NODE_LOAD(reinterpret_cast<const uint4 *>(quads + off + 48u));
       EXP_STEP_EXTRA_LOADS(quads, off, T);
       wave_prio(PBRT_PRIO_ARITH);
       if (COUNT) cn++;  // one 64-byte fetch
@@ -529,9 +529,9 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
         if (cnt > i && !stop) {
           const uint32_t slot = first + i;
           wave_prio(PBRT_PRIO_FETCH);  // (as for the node fetch)
-          const float4 a = *reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride));
-          const float4 b = *reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride) + 16u);
-          const float4 c = *reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride) + 32u);
+          const float4 a = EXP_TRI_LOAD(reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride)));
+          const float4 b = EXP_TRI_LOAD(reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride) + 16u));
+          const float4 c = EXP_TRI_LOAD(reinterpret_cast<const float4 *>(tris + slot * (16u * kTriStride) + 32u));
           wave_prio(PBRT_PRIO_ARITH);
           if (COUNT) ct++;
               // Moeller-Trumbore, operation order of DESIGN.md 3.5
