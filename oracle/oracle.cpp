@@ -388,14 +388,20 @@ class PathIntegrator {
       Vec3 nf = dot(ng, wo) < 0.f ? -ng : ng;
       Vec3 po = p + nf * kSpawnEps;
       Vec3 k = v3(m->k[0], m->k[1], m->k[2]);
-      if (m->type == 0 && m->kd_tex != 0u && h.prim < scene.n_tris() && !scene.tri_uv.empty()) {
+      if (m->type == 0 && m->kd_tex != 0u && (h.prim >= scene.n_tris() || !scene.tri_uv.empty())) {
         // Kd from a texture (pbrt-v3 Checkerboard2DTexture over UVMapping2D, aamode none): the corner (u, v) of the
-        // triangle interpolated with the hit's barycentrics in the order the hit point is, then (s, t) = (su u + du, sv v + dv);
-        // tex1 where floor(s) + floor(t) is even
+        // triangle interpolated with the hit's barycentrics in the order the hit point is -- a sphere: its own (u, v), sphere_uv on the
+        // normal --, then (s, t) = (su u + du, sv v + dv); tex1 where floor(s) + floor(t) is even
         const orc_texture &tx = scene.textures[m->kd_tex - 1u];
-        const float *uv = &scene.tri_uv[6 * (size_t)h.prim];
-        const float w = (1.0f - h.b1) - h.b2;
-        const float u = (uv[0] * w + uv[2] * h.b1) + uv[4] * h.b2, v = (uv[1] * w + uv[3] * h.b1) + uv[5] * h.b2;
+        float u, v;
+        if (h.prim < scene.n_tris()) {
+          const float *uv = &scene.tri_uv[6 * (size_t)h.prim];
+          const float w = (1.0f - h.b1) - h.b2;
+          u = (uv[0] * w + uv[2] * h.b1) + uv[4] * h.b2;
+          v = (uv[1] * w + uv[3] * h.b1) + uv[5] * h.b2;
+        } else {
+          sphere_uv(ng.x, ng.y, ng.z, &u, &v);
+        }
         const float ss = tx.su * u + tx.du, tt = tx.sv * v + tx.dv;
         const int cell = (int)std::floor(ss) + (int)std::floor(tt);
         k = (cell & 1) == 0 ? v3(tx.tex1[0], tx.tex1[1], tx.tex1[2]) : v3(tx.tex2[0], tx.tex2[1], tx.tex2[2]);

@@ -205,4 +205,46 @@ static inline float poly_cos(float x) {
   return ((p * z) * z - 0.5f * z) + 1.0f;
 }
 
+// ---- a sphere's (u, v) for 2-D textures (pbrt-v3 Sphere::Intersect: u = phi / 2 pi with phi = atan2(y, x) in [0, 2 pi),
+// v = (theta - pi) / (0 - pi) with theta = acos(z)) on the unit normal n = (p - c) / r, the sphere's own frame being the world's axes.  atan
+// and asin are the Cephes single-precision polynomials written out (|error| < 2e-7), the same operations on CPU and GPU. ----
+static inline float poly_atan_pos(float x) {  // x >= 0 (+inf included): atan(x) in [0, pi / 2]
+  float y0 = 0.f;
+  if (x > 2.414213562373095f) {
+    y0 = 1.5707963267948966f;
+    x = -(1.0f / x);
+  } else if (x > 0.4142135623730950f) {
+    y0 = 0.7853981633974483f;
+    x = (x - 1.0f) / (x + 1.0f);
+  }
+  const float z = x * x;
+  float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+  p = p * z + 1.99777106478e-1f;
+  p = p * z - 3.33329491539e-1f;
+  return y0 + ((p * z) * x + x);
+}
+static inline float poly_asin_small(float a) {  // |a| <= 0.5
+  const float z = a * a;
+  float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
+  p = p * z + 4.5470025998e-2f;
+  p = p * z + 7.4953002686e-2f;
+  p = p * z + 1.6666752422e-1f;
+  return (p * z) * a + a;
+}
+static inline float poly_acos(float x) {  // x in [-1, 1]
+  if (x < -0.5f) return 3.14159265358979323846f - 2.0f * poly_asin_small(std::sqrt(0.5f * (1.0f + x)));
+  if (x > 0.5f) return 2.0f * poly_asin_small(std::sqrt(0.5f * (1.0f - x)));
+  return 1.5707963267948966f - poly_asin_small(x);
+}
+static inline void sphere_uv(float nx, float ny, float nz, float *u, float *v) {
+  const float ax = std::fabs(nx), ay = std::fabs(ny);
+  float phi = (ax == 0.f && ay == 0.f) ? 0.f : poly_atan_pos(ay / ax);  // first quadrant (ax == 0: atan(+inf) = pi / 2)
+  if (nx < 0.f) phi = 3.14159265358979323846f - phi;
+  if (ny < 0.f) phi = 6.28318530717958647692f - phi;
+  const float zc = nz < -1.0f ? -1.0f : (nz > 1.0f ? 1.0f : nz);
+  const float theta = poly_acos(zc);
+  *u = phi * 0.15915494309189533577f;  // 1 / (2 pi)
+  *v = (theta - 3.14159265358979323846f) / (0.f - 3.14159265358979323846f);
+}
+
 }  // namespace orc

@@ -736,7 +736,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     if (!(d->fov > 0.f && d->fov < 180.f)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: fov must lie in (0, 180) degrees");
     for (uint32_t s = 0; s < d->n_spheres; s++)
       if (d->spheres[s].mat >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere material id out of range");
-    bool textured = false;  // a triangle whose material's Kd is a texture
+    bool textured = false;      // a triangle whose material's Kd is a texture: its corner (u, v) must be there
+    bool textured_sph = false;  // a sphere whose material's Kd is one: (u, v) from its own parametrisation (kernels.hip sphere_uv)
     if (d->n_textures && !d->textures) return fail(PBRT_HIP_ERR_INVALID, "scene_create: n_textures > 0 but no texture table");
     for (uint32_t i = 0; i < d->n_mats; i++) {
       if (d->mats[i].kd_tex > d->n_textures) return fail(PBRT_HIP_ERR_INVALID, "scene_create: material texture number out of range");
@@ -749,6 +750,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
         return fail(PBRT_HIP_ERR_INVALID, "scene_create: texture mapping is not finite");
     }
     for (uint32_t t = 0; t < d->n_tris && !textured; t++) textured = d->mats[d->mat_id[t]].kd_tex != 0u && d->mats[d->mat_id[t]].type == 0u;
+    for (uint32_t i = 0; i < d->n_spheres && !textured_sph; i++) textured_sph = d->mats[d->spheres[i].mat].kd_tex != 0u && d->mats[d->spheres[i].mat].type == 0u;
     if (textured && !d->tri_uv) return fail(PBRT_HIP_ERR_INVALID, "scene_create: a triangle's material is textured but tri_uv is NULL");
     if (textured)
       for (size_t i = 0; i < 6 * (size_t)d->n_tris; i++)
@@ -771,7 +773,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     s->desc.P = nullptr; s->desc.idx = nullptr; s->desc.mat_id = nullptr;
     s->desc.mats = nullptr; s->desc.lights = nullptr; s->desc.spheres = nullptr;
     s->desc.tri_uv = nullptr; s->desc.textures = nullptr;
-    s->textured = textured;
+    s->textured = textured || textured_sph;
 
     // --- accelerator: ONE default -- the device builder further down (binned SAH + parallel re-insertion + collapse), whoever asks
     // and however (pbrt_hip_scene_create, flags 0, pbrt_hip_render_multi, the command line, bench.py); the host's binned-SAH
@@ -905,7 +907,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     HIP_TRY(up(s->d_lights.p, lights.data(), lights.size() * 16));
     HIP_TRY(up(s->d_spheres.p, spheres.data(), spheres.size() * 16));
     HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order.p, nt, s->d_tris.p, s->stream));
-    if (textured) {  // corner (u, v) into leaf-slot order (whichever builder made d_order), the texture table as 3 x 16 B records
+    if (textured || textured_sph) {  // corner (u, v) into leaf-slot order (whichever builder made d_order), the texture table as 3 x 16 B records
       std::vector<float4> tex(3 * (size_t)d->n_textures);
       for (uint32_t i = 0; i < d->n_textures; i++) {
         const pbrt_hip_texture &tx = d->textures[i];
@@ -913,12 +915,14 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
         tex[3 * i + 1] = make_float4(tx.tex2[0], tx.tex2[1], tx.tex2[2], tx.su);
         tex[3 * i + 2] = make_float4(tx.sv, tx.du, tx.dv, 0.f);
       }
-      HIP_TRY(s->d_tri_uv_in.alloc(6 * (size_t)nt));
-      HIP_TRY(s->d_tri_uv.alloc(3 * (size_t)nt));
       HIP_TRY(s->d_textures.alloc(tex.size()));
-      HIP_TRY(up(s->d_tri_uv_in.p, d->tri_uv, 24 * (size_t)nt));
       HIP_TRY(up(s->d_textures.p, tex.data(), tex.size() * 16));
-      HIP_TRY(launch_pack_uv(s->d_tri_uv_in.p, s->d_order.p, nt, s->d_tri_uv.p, s->stream));
+      if (textured) {
+        HIP_TRY(s->d_tri_uv_in.alloc(6 * (size_t)nt));
+        HIP_TRY(s->d_tri_uv.alloc(3 * (size_t)nt));
+        HIP_TRY(up(s->d_tri_uv_in.p, d->tri_uv, 24 * (size_t)nt));
+        HIP_TRY(launch_pack_uv(s->d_tri_uv_in.p, s->d_order.p, nt, s->d_tri_uv.p, s->stream));
+      }
       HIP_TRY(hipStreamSynchronize(s->stream));  // (tex is a local)
     }
     HIP_TRY(hipStreamSynchronize(s->stream));

@@ -364,7 +364,7 @@ struct Api {
   // Texture "name" "spectrum" "class" ... (api.rs:524-580 stores nothing; texture.rs is an empty marker).  On this path: a 2-D
   // CHECKERBOARD over the (u, v) mapping keeps its pattern (pbrt-v3 Checkerboard2DTexture, point-sampled: DESIGN.md 3.15) when a
   // matte material names it as Kd; every spectrum texture is also reduced to one constant colour, which is what a parameter other
-  // than a matte Kd -- and a sphere, whose (u, v) need libm -- gets.
+  // than a matte Kd gets.
   void texture(const std::string &name, const std::string &kind, const std::string &cls, const ParamSet &ps) {
     if (kind != "spectrum" && kind != "color" && kind != "rgb") return;  // float textures: nothing on the path uses them
     std::array<float, 3> c = {0.5f, 0.5f, 0.5f};
@@ -455,7 +455,14 @@ struct Api {
       s.mat = mid;
       out->spheres.push_back(s);
       if (gs.has_area_light && !in_object) warn("sphere area lights emit but are not sampled by the direct-light estimate");
-      if (gs.material.kd_tex) warn("a textured Kd on a sphere: the texture's mean colour is used (a sphere's (u, v) is not computed on this path)");
+      if (gs.material.kd_tex) {  // (u, v) = (phi / 2 pi, 1 - theta / pi) about the WORLD's z axis: a sphere is a centre and a radius here
+        bool axes_kept = true;
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++)
+            if (i != j && M[4 * i + j] != 0.f) axes_kept = false;
+        if (!axes_kept || M[0] < 0.f || M[5] < 0.f || M[10] < 0.f)
+          warn("a textured sphere under a rotating / mirroring transform: its (u, v) follow the world's axes, not the transformed ones");
+      }
     } else if (name == "trianglemesh") {
       const ParamItem *pi = ps.find("indices", "integer");
       const ParamItem *pp = ps.find("P", "point3");

@@ -906,6 +906,34 @@ def test_mirror_furnace_is_exact_up_to_three_bounces_on_the_gpu(gpu, max_depth):
     assert exact.mean() >= 0.99 and (rgb <= want * (1 + 3e-6)).all(), (max_depth, exact.mean(), rgb.min(), rgb.max(), want)
 
 
+def test_checkerboard_on_a_sphere(gpu, oracle):
+    """Textured spheres ((u, v) from the sphere's own parametrisation, atan / acos as polynomials on both sides): the closed
+    form on the HIP path (a uniform sky: every one-cell pixel is its cell's colour, the cell found by numpy in float64), and films equal to
+    the oracle's bit for bit where the texture meets everything else -- C0's scene with its sphere matte and checkered beside the checkered
+    ground, path depth 5, integrator 2, the table samplers, a wide box filter, three ranks."""
+    from pbrt_amd import INTEGRATOR_PATH_MIS, loader
+    from util import check_checker_sphere, checker_sphere_scene
+    sd = checker_sphere_scene(200, 120)
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(max_depth=1, spp=(4, 4), seed=3)
+    check_checker_sphere(pbrt_amd.film_to_rgb(film))
+    assert_bit_equal(film, oracle.OracleScene(sd).render(max_depth=1, spp=(4, 4), seed=3)[0], "checkered sphere under the sky")
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "c0_check_sphere.pbrt")).read()
+    text = text.replace("[400]", "[80]").replace('"integer pixelsamples" 128', '"integer pixelsamples" 8')
+    assert 'Material "mirror"' in text
+    text = text.replace('Material "mirror"', 'Texture "dots" "spectrum" "checkerboard" "float uscale" [10] "float vscale" [5] "rgb tex1" [.7 .2 .2] "rgb tex2" [.9 .9 .8]\n  Material "matte" "texture Kd" "dots"', 1)
+    ls = loader.load_string(text)
+    assert ls.scene.mat_tex[int(ls.scene.spheres[0, 4])] != 0 and not any("mean colour" in w for w in ls.warnings)
+    o = oracle.OracleScene(ls.scene)
+    kw = ls.render_kwargs()
+    with gpu.Scene(ls.scene) as sc:
+        for extra in (dict(), dict(integrator=INTEGRATOR_PATH_MIS), dict(sampler="sobol_nd"), dict(filter_width=(1.25, 1.5)), dict(sampler="stratified", integrator=INTEGRATOR_PATH_MIS, filter_width=(0.75, 2.0))):
+            k2 = dict(kw, seed=4, **extra)
+            assert_bit_equal(sc.render(**k2)[0], o.render(**k2)[0], f"C0 with a checkered sphere, {extra}")
+        parts = sum(sc.render(rank=r, world_size=3, seed=4, **kw)[0] for r in range(3))
+    assert_bit_equal(parts, o.render(seed=4, **kw)[0], "three ranks")
+
+
 @pytest.mark.parametrize("builder", [None, "host"])
 @pytest.mark.parametrize("name", ["mesh1k", "cornell", "mesh20k"])
 def test_closest_hits_equal_a_float64_brute_force_on_the_gpu(gpu, name, builder):

@@ -488,3 +488,13 @@ def test_closest_hits_equal_a_float64_brute_force(oracle, name):
     o, d, tmax = random_rays(3000, 11, inside=1.5)
     t, prim = oracle.OracleScene(sd).intersect(o, d, tmax)[:2]
     check_hits_against_brute_force(sd, o, d, tmax, t, prim)
+
+
+@pytest.mark.parametrize("res", [(160, 160), (200, 120)])
+def test_checkerboard_on_a_sphere_closed_form(oracle, res):
+    """A checkerboard Kd over a SPHERE's own (u, v) = (phi / 2 pi, 1 - theta / pi) (pbrt-v3 Sphere::Intersect; the path's atan / acos are
+    polynomials written out) under a uniform sky: every pixel inside one cell is that cell's colour to 3e-6, the cell
+    found with numpy's arctan2 / arccos in float64 (util.check_checker_sphere)."""
+    from util import check_checker_sphere, checker_sphere_scene
+    film, _ = oracle.OracleScene(checker_sphere_scene(*res)).render(max_depth=1, spp=(4, 4), seed=3)
+    check_checker_sphere(oracle.film_write_rgb(film))

@@ -357,3 +357,16 @@ def test_object_instances_cannot_ask_for_unbounded_memory(monkeypatch):
     with pytest.raises(PbrtHipError) as e:
         loader.load_string(text)
     assert "2^28" in str(e.value)
+
+
+def test_textured_sphere_keeps_its_texture():
+    """A checkerboard named as a sphere's matte Kd stays a checkerboard (the sphere's own (u, v)); a rotated or mirrored
+    sphere is rendered with (u, v) about the world's axes and says so."""
+    tex = 'Texture "c" "spectrum" "checkerboard" "float uscale" 8 "float vscale" 4 Material "matte" "texture Kd" "c" '
+    ls = loader.load_string("WorldBegin " + tex + 'Translate 1 2 3 Scale 2 2 2 Shape "sphere" "float radius" 0.5 WorldEnd')
+    assert ls.scene.mat_tex[int(ls.scene.spheres[0, 4])] == 1 and ls.scene.textures.shape[0] == 1
+    assert ls.scene.spheres[0, :4].tolist() == [1, 2, 3, 1.0]
+    assert not [w for w in ls.warnings if "sphere" in w]
+    for xf in ("Rotate 30 1 0 0", "Scale -1 1 1"):
+        ls = loader.load_string("WorldBegin " + tex + xf + ' Shape "sphere" WorldEnd')
+        assert any("world's axes" in w for w in ls.warnings), (xf, ls.warnings)

@@ -345,3 +345,62 @@ def check_hits_against_brute_force(sd, o, d, tmax, t, prim):
     hit = robust & (bp >= 0)
     assert hit.sum() > 100 and np.allclose(t[hit], bt[hit], rtol=3e-5, atol=1e-6)
     assert (got == bp).mean() > 0.995  # the fragile ones still mostly agree
+
+
+def checker_sphere_scene(xres, yres, su=8.0, sv=4.0):
+    """BASELINE C1's sphere and camera, the sphere matte with a checkerboard Kd over ITS OWN (u, v) = (phi / 2 pi, 1 - theta / pi)
+    (pbrt-v3 Sphere::Intersect; DESIGN.md 3.15), lit by a constant environment of radiance 1: a convex matte body under a uniform sky
+    reflects exactly Kd, so every sample's value is one of the texture's two colours (background: the sky, 1)."""
+    from pbrt_amd import LIGHT_INFINITE, scenes
+    sd = scenes.sphere_scene(xres, yres)
+    sd.lights = np.array([[LIGHT_INFINITE, 0, 0, 0, 1, 1, 1]], np.float32)
+    sd.mat_tex = np.array([1], np.uint32)
+    sd.textures = np.array([[0, 0.1, 0.2, 0.3, 0.8, 0.7, 0.6, su, sv, 0.0, 0.0]], np.float32)
+    return sd.normalized()
+
+
+def check_checker_sphere(rgb, su=8.0, sv=4.0, sub=4):
+    """rgb[y, x, 3]: checker_sphere_scene rendered with the path integrator at maxdepth 1.  The expected image from first principles in
+    float64 numpy (camera and sphere root as in c1_analytic_image, numpy's own arctan2 / arccos for the parametrisation): every pixel all
+    of whose sub x sub points fall into one cell of the checkerboard must be that cell's colour to 3e-6; the others one of the two colours
+    mixed (between them); the background the sky."""
+    yres, xres, _ = rgb.shape
+    eye, look, up, fov = np.array([3.0, 4.0, 1.5]), np.array([0.5, 0.5, 0.0]), np.array([0.0, 0.0, 1.0]), 45.0
+    fwd = (look - eye) / np.linalg.norm(look - eye)
+    right = np.cross(up, fwd)
+    right /= np.linalg.norm(right)
+    new_up = np.cross(fwd, right)
+    aspect = xres / yres
+    wx, wy = (aspect, 1.0) if aspect >= 1 else (1.0, 1.0 / aspect)
+    t = np.tan(np.radians(fov) / 2)
+    fx, fy = (np.arange(xres * sub) + 0.5) / sub, (np.arange(yres * sub) + 0.5) / sub
+    d = ((2 * fx / xres - 1) * wx * t)[None, :, None] * right + ((1 - 2 * fy / yres) * wy * t)[:, None, None] * new_up + fwd
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    b = 2 * (d @ eye)
+    disc = b * b - 4 * (eye @ eye - 1.0)
+    hit = disc > 0
+    tt = np.where(hit, (-b - np.sqrt(np.where(hit, disc, 0))) / 2, 0)
+    n = eye + tt[..., None] * d
+    phi = np.arctan2(n[..., 1], n[..., 0])
+    phi = np.where(phi < 0, phi + 2 * np.pi, phi)
+    theta = np.arccos(np.clip(n[..., 2], -1, 1))
+    u, v = phi / (2 * np.pi), 1 - theta / np.pi
+    fs, ft = su * u, sv * v
+    cell = (np.floor(fs) + np.floor(ft)).astype(np.int64) & 1
+    # a point is safely inside its cell when neither coordinate is within 2e-3 of a border (the seam phi = 0 is one)
+    safe = hit & (np.abs(fs - np.round(fs)) > 2e-3) & (np.abs(ft - np.round(ft)) > 2e-3)
+    blk = lambda a: a.reshape(yres, sub, xres, sub)
+    one_cell = blk(safe).all((1, 3)) & (blk(cell).max((1, 3)) == blk(cell).min((1, 3)))
+    all_miss = blk(~hit).all((1, 3))
+    pad = lambda m: np.logical_and.reduce([np.pad(m, 1, constant_values=False)[1 + dy:1 + dy + yres, 1 + dx:1 + dx + xres] for dy in (-1, 0, 1) for dx in (-1, 0, 1)])
+    one_cell, all_miss = pad(one_cell), pad(all_miss)  # (a jittered sample may fall where the regular grid does not)
+    c1, c2 = np.array([0.1, 0.2, 0.3]), np.array([0.8, 0.7, 0.6])
+    want = np.where(blk(cell)[:, 0, :, 0][..., None] == 0, c1, c2)
+    assert one_cell.mean() > 0.04 and all_miss.mean() > 0.5, (one_cell.mean(), all_miss.mean())
+    assert np.abs(rgb[one_cell] - want[one_cell]).max() < 3e-6
+    assert np.abs(rgb[all_miss] - 1.0).max() < 3e-6
+    both = [(np.abs(rgb[one_cell] - c).max(-1) < 3e-6).mean() for c in (c1, c2)]
+    assert min(both) > 0.25, both  # both colours show, on comparable areas
+    on_sphere = pad(blk(hit).all((1, 3)))
+    assert (rgb[on_sphere] >= c1 - 3e-6).all() and (rgb[on_sphere] <= c2 + 3e-6).all()  # a border pixel mixes the two
+    return one_cell.mean()
