@@ -808,7 +808,10 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
         std::memcpy(c2w.inv, api.ctm[0].m, 64);
         api.named_cs["camera"] = {c2w, c2w};
         api.camera_set = true;
-        ps.find("frameaspectratio", "float"); ps.find("screenwindow", "float"); ps.find("lensradius", "float");
+        // what the pinhole camera of this path does not model is said, not dropped in silence
+        if (ps.one_float("lensradius", 0.f) != 0.f) api.warn("Camera: \"lensradius\" ignored (pinhole camera: no depth of field)");
+        if (ps.find("screenwindow", "float") || ps.find("frameaspectratio", "float"))
+          api.warn("Camera: \"screenwindow\" / \"frameaspectratio\" ignored (the screen window follows the film's aspect ratio)");
         ps.find("focaldistance", "float"); ps.find("shutteropen", "float"); ps.find("shutterclose", "float");
         api.report_unused("Camera", ps);
       }
@@ -875,7 +878,12 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
           out->integrator = ps.one_bool("mis", false) ? PBRT_HIP_INTEGRATOR_PATH_MIS : PBRT_HIP_INTEGRATOR_PATH;
           if (name != "path") api.warn("Integrator \"" + name + "\": only \"path\" and \"directlighting\" exist, \"path\" used");
         }
-        ps.find("rrthreshold", "float"); ps.find("lightsamplestrategy", "string"); ps.find("strategy", "string");
+        if (ps.one_float("rrthreshold", 1.f) != 1.f) api.warn("Integrator: \"rrthreshold\" ignored (Russian roulette from the fourth bounce on with q = max(0.05, 1 - max beta))");
+        {
+          const std::string lss = ps.one_string("lightsamplestrategy", "uniform"), st = ps.one_string("strategy", "one");
+          if (lss != "uniform") api.warn("Integrator: \"lightsamplestrategy\" \"" + lss + "\" ignored (one light chosen uniformly)");
+          if (st != "one") api.warn("Integrator: \"strategy\" \"" + st + "\" ignored (one light per vertex, chosen uniformly, x the number of lights)");
+        }
         api.report_unused("Integrator", ps);
       }
     } else if (tok == "LightSource") {
@@ -918,7 +926,8 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
           out->sampler = PBRT_HIP_SAMPLER_STRATIFIED;
           out->spp_x = (uint32_t)std::max(1, ps.one_int("xsamples", 4));
           out->spp_y = (uint32_t)std::max(1, ps.one_int("ysamples", 4));
-          ps.find("jitter", "bool"); ps.find("dimensions", "integer");
+          if (!ps.one_bool("jitter", true)) api.warn("Sampler \"stratified\": \"jitter\" \"false\" ignored (samples are jittered inside their strata)");
+          ps.find("dimensions", "integer");
         } else {
           // "halton" (the reference's default name, api.rs:235) and "sobol" have samplers of their own; the
           // other low-discrepancy names are served by the padded (0,2)-sequence sampler of 3.10, "random" and anything unknown

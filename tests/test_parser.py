@@ -370,3 +370,19 @@ def test_textured_sphere_keeps_its_texture():
     for xf in ("Rotate 30 1 0 0", "Scale -1 1 1"):
         ls = loader.load_string("WorldBegin " + tex + xf + ' Shape "sphere" WorldEnd')
         assert any("world's axes" in w for w in ls.warnings), (xf, ls.warnings)
+
+
+def test_camera_parameters_the_pinhole_ignores_are_reported():
+    ls = loader.load_string('Camera "perspective" "float fov" 30 "float lensradius" 0.1 "float focaldistance" 4 "float screenwindow" [-1 1 -1 1]')
+    assert any("lensradius" in w for w in ls.warnings) and any("screenwindow" in w for w in ls.warnings)
+    ls = loader.load_string('Camera "perspective" "float fov" 30 "float lensradius" 0 "float shutteropen" 0')
+    assert not ls.warnings
+
+
+def test_integrator_parameters_without_effect_are_reported():
+    ls = loader.load_string('Integrator "path" "float rrthreshold" 0.5 "string lightsamplestrategy" "spatial"')
+    assert any("rrthreshold" in w for w in ls.warnings) and any("lightsamplestrategy" in w for w in ls.warnings)
+    ls = loader.load_string('Integrator "directlighting" "string strategy" "all"')
+    assert any('"strategy" "all"' in w for w in ls.warnings)
+    ls = loader.load_string('Integrator "path" "float rrthreshold" 1 "string lightsamplestrategy" "uniform" "integer maxdepth" 7')
+    assert not ls.warnings and ls.max_depth == 7
