@@ -32,6 +32,9 @@ int pbrt_hip_scene_walk_info(const pbrt_hip_scene *scene, uint32_t *quad_nodes, 
  * 64 x 4 bytes per wave, one-wave workgroups a CU holds at once with them (the grid is this x the CU count), and the
  * entries per lane kept in an HBM overflow area (non-zero = the overflow variant of the kernel). */
 int pbrt_hip_render_stack_plan(uint32_t stack_need, uint32_t *lds_rows, uint32_t *waves_per_cu, uint32_t *overflow_entries);
+/* the librccl the in-library multi-GPU path uses (pbrt_hip_multi_*: loaded on first use by dlopen): its file name -- it must be the one
+ * that belongs to the HIP runtime of the process (beside the loaded libamdhip64), whichever host loaded that.  No device is touched. */
+int pbrt_hip_rccl_library(char *path, size_t cap);
 /* host-only variant for CPU-side tests of the builder: no device is touched */
 int pbrt_hip_bvh_build_host(const float *P, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
                             uint32_t *nodes /* 8*(2*n_tris) words cap */, uint32_t *order, uint32_t *n_nodes,

@@ -64,6 +64,7 @@ SYMBOLS = {
     "pbrt_hip_scene_build_info": (C.c_int, [_vp, _pu32, C.POINTER(C.c_double)]),
     "pbrt_hip_scene_canonical_info": (C.c_int, [_vp, _pu32, C.POINTER(C.c_double)]),
     "pbrt_hip_scene_optimize_info": (C.c_int, [_vp, _pu32, _pu32, C.POINTER(C.c_double)]),
+    "pbrt_hip_rccl_library": (C.c_int, [C.c_char_p, C.c_size_t]),
     "pbrt_hip_scene_optimize_cost": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _pu32]),
     "pbrt_hip_scene_export_quads": (C.c_int, [_vp, _pu32, _u32, _pu32, _pu32]),
     "pbrt_hip_scene_destroy": (None, [_vp]),

@@ -55,8 +55,24 @@ Rccl &rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // The RCCL that belongs to the HIP runtime this process runs on: a PyTorch-ROCm process carries its own libamdhip64 AND its own
+    // librccl (torch/lib), a C++ host uses /opt/rocm's pair -- so the first candidates sit beside the libamdhip64 that is loaded (an
+    // RCCL of another ROCm release against this runtime is the mismatch to avoid), then the loader's search path.
+    std::vector<std::string> names;
+    if (void *sym = dlsym(RTLD_DEFAULT, "hipGetDeviceCount")) {
+      Dl_info info;
+      if (dladdr(sym, &info) && info.dli_fname) {
+        const std::string f = info.dli_fname;
+        const size_t slash = f.rfind('/');
+        if (slash != std::string::npos) {
+          names.push_back(f.substr(0, slash) + "/librccl.so.1");
+          names.push_back(f.substr(0, slash) + "/librccl.so");
+        }
+      }
+    }
+    for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(n);
+    for (const std::string &name : names) {
+      r.so = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (r.so) break;
     }
     if (!r.so) { r.why = std::string("cannot load librccl: ") + dlerror(); return; }
@@ -365,6 +381,15 @@ int pbrt_hip_multi_create(const pbrt_hip_scene_desc *d, int n_gpus, uint32_t fla
 }
 
 int pbrt_hip_multi_gpus(const pbrt_hip_multi *m) { return m ? m->n : 0; }
+
+int pbrt_hip_rccl_library(char *path, size_t cap) {
+  Rccl &rc = rccl();
+  if (!rc.why.empty()) return fail(PBRT_HIP_ERR_INTERNAL, rc.why);
+  Dl_info info;
+  if (!dladdr((void *)rc.Gather, &info) || !info.dli_fname) return fail(PBRT_HIP_ERR_INTERNAL, "rccl_library: dladdr failed");
+  if (path && cap) { std::strncpy(path, info.dli_fname, cap - 1); path[cap - 1] = 0; }
+  return PBRT_HIP_OK;
+}
 
 void pbrt_hip_multi_destroy(pbrt_hip_multi *m) { delete m; }
 

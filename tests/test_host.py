@@ -612,6 +612,12 @@ torch.cuda.is_available()
 after = runtimes()
 assert before == after and len(after) == 2, (before, after)
 assert all(os.sep + 'torch' + os.sep in p for p in after), after
+# ... and the RCCL of the in-library multi-GPU path is the one beside that runtime (torch's), not another ROCm release's
+import ctypes
+from pbrt_amd import _lib
+buf = ctypes.create_string_buffer(4096)
+assert _lib.lib().pbrt_hip_rccl_library(buf, 4096) == 0, _lib.lib().pbrt_hip_last_error()
+assert os.path.dirname(os.path.realpath(buf.value.decode())) == os.path.dirname(after[0]), (buf.value, after)
 print('ok')
 """
     for order in ("library_first", "torch_first"):
