@@ -21,10 +21,10 @@ def test_oracle_reproduces_round5_golden(oracle):
     """What round 5 added beside the default path -- sampler 2's dimensions 33 .. 128, the Halton sampler, integrator 2 (MIS), a
     checkerboard Kd -- pinned the same way (tests/golden/make_golden_r05.py); test_oracle_reproduces_golden above still passing on the
     round-2 file is the evidence that the default path's arithmetic did not move."""
-    from util import checker_plane_scene
-    scenes = dict(SMALL_SCENES, checker=lambda: checker_plane_scene(40)[0])
+    from util import checker_plane_scene, checker_sphere_scene
+    scenes = dict(SMALL_SCENES, checker=lambda: checker_plane_scene(40)[0], checkersphere=lambda: checker_sphere_scene(48, 40))
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_golden_r05.npz"))
-    assert len(g.files) == 9
+    assert len(g.files) == 11
     for key in g.files:
         name, integ, depth, sx, sy, seed, sampler = key.split("-")
         film, _ = oracle.OracleScene(scenes[name]()).render(integrator=int(integ), max_depth=int(depth),

@@ -385,10 +385,10 @@ def test_golden_fixture(gpu):
     """tests/golden/render_golden.npz: films the oracle produced when the fixtures were made
     (tests/golden/make_golden.py); the HIP path must reproduce them bit for bit."""
     import os
-    from util import checker_plane_scene
-    every = dict(SMALL_SCENES, checker=lambda: checker_plane_scene(40)[0])
-    # (render_golden_r05.npz: what round 5 added beside the default path -- samplers 2 / 3, integrator 2, a checkerboard Kd)
-    for fixture, n in (("render_golden.npz", 6), ("render_golden_r05.npz", 9)):
+    from util import checker_plane_scene, checker_sphere_scene
+    every = dict(SMALL_SCENES, checker=lambda: checker_plane_scene(40)[0], checkersphere=lambda: checker_sphere_scene(48, 40))
+    # (render_golden_r05.npz: what round 5 added beside the default path -- samplers 2 / 3, integrator 2, a checkerboard Kd on triangles and on a sphere)
+    for fixture, n in (("render_golden.npz", 6), ("render_golden_r05.npz", 11)):
         g = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
         assert len(g.files) == n
         for key in g.files:
