@@ -272,7 +272,7 @@ struct Api {
   // instancing multiplies geometry (instances x the object's triangles): a bound on what a small file can ask for (the tests lower it)
   const size_t kMaxSceneTriangles = [] {
     const char *on = std::getenv("PBRT_HIP_DEBUG_KNOBS"), *v = std::getenv("PBRT_HIP_MAX_SCENE_TRIANGLES");
-    return (on && *on && !(on[0] == '0' && !on[1]) && v && *v) ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)1 << 28;
+    return (on && *on && !(on[0] == '0' && !on[1]) && v && *v) ? (size_t)std::strtoull(v, nullptr, 10) : (size_t)1 << 24;  // = what pbrt_hip_scene_create takes (a leaf reference holds a 24-bit slot)
   }();
 
   explicit Api(LoadedScene *o) : out(o) {
@@ -490,7 +490,7 @@ struct Api {
       if (!read_ply(path, &mesh, &perr)) { warn("plymesh \"" + fn + "\": " + perr + ": shape skipped"); return; }  // (pbrt-v3 logs the error and goes on)
       if (mesh.skipped_faces) warn("plymesh \"" + fn + "\": " + std::to_string(mesh.skipped_faces) + " faces with other than 3 or 4 vertices ignored");
       if (mesh.idx.empty()) { warn("plymesh \"" + fn + "\": no faces: skipped"); return; }
-      if (out->idx.size() / 3 + mesh.idx.size() / 3 > kMaxSceneTriangles) { warn("plymesh \"" + fn + "\": scene would pass 2^28 triangles: skipped"); return; }
+      if (out->idx.size() / 3 + mesh.idx.size() / 3 > kMaxSceneTriangles) { warn("plymesh \"" + fn + "\": scene would pass 2^24 triangles: skipped"); return; }
       add_mesh(mesh.P.data(), (uint32_t)(mesh.P.size() / 3), mesh.idx.data(), mesh.idx.size() / 3, mesh.uv.empty() ? nullptr : mesh.uv.data(), mid);
       if (ps.find("alpha", "texture", "float") || ps.find("shadowalpha", "texture", "float")) warn("plymesh: alpha / shadowalpha are not supported (opaque)");
     } else {
@@ -1006,7 +1006,7 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     } else if (tok == "ObjectInstance") {
       if (!p.quoted(&name)) return fin(false);
       if (in_world("ObjectInstance") && !api.object_instance(name))
-        return fin(p.fail(ParseError::Syntax, "ObjectInstance \"" + name + "\": the scene would pass 2^28 triangles"));
+        return fin(p.fail(ParseError::Syntax, "ObjectInstance \"" + name + "\": the scene would pass 2^24 triangles"));
     } else if (tok == "MakeNamedMedium" || tok == "MediumInterface" || tok == "TransformTimes") {
       return fin(p.fail(ParseError::NotImplemented, tok));  // parser.rs:270-310: out of scope here too
     } else {

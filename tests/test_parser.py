@@ -348,15 +348,15 @@ def test_object_instancing_flattens_into_the_scene():
 
 
 def test_object_instances_cannot_ask_for_unbounded_memory(monkeypatch):
-    """A file of n bytes can ask for ~n^2 triangles (instances x the object's triangles): beyond 2^28 the file is refused with an error
-    instead of an allocation.  (The bound is lowered here: reaching the real one takes 10 GB of host arrays.)"""
+    """A file of n bytes can ask for ~n^2 triangles (instances x the object's triangles): beyond 2^24 (what pbrt_hip_scene_create takes) the file is refused with an error
+    instead of an allocation.  (The bound is lowered here: reaching the real one takes most of a gigabyte of host arrays.)"""
     tri = 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]'
     text = 'WorldBegin ObjectBegin "o" ' + " ".join([tri] * 10) + " ObjectEnd " + 'ObjectInstance "o" ' * 11 + "WorldEnd"
     assert loader.load_string(text).scene.idx.shape[0] == 110
     monkeypatch.setenv("PBRT_HIP_MAX_SCENE_TRIANGLES", "100")
     with pytest.raises(PbrtHipError) as e:
         loader.load_string(text)
-    assert "2^28" in str(e.value)
+    assert "2^24" in str(e.value)
 
 
 def test_textured_sphere_keeps_its_texture():
