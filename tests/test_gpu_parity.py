@@ -245,6 +245,36 @@ def test_render_limits(gpu):
         sc.render_wait()
 
 
+def test_maximum_triangle_count_matches_oracle(gpu, oracle):
+    """The largest scene the boundary takes -- 2^24 triangles (a leaf reference holds a 24-bit slot) -- built and optimised on the
+    device (1.1 s), rendered and intersected: film and 20 000 hit records equal to the oracle's on the same arrays; one triangle more is
+    refused with PBRT_HIP_ERR_LIMIT (tools/max_size_check.py is the same as a script; profiles/r05y_max_size_check.txt)."""
+    from pbrt_amd import _lib
+    sd = scenes.random_mesh_scene((1 << 24) - 14, 64, 48)  # + the box's 12 triangles and the light's 2
+    assert sd.idx.shape[0] == 1 << 24
+    kw = dict(max_depth=6, spp=(2, 2), seed=7)
+    o, d, tmax = random_rays(20000, 3, inside=1.9)
+    with gpu.Scene(sd) as sc:
+        assert sc.build_info()["gpu_built"]
+        film, st = sc.render(**kw)
+        hit = sc.intersect(o, d, tmax)
+        occ = sc.occluded(o, d, tmax)
+    ref = oracle.OracleScene(sd)
+    assert_bit_equal(film, ref.render(**kw)[0], "film of the 2^24-triangle scene")
+    rhit = ref.intersect(o, d, tmax)
+    for a, b, what in zip(hit[:4], rhit[:4], ("t", "prim", "b1", "b2")):
+        assert_bit_equal(a, b, f"2^24 triangles: {what}")
+    assert (rhit[1] != 0xffffffff).mean() > 0.9 and np.array_equal(occ != 0, ref.occluded(o, d, tmax) != 0)
+    del ref
+    more = SMALL_SCENES["cornell"]()
+    more.P = np.zeros((3, 3), np.float32)
+    more.idx = np.zeros(((1 << 24) + 1, 3), np.uint32)
+    more.mat_id = np.zeros((1 << 24) + 1, np.uint16)
+    with pytest.raises(_lib.PbrtHipError) as e:
+        gpu.Scene(more.normalized())
+    assert e.value.code == -4 and "2^24" in str(e.value)
+
+
 def test_maximum_sample_count_matches_oracle(gpu, oracle):
     """The largest sample count the boundary takes -- PBRT_HIP_MAX_SPP = 2^20 = 1024 x 1024 strata -- on a one-pixel crop window of
     the Cornell-style box: 16 chunks of 65 536 samples, the 20-bit sample index full, the longest RNG streams and (Halton) the most
