@@ -275,6 +275,23 @@ def test_maximum_triangle_count_matches_oracle(gpu, oracle):
     assert e.value.code == -4 and "2^24" in str(e.value)
 
 
+def test_large_film_matches_oracle(gpu, oracle):
+    """A 16 384 x 16 384 film (268 M pixels, 4.3 GB; 65 536 super-tiles; the partial sums in three passes under the 2 GiB cap) at one sample
+    per pixel: weight 1 everywhere, finite, and three 16 x 16 windows -- both far corners and one inside -- equal to the oracle's.
+    (32 768 x 32 768 renders likewise in 0.4 s of kernel time: profiles/README.md r05y; the suite stays at a size whose host-side checks
+    take a second.)"""
+    res = 16384
+    kw = dict(max_depth=5, spp=(1, 1), seed=3)
+    with gpu.Scene(scenes.cornell_scene(res, res)) as sc:
+        film, st = sc.render(**kw)
+    assert film.shape == (res, res, 4) and st["samples"] == res * res
+    assert (film[..., 3] == 1).all() and np.isfinite(film[::7]).all()
+    for (x0, y0) in ((0, 0), (res - 16, res - 16), (res // 2 + 5, res // 3)):
+        crop = (x0 / res, (x0 + 16) / res, y0 / res, (y0 + 16) / res)
+        ref, _ = oracle.OracleScene(scenes.cornell_scene(res, res, crop=crop)).render(**kw)
+        assert_bit_equal(film[y0:y0 + 16, x0:x0 + 16], ref, f"window at {x0},{y0} of the 16k film")
+
+
 def test_maximum_sample_count_matches_oracle(gpu, oracle):
     """The largest sample count the boundary takes -- PBRT_HIP_MAX_SPP = 2^20 = 1024 x 1024 strata -- on a one-pixel crop window of
     the Cornell-style box: 16 chunks of 65 536 samples, the 20-bit sample index full, the longest RNG streams and (Halton) the most
