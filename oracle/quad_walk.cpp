@@ -68,13 +68,27 @@ uint64_t *g_visits = nullptr;
 void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
   Out r;
   uint32_t cur = kDone;
-  const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-  const bool negx = inv.x < 0.f, negy = inv.y < 0.f, negz = inv.z < 0.f;
+  const V3 inv1 = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  const bool negx = inv1.x < 0.f, negy = inv1.y < 0.f, negz = inv1.z < 0.f;
   if (T.root_ref != kDone) {
     const float *b = T.root_box;
     const bool inside = o.x >= b[0] && o.x <= b[3] && o.y >= b[1] && o.y <= b[4] && o.z >= b[2] && o.z <= b[5];
-    if (inside || box_test(b, o, inv, tmax)) cur = (T.root_ref & kLeafRef) ? T.root_ref : 0u;
+    if (inside || box_test(b, o, inv1, tmax)) cur = (T.root_ref & kLeafRef) ? T.root_ref : 0u;
   }
+  // the kernel's stand-in for 1 / 0 (kernels.hip trav_run; pbrt_amd/csrc/host_math.hpp inv_parallel_for_extent, restated)
+  float big;
+  {
+    const float *b = T.root_box;
+    const float extent = std::fmax(b[3] - b[0], std::fmax(b[4] - b[1], b[5] - b[2]));
+    int x = 0;
+    if (extent > 0.f && std::isfinite(extent)) (void)std::frexp(2.0f * extent, &x);
+    int e = 123 - x;
+    if (e > 120) e = 120;
+    if (e < -100) e = -100;
+    big = std::ldexp(1.0f, e);
+  }
+  const V3 inv = {d.x == 0.f ? std::copysign(big, inv1.x) : inv1.x, d.y == 0.f ? std::copysign(big, inv1.y) : inv1.y,
+                  d.z == 0.f ? std::copysign(big, inv1.z) : inv1.z};
   std::vector<uint32_t> stack;
   stack.reserve(64);
   // experiment (ORC_WALK_CULL=n): every stacked entry carries its entry distance rounded DOWN to its n top bits (32: exact);

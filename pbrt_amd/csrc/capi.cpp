@@ -718,6 +718,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     if (d->n_tris && (!d->P || !d->idx || !d->mat_id)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: missing mesh arrays");
     if ((d->n_tris || d->n_spheres) && (!d->mats || d->n_mats == 0)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: no materials");
     if (d->n_mats > 65536) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 65536 materials");
+    if (d->n_tris > (1u << 24)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 2^24 triangles (leaf references hold a 24-bit slot)");
     for (size_t i = 0; i < 3 * (size_t)d->n_tris; i++)
       if (d->idx[i] >= d->n_verts) return fail(PBRT_HIP_ERR_INVALID, "scene_create: vertex index out of range");
     for (uint32_t t = 0; t < d->n_tris; t++)
@@ -793,7 +794,6 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       flags |= PBRT_HIP_SCENE_GPU_BUILD;  // (PBRT_HIP_SCENE_PLAIN_TREE alone qualifies the default)
     }
     s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && d->n_tris >= 2;
-    if (d->n_tris > (1u << 24)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 2^24 triangles (leaf references hold a 24-bit slot)");
     PairNodes pairs;
     if (!s->gpu_built) {
       const auto t0 = std::chrono::steady_clock::now();
@@ -947,6 +947,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       for (int k = 0; k < 3; k++) { D.root_lo[k] = gb.root_lo[k]; D.root_hi[k] = gb.root_hi[k]; }
       s->n_quads_gpu = gb.n_quads;
     }
+    D.inv_parallel = inv_parallel_for_extent(std::max(D.root_hi[0] - D.root_lo[0], std::max(D.root_hi[1] - D.root_lo[1], D.root_hi[2] - D.root_lo[2])));
     D.n_tris = nt;
     D.n_spheres = d->n_spheres;
     D.n_lights = s->n_lights;

@@ -132,6 +132,10 @@ struct DevScene {
   float cam_ax, cam_bx, cam_ay, cam_by;
   int32_t xres, yres;
   int32_t cx0, cy0, cx1, cy1;  // cropped pixel bounds
+  // The production walk's stand-in for 1 / 0 (a ray PARALLEL to a slab; kernels.hip trav_run): a power of two so large that every t it
+  // makes lies outside any ray interval, yet small enough that (o - origin) x it stays finite for every origin inside the root box
+  // (host_math.hpp inv_parallel_for_extent).
+  float inv_parallel;
 };
 
 struct RenderParams {

@@ -376,9 +376,21 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
                                          const bool alive, const TravTuning tune, unsigned long long &cn,
                                          unsigned long long &ct) {
   const V3 o = T.o, d = T.d;
-  const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-  const bool negx = inv.x < 0.f, negy = inv.y < 0.f, negz = inv.z < 0.f;
+  const V3 inv1 = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  const bool negx = inv1.x < 0.f, negy = inv1.y < 0.f, negz = inv1.z < 0.f;
   const uint32_t negbits = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
+  // Production walk: a ray PARALLEL to a slab (d exactly 0 on that axis; 1 / d = +-inf) multiplies by the scene's huge finite power of
+  // two instead (device_types.h inv_parallel, host_math.hpp): with inf every quantised plane's t = q * inf - inf is NaN, the axis drops
+  // out of the slab test and a ray along an axis -- every shadow ray towards a sun straight overhead -- walks the whole tree.  The
+  // canonical walk (EXACT) keeps 1 / 0 = inf: its planes are real floats ((lo - o) * inf is +-inf with the right sign) and its visit
+  // counters are the oracle's.
+#ifdef PBRT_INV_INF  // A-B switch: the walk as it was before the stand-in (tools/experiments/README.md, round 5)
+  const V3 inv = inv1;
+#else
+  const V3 inv = EXACT ? inv1
+                       : V3{d.x == 0.f ? copysignf(S.inv_parallel, inv1.x) : inv1.x, d.y == 0.f ? copysignf(S.inv_parallel, inv1.y) : inv1.y,
+                            d.z == 0.f ? copysignf(S.inv_parallel, inv1.z) : inv1.z};
+#endif
   const char *nodes = reinterpret_cast<const char *>(S.nodes);
   const char *quads = reinterpret_cast<const char *>(S.quads);
   const char *tris = reinterpret_cast<const char *>(S.tris);
@@ -455,9 +467,10 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // roundings inside gi = fl(fl(o - origin) * inv) are absolute errors <= 2 eps |gi| in t, covered by
       // the margin m = 3 eps |gi|: near planes subtract gi + m, far planes gi - m, so every computed
       // t_near / t_far lies outside the true one and the walk stays a superset of the exact walk; the
-      // fma's own relative rounding is what the (1 + 2 gamma_3) pad of DESIGN.md 3.4 is for.  An
-      // infinite inv (ray parallel to the slab) yields NaN or +-inf, which fmin / fmax ignore or keep
-      // conservative.
+      // fma's own relative rounding is what the (1 + 2 gamma_3) pad of DESIGN.md 3.4 is for.  A ray
+      // parallel to the slab (d = 0) has the scene's finite stand-in for 1 / 0 in inv (above): t is then
+      // negative huge or positive huge by the side of the plane the origin is on; an inv that is infinite
+      // because d is a denormal yields NaN or +-inf, which fmin / fmax ignore or keep conservative.
       const float gx = (o.x - __uint_as_float(W0.x)) * inv.x, gy = (o.y - __uint_as_float(W0.y)) * inv.y;
       const float gz = (o.z - __uint_as_float(W0.z)) * inv.z;
       // g +- 3 eps |g| as one fma each (|x| and -x are operand modifiers): rounded once instead of twice, at least

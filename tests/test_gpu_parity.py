@@ -245,6 +245,45 @@ def test_render_limits(gpu):
         sc.render_wait()
 
 
+def test_rays_parallel_to_an_axis_are_pruned_like_any_other(gpu, oracle):
+    """A direction component that is exactly 0 (a shadow ray towards a sun straight overhead -- pbrt-v3's default distant light points
+    along z --, a probe ray along an axis) used to turn every quantised plane's t on that axis into NaN (q x inf - inf): the axis dropped
+    out of the slab test and such a ray walked every node its remaining coordinate allowed -- 2 500 x the frame time on 1 M triangles,
+    found with the 2^24-triangle scene.  The production walk now multiplies by a huge finite power of two instead (kernels.hip trav_run,
+    host_math.hpp inv_parallel_for_extent): same film and hits as the oracle, and about the node fetches of a ray that is not parallel."""
+    from pbrt_amd import LIGHT_DISTANT
+    fetches = {}
+    for name, w in (("overhead", (0.0, 0.0, 1.0)), ("tilted", (0.01, 0.02, 1.0))):
+        sd = scenes.random_mesh_scene(20000, 96, 96)
+        v = np.array(w) / np.linalg.norm(w)
+        sd.lights = np.array([[LIGHT_DISTANT, v[0], v[1], v[2], 3, 3, 3]], np.float32)
+        sd = sd.normalized()
+        kw = dict(max_depth=3, spp=(2, 2), seed=1)
+        ref, rst = oracle.OracleScene(sd).render(**kw)
+        with gpu.Scene(sd) as sc:
+            film, _ = sc.render(**kw)
+            _, wk = sc.render(counters="walk", **kw)
+        assert_bit_equal(film, ref, f"sun {name}")
+        fetches[name] = wk["nodes_visited"] / (rst["camera_rays"] + rst["bounce_rays"] + rst["shadow_rays"])
+    assert fetches["overhead"] < 1.5 * fetches["tilted"], fetches
+    # probe rays along the axes and the diagonals of the coordinate planes, from inside and outside the scene
+    sd = SMALL_SCENES["mesh20k"]()
+    rng = np.random.default_rng(5)
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 0], [0, -1, 1], [-1, 0, 1], [0, -0.0, 1]], np.float32)
+    d = np.repeat(dirs, 200, 0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = rng.uniform(-1.6, 1.6, d.shape).astype(np.float32)
+    o[::3] = np.round(o[::3] * 4) / 4  # origins on round coordinates: planes of the grid the nodes sit on
+    tmax = np.full(len(d), np.inf, np.float32)
+    with gpu.Scene(sd) as sc:
+        hit = sc.intersect(o, d, tmax)
+        occ = sc.occluded(o, d, tmax)
+    ref = oracle.OracleScene(sd)
+    for a, b, what in zip(hit[:4], ref.intersect(o, d, tmax)[:4], ("t", "prim", "b1", "b2")):
+        assert_bit_equal(a, b, f"axis-parallel rays: {what}")
+    assert np.array_equal(occ != 0, ref.occluded(o, d, tmax) != 0)
+
+
 def test_maximum_triangle_count_matches_oracle(gpu, oracle):
     """The largest scene the boundary takes -- 2^24 triangles (a leaf reference holds a 24-bit slot) -- built and optimised on the
     device (1.1 s), rendered and intersected: film and 20 000 hit records equal to the oracle's on the same arrays; one triangle more is

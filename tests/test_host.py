@@ -545,6 +545,34 @@ def test_production_tree_finds_the_oracles_hits(oracle, name, tree):
     _check_quads(q["quads"], q["stack_need"], sd.P, sd.idx, q["order"])
 
 
+def test_walk_prunes_rays_parallel_to_an_axis(oracle):
+    """The kernel's step restated (oracle/quad_walk.cpp) on rays with direction components that are exactly 0: the slab test of such an axis
+    must still prune (the walk multiplies by a huge finite power of two where 1 / d is infinite: a quantised plane's t = q x inf - inf was
+    NaN and the axis dropped out) -- about the node steps of a ray in general position instead of a tenth of the tree --, with the
+    oracle's hits; also in scenes of size 1e12 and 1e-2 (the stand-in follows the root box's extent)."""
+    from pbrt_amd.api import quad_build_host_ex
+    from util import SMALL_SCENES
+    rng = np.random.default_rng(5)
+    dirs = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 0], [0, -1, 1], [-1, 0, 1], [0, -0.0, 1]], np.float32)
+    d = np.repeat(dirs, 300, 0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for scale in (1.0, 1e12, 1e-2):
+        sd = SMALL_SCENES["mesh20k"]().normalized()
+        sd.P = (sd.P.astype(np.float64) * scale).astype(np.float32)
+        o = (rng.uniform(-1.6, 1.6, d.shape) * scale).astype(np.float32)
+        o[::3] = (np.round(o[::3].astype(np.float64) / scale * 4) / 4 * scale).astype(np.float32)  # on round planes of the nodes' grids
+        tmax = np.full(len(d), np.inf, np.float32)
+        q = quad_build_host_ex(sd.P, sd.idx, tree="sah")
+        got = oracle.quad_walk(q["quads"], q["root_box"], sd.P, sd.idx, q["order"], o, d, tmax)
+        g = rng.normal(size=d.shape)
+        dg = (g / np.linalg.norm(g, axis=1, keepdims=True)).astype(np.float32)
+        general = oracle.quad_walk(q["quads"], q["root_box"], sd.P, sd.idx, q["order"], o, dg, tmax)
+        rt, rp = oracle.OracleScene(sd).intersect(o, d, tmax)[:2]
+        assert np.array_equal(got["prim"], rp) and np.array_equal(got["t"].view(np.uint32), rt.view(np.uint32)), scale
+        assert (rp != 0xffffffff).mean() > 0.3
+        assert got["steps"].mean() < 1.5 * general["steps"].mean(), (scale, got["steps"].mean(), general["steps"].mean())
+
+
 def test_reinsertion_cuts_the_walks_work(oracle):
     """PBRT_HIP_SCENE_OPTIMIZED_TREE / PBRT_HIP_TREE_REINSERT (the device builder's parallel re-insertion pass, run here on the host):
     on a mesh of BASELINE's kind the optimised tree costs a walk less work than the binned-SAH tree for the same hits -- here (20 k

@@ -24,6 +24,7 @@ print(f"scene: {sd.idx.shape[0]} triangles ({time.time() - t:.1f} s)")
 kw = dict(max_depth=6, spp=(2, 2), seed=7)
 o, d, tmax = random_rays(20000, 3, inside=1.9)
 t = time.time()
+t0 = time.time()
 with pbrt_amd.Scene(sd) as sc:
     info = sc.build_info()
     print(f"device build: {info.get('build_ms', 0):.0f} ms, optimisation {info.get('reinsert_ms', 0):.0f} ms, {sc.info()['device_bytes'] / 2**30:.2f} GiB on the device ({time.time() - t:.1f} s with the upload)")
@@ -31,16 +32,20 @@ with pbrt_amd.Scene(sd) as sc:
     hit = sc.intersect(o, d, tmax)
     occ = sc.occluded(o, d, tmax)
     print(f"render: {st['kernel_ms']:.1f} ms for {st['samples']} samples")
+print(f"GPU side in all: {time.time() - t0:.1f} s")
 t = time.time()
 ref = ob.OracleScene(sd)
 print(f"oracle tree: {time.time() - t:.1f} s")
+t = time.time()
 rfilm, _ = ref.render(**kw)
 rhit = ref.intersect(o, d, tmax)
 rocc = ref.occluded(o, d, tmax)
+print(f"oracle film + hits: {time.time() - t:.1f} s")
 ok = np.array_equal(film.view(np.uint32), rfilm.view(np.uint32))
 ok_hit = all(np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)) for a, b in zip(hit[:4], rhit[:4]))
 ok_occ = np.array_equal(occ != 0, rocc != 0)
 print("film bit-equal:", ok, "| hit records bit-equal:", ok_hit, f"({(rhit[1] != 0xffffffff).mean():.3f} of the rays hit)", "| occlusion equal:", ok_occ)
+t = time.time()
 one_more = scenes.random_mesh_scene(64, 16, 16)
 one_more.P = np.zeros((3, 3), np.float32)
 one_more.idx = np.zeros(((1 << 24) + 1, 3), np.uint32)
@@ -51,5 +56,5 @@ try:
     refused = False
 except _lib.PbrtHipError as e:
     refused = e.code == -4 and "2^24" in str(e)
-print("2^24 + 1 triangles refused (PBRT_HIP_ERR_LIMIT):", refused)
+print("2^24 + 1 triangles refused (PBRT_HIP_ERR_LIMIT):", refused, f"({time.time() - t:.1f} s)")
 sys.exit(0 if ok and ok_hit and ok_occ and refused else 1)
