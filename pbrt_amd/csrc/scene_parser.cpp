@@ -1021,6 +1021,8 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     if (!textured) { out->tri_uv.clear(); out->tri_uv.shrink_to_fit(); }
   }
   if (!api.camera_set) mat_identity(out->cam_to_world);
+  if (out->spheres.size() > 256)  // (C0 / C1 have one sphere; the accelerator holds triangles only)
+    api.warn(std::to_string(out->spheres.size()) + " spheres: spheres are not in the BVH, every ray tests each of them (meshes scale, spheres do not)");
   return fin(true);
 }
 
