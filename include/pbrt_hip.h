@@ -259,7 +259,8 @@ int pbrt_hip_render_multi(const pbrt_hip_scene_desc *desc, const pbrt_hip_render
                           pbrt_hip_stats *per_gpu);
 
 /* Ray-batch entry points: the traversal kernels on their own (parity + roofline of the
- * dominant loop).  Host SoA-of-xyz arrays, n rays.  prim = 0xffffffff on a miss. */
+ * dominant loop).  Host SoA-of-xyz arrays, n rays.  prim = 0xffffffff on a miss.  A ray whose origin or direction has a component
+ * that is not finite, or whose tmax is NaN, is a miss (and is not walked); direction components that are exactly 0 are fine. */
 int pbrt_hip_intersect(pbrt_hip_scene *scene, int64_t n, const float *o, const float *d, const float *tmax, float *t,
                        uint32_t *prim, float *b1, float *b2, uint64_t *counters /* 2, may be NULL */);
 int pbrt_hip_occluded(pbrt_hip_scene *scene, int64_t n, const float *o, const float *d, const float *tmax,

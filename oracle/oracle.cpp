@@ -788,12 +788,24 @@ void orc_bvh_export(const orc_scene *s, uint32_t *nodes, uint32_t *order) {
 }
 uint32_t orc_light_count(const orc_scene *s) { return (uint32_t)s->s.lights.size(); }
 
+// A probe ray (pbrt_hip_intersect / pbrt_hip_occluded) with a non-finite origin or direction, or a NaN tmax, hits nothing -- which is what
+// the arithmetic makes of it anyway (every test against a NaN fails) -- and is not walked at all: with NaN slabs nothing prunes, and a
+// batch of such rays would keep a GPU busy for seconds per ray on a large scene.  (The renderer's own rays are finite.)
+static bool probe_ray_is_sane(const float *o, const float *d, float tmax) {
+  return std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2]) && std::isfinite(d[0]) && std::isfinite(d[1]) && std::isfinite(d[2]) &&
+         !std::isnan(tmax);
+}
 void orc_intersect(const orc_scene *sc, int64_t n, const float *o, const float *d, const float *tmax, float *t,
                    uint32_t *prim, float *b1, float *b2, uint64_t *counters, int brute_force) {
   const Scene &s = sc->s;
   Counters c;
   for (int64_t i = 0; i < n; i++) {
     Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]};
+    if (!probe_ray_is_sane(o + 3 * i, d + 3 * i, tmax[i])) {
+      const Hit miss;
+      t[i] = miss.t; prim[i] = miss.prim; b1[i] = miss.b1; b2[i] = miss.b2;
+      continue;
+    }
     Hit h = brute_force ? s.IntersectBrute(r) : s.Intersect(r, &c);
     t[i] = h.t; prim[i] = h.prim; b1[i] = h.b1; b2[i] = h.b2;
   }
@@ -804,6 +816,7 @@ void orc_occluded(const orc_scene *sc, int64_t n, const float *o, const float *d
   const Scene &s = sc->s;
   for (int64_t i = 0; i < n; i++) {
     Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmax[i]};
+    if (!probe_ray_is_sane(o + 3 * i, d + 3 * i, tmax[i])) { hit[i] = 0; continue; }
     hit[i] = (brute_force ? s.IntersectPBrute(r) : s.IntersectP(r, nullptr)) ? 1 : 0;
   }
 }

@@ -973,8 +973,21 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
       if (next < B.n) {
         idx = next;
         next += stride;
-        trav_begin<COUNT>(S, T, stk, mk(B.o[3 * idx], B.o[3 * idx + 1], B.o[3 * idx + 2]),
-                          mk(B.d[3 * idx], B.d[3 * idx + 1], B.d[3 * idx + 2]), B.tmax[idx], any_hit != 0, cn);
+        const V3 ro = mk(B.o[3 * idx], B.o[3 * idx + 1], B.o[3 * idx + 2]), rd = mk(B.d[3 * idx], B.d[3 * idx + 1], B.d[3 * idx + 2]);
+        const float rt = B.tmax[idx];
+        // a probe ray with a non-finite origin / direction or a NaN tmax hits nothing and is not walked (with NaN slabs nothing prunes: such
+        // a ray would visit every node of the tree; oracle.cpp probe_ray_is_sane is the same rule) -- the renderer's own rays are finite
+        const bool sane = fabsf(ro.x) < kInf && fabsf(ro.y) < kInf && fabsf(ro.z) < kInf && fabsf(rd.x) < kInf && fabsf(rd.y) < kInf && fabsf(rd.z) < kInf && rt == rt;
+        if (sane) {
+          trav_begin<COUNT>(S, T, stk, ro, rd, rt, any_hit != 0, cn);
+        } else {  // the miss is written when the loop comes round
+          T.o = mk(0.f, 0.f, 0.f);
+          T.d = mk(0.f, 0.f, 1.f);
+          T.tmax = 0.f;
+          T.any = 0;
+          T.h = HitRec{kInf, kNoPrim, kNoPrim, 0.f, 0.f};
+          T.cur = kDone;
+        }
         have = true;
       }
     }

@@ -83,6 +83,18 @@ def test_intersect_edge_cases(gpu, oracle):
         assert_bit_equal(got[0], ref[0], "t ragged")
         tz = np.zeros(len(o), np.float32)  # tmax = 0: nothing can be hit
         assert (sc.intersect(o, d, tz)[1] == 0xFFFFFFFF).all() and (sc.occluded(o, d, tz) == 0).all()
+        # probe rays that are not numbers: a NaN / infinite origin or direction component, a NaN tmax -- misses on both sides, with the
+        # canonical counters (such a ray is not walked: with NaN slabs it would visit the whole tree), the sane rays around them unchanged
+        ob, db, tb = o.copy(), d.copy(), tmax.copy()
+        ob[3, 1] = np.nan; ob[7, 0] = np.inf; db[11, 2] = np.nan; db[13, 0] = -np.inf; tb[17] = np.nan; db[19] = (np.nan, np.nan, np.nan)
+        bad = [3, 7, 11, 13, 17, 19]
+        gotb, refb = sc.intersect(ob, db, tb, counters=True), oracle.OracleScene(sd).intersect(ob, db, tb)
+        for a, b, what in zip(gotb[:4], refb[:4], ("t", "prim", "b1", "b2")):
+            assert_bit_equal(a, b, f"batch with non-finite rays: {what}")
+        assert (gotb[1][bad] == 0xFFFFFFFF).all() and np.isinf(gotb[0][bad]).all() and gotb[4] == refb[4]
+        keep = np.setdiff1d(np.arange(len(o)), bad)
+        assert_bit_equal(gotb[0][keep], got[0][keep], "the sane rays of that batch")
+        assert np.array_equal(sc.occluded(ob, db, tb) != 0, oracle.OracleScene(sd).occluded(ob, db, tb) != 0) and (sc.occluded(ob, db, tb)[bad] == 0).all()
     # a scene with no geometry at all
     sd = SceneData(xres=16, yres=16, lights=np.array([[LIGHT_INFINITE, 0, 0, 0, 0.25, 0.5, 1.0]], np.float32))
     with gpu.Scene(sd) as sc:
