@@ -732,6 +732,17 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       if (!std::isfinite(sp.c[0]) || !std::isfinite(sp.c[1]) || !std::isfinite(sp.c[2]) || !std::isfinite(sp.r) || !(sp.r > 0.f))
         return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere centre / radius must be finite and the radius positive");
     }
+    // (a NaN in a light's position or in a colour travels into ray directions and throughputs: a ray that is not a number is pruned by
+    // nothing and walks the whole tree -- minutes per frame on a large scene -- before its sample is dropped as NaN)
+    if (d->n_lights && !d->lights) return fail(PBRT_HIP_ERR_INVALID, "scene_create: n_lights > 0 but no light table");
+    for (uint32_t i = 0; i < d->n_lights; i++)
+      for (int k = 0; k < 3; k++)
+        if (!std::isfinite(d->lights[i].p[k]) || !std::isfinite(d->lights[i].c[k]))
+          return fail(PBRT_HIP_ERR_INVALID, "scene_create: light " + std::to_string(i) + ": position / direction / colour is not finite");
+    for (uint32_t i = 0; i < d->n_mats; i++)
+      for (int k = 0; k < 3; k++)
+        if (!std::isfinite(d->mats[i].k[k]) || !std::isfinite(d->mats[i].le[k]))
+          return fail(PBRT_HIP_ERR_INVALID, "scene_create: material " + std::to_string(i) + ": colour / emission is not finite");
     for (int k = 0; k < 16; k++)
       if (!std::isfinite(d->cam_to_world[k])) return fail(PBRT_HIP_ERR_INVALID, "scene_create: camera matrix is not finite");
     if (!(d->fov > 0.f && d->fov < 180.f)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: fov must lie in (0, 180) degrees");
@@ -749,6 +760,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       if (tx.type != 0u) return fail(PBRT_HIP_ERR_INVALID, "scene_create: unknown texture type");
       if (!std::isfinite(tx.su) || !std::isfinite(tx.sv) || !std::isfinite(tx.du) || !std::isfinite(tx.dv))
         return fail(PBRT_HIP_ERR_INVALID, "scene_create: texture mapping is not finite");
+      for (int k = 0; k < 3; k++)
+        if (!std::isfinite(tx.tex1[k]) || !std::isfinite(tx.tex2[k])) return fail(PBRT_HIP_ERR_INVALID, "scene_create: texture colour is not finite");
     }
     for (uint32_t t = 0; t < d->n_tris && !textured; t++) textured = d->mats[d->mat_id[t]].kd_tex != 0u && d->mats[d->mat_id[t]].type == 0u;
     for (uint32_t i = 0; i < d->n_spheres && !textured_sph; i++) textured_sph = d->mats[d->spheres[i].mat].kd_tex != 0u && d->mats[d->spheres[i].mat].type == 0u;

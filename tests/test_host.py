@@ -199,6 +199,16 @@ def test_bad_arguments_are_rejected_before_any_device_work():
         pbrt_amd.Scene(sd)
     with pytest.raises(ValueError):
         pbrt_amd.slab_pixel_index(64, 64, (0, 1, 0, 1), 2, 2)
+    # lights and colours that are not numbers (they would become ray directions / throughputs that nothing prunes)
+    for field, row, col, what in (("lights", 0, 2, "light 0"), ("lights", 0, 5, "light 0"), ("materials", 1, 2, "material 1"), ("materials", 0, 5, "material 0")):
+        for bad in (np.nan, np.inf):
+            sd = scenes.check_sphere_scene(8, 8)
+            arr = getattr(sd, field).copy()
+            arr[row, col] = bad
+            setattr(sd, field, arr)
+            with pytest.raises(_lib.PbrtHipError) as e:
+                pbrt_amd.Scene(sd)
+            assert e.value.code == -1 and what in str(e.value) and "not finite" in str(e.value), (field, row, col, str(e.value))
     # textured materials: a texture number beyond the table, a textured triangle without corner (u, v), non-finite (u, v)
     # or mapping, an unknown texture type
     from util import checker_plane_scene
@@ -206,6 +216,7 @@ def test_bad_arguments_are_rejected_before_any_device_work():
                           (lambda sd: setattr(sd, "tri_uv", np.zeros((0, 6), np.float32)), "tri_uv is NULL"),
                           (lambda sd: sd.tri_uv.__setitem__((1, 3), np.inf), "tri_uv is not finite"),
                           (lambda sd: sd.textures.__setitem__((0, 7), np.nan), "mapping is not finite"),
+                          (lambda sd: sd.textures.__setitem__((0, 2), np.inf), "texture colour is not finite"),
                           (lambda sd: sd.textures.__setitem__((0, 0), 5), "unknown texture type")):
         sd, _ = checker_plane_scene(8)
         breakit(sd)
