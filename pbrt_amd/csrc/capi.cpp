@@ -746,6 +746,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     for (int k = 0; k < 16; k++)
       if (!std::isfinite(d->cam_to_world[k])) return fail(PBRT_HIP_ERR_INVALID, "scene_create: camera matrix is not finite");
     if (!(d->fov > 0.f && d->fov < 180.f)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: fov must lie in (0, 180) degrees");
+    for (int k = 0; k < 4; k++)  // Film "cropwindow": fractions of the film (film.rs:92-101 multiplies and rounds them up: a NaN or 1e30 there is an int overflow)
+      if (!(d->crop[k] >= 0.f && d->crop[k] <= 1.f)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: crop window values must lie in [0, 1]");
     for (uint32_t s = 0; s < d->n_spheres; s++)
       if (d->spheres[s].mat >= d->n_mats) return fail(PBRT_HIP_ERR_INVALID, "scene_create: sphere material id out of range");
     bool textured = false;      // a triangle whose material's Kd is a texture: its corner (u, v) must be there

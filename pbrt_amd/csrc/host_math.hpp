@@ -79,11 +79,18 @@ inline void look_at(const float pos[3], const float look[3], const float up[3], 
 }
 
 // Film::new, core/film.rs:92-101: cropped_pixel_bounds = ceil(resolution * crop)
+inline int32_t ceil_to_i32(float v) {  // ceil, saturated; NaN -> 0 (the cast of a float outside int32 is undefined behaviour)
+  if (!(v == v)) return 0;
+  v = std::ceil(v);
+  if (v >= 2147483648.f) return 2147483647;
+  if (v <= -2147483648.f) return -2147483647 - 1;
+  return (int32_t)v;
+}
 inline void film_cropped_bounds(int xres, int yres, const float crop[4], int32_t b[4]) {
-  b[0] = (int32_t)std::ceil((float)xres * crop[0]);
-  b[1] = (int32_t)std::ceil((float)yres * crop[2]);
-  b[2] = (int32_t)std::ceil((float)xres * crop[1]);
-  b[3] = (int32_t)std::ceil((float)yres * crop[3]);
+  b[0] = ceil_to_i32((float)xres * crop[0]);
+  b[1] = ceil_to_i32((float)yres * crop[2]);
+  b[2] = ceil_to_i32((float)xres * crop[1]);
+  b[3] = ceil_to_i32((float)yres * crop[3]);
 }
 
 // core/spectrum.rs:129-145

@@ -199,6 +199,12 @@ def test_bad_arguments_are_rejected_before_any_device_work():
         pbrt_amd.Scene(sd)
     with pytest.raises(ValueError):
         pbrt_amd.slab_pixel_index(64, 64, (0, 1, 0, 1), 2, 2)
+    for crop in ((0.0, np.nan, 0.0, 1.0), (0.0, 1.0, -0.1, 1.0), (0.0, 1e30, 0.0, 1.0)):
+        sd = scenes.cornell_scene(8, 8)
+        sd.crop = crop
+        with pytest.raises(_lib.PbrtHipError) as e:
+            pbrt_amd.Scene(sd)
+        assert e.value.code == -1 and "crop window" in str(e.value)
     # lights and colours that are not numbers (they would become ray directions / throughputs that nothing prunes)
     for field, row, col, what in (("lights", 0, 2, "light 0"), ("lights", 0, 5, "light 0"), ("materials", 1, 2, "material 1"), ("materials", 0, 5, "material 0")):
         for bad in (np.nan, np.inf):
