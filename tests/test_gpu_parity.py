@@ -1253,6 +1253,9 @@ def _random_scene(seed):
             lights.append([kind, 0, 0, 0, *rng.uniform(0.1, 1.0, 3)])
         elif kind == 1:
             d = rng.normal(size=3); d /= np.linalg.norm(d)
+            if seed % 6 == 5:  # a sun exactly along an axis: every shadow ray towards it is parallel to two slabs
+                k = int(np.argmax(np.abs(d)))
+                d = np.where(np.arange(3) == k, np.sign(d[k]), 0.0)
             lights.append([kind, *d, *rng.uniform(0.5, 3.0, 3)])
         else:
             lights.append([kind, *rng.uniform(-3, 3, 3), *rng.uniform(2.0, 30.0, 3)])
