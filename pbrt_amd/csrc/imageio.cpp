@@ -237,22 +237,29 @@ void zlib_deflate(const std::vector<uint8_t> &raw, std::vector<uint8_t> *z) {
   z->push_back(0x78); z->push_back(0x9c);
   BitWriter bw(*z);
   const size_t n = raw.size();
-  constexpr uint32_t kHashBits = 15, kWindow = 32768, kMaxChain = 64, kNil = 0xffffffffu;
+  constexpr uint32_t kHashBits = 15, kWindow = 32768, kMaxChain = 64;
+  constexpr uint64_t kNil = ~0ull;
   constexpr size_t kBlockTokens = 1u << 16;
-  std::vector<uint32_t> head(1u << kHashBits, kNil), prev(n ? n : 1, kNil);
+  // hash chains over the last kWindow positions only (a ring: 32 K entries whatever the image's size; positions are 64-bit, a film of
+  // 32 768^2 pixels is 3.2 GB of scanlines)
+  std::vector<uint64_t> head(1u << kHashBits, kNil), prev(kWindow, kNil);
   auto hash3 = [&](size_t i) { return (((uint32_t)raw[i] | (uint32_t)raw[i + 1] << 8 | (uint32_t)raw[i + 2] << 16) * 0x9e3779b1u) >> (32 - kHashBits); };
-  auto enter = [&](size_t i) { if (i + 3 <= n) { const uint32_t hsh = hash3(i); prev[i] = head[hsh]; head[hsh] = (uint32_t)i; } };
+  auto enter = [&](size_t i) { if (i + 3 <= n) { const uint32_t hsh = hash3(i); prev[i & (kWindow - 1)] = head[hsh]; head[hsh] = i; } };
   auto longest = [&](size_t i, uint32_t *dist) -> uint32_t {  // the longest earlier occurrence of raw[i ...] inside the window (0 if under 3 bytes)
     if (i + 3 > n) return 0;
     const size_t max_len = n - i < 258 ? n - i : 258;
-    uint32_t best = 0, cand = head[hash3(i)], chain = 0;
-    while (cand != kNil && i - cand <= kWindow && chain++ < kMaxChain) {
+    uint32_t best = 0, chain = 0;
+    uint64_t cand = head[hash3(i)];
+    // (a position's ring slot is its own while it is less than kWindow back: older candidates end the chain)
+    while (cand != kNil && i - cand < kWindow && chain++ < kMaxChain) {
       if (raw[cand + best] == raw[i + best]) {
         size_t l = 0;
         while (l < max_len && raw[cand + l] == raw[i + l]) l++;
         if (l > best) { best = (uint32_t)l; *dist = (uint32_t)(i - cand); if (l == max_len) break; }
       }
-      cand = prev[cand];
+      const uint64_t older = prev[cand & (kWindow - 1)];
+      if (older != kNil && older >= cand) break;  // (the slot was taken over by a later position: not this chain any more)
+      cand = older;
     }
     return best >= 3 ? best : 0;
   };
