@@ -324,7 +324,13 @@ bool write_png(const char *name, const float *rgb, int w, int h) {
   be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h);
   ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
   chunk(out, "IHDR", ihdr);
-  chunk(out, "IDAT", z);
+  // (a chunk's length field is 31 bits: a film whose compressed scanlines pass 1 GiB goes out as several IDAT chunks, which a decoder
+  // reads as one stream)
+  for (size_t at = 0; at < z.size() || at == 0; at += (size_t)1 << 30) {
+    const size_t k = std::min(z.size() - at, (size_t)1 << 30);
+    chunk(out, "IDAT", std::vector<uint8_t>(z.begin() + (ptrdiff_t)at, z.begin() + (ptrdiff_t)(at + k)));
+    if (z.empty()) break;
+  }
   chunk(out, "IEND", {});
   FILE *f = std::fopen(name, "wb");
   if (!f) return false;
