@@ -37,7 +37,7 @@ def main(argv=None):
             log(1, f"{path}: {e}")
             return 1
         for w in ls.warnings:
-            log(3, f"warning: {w}")
+            log(1, f"warning: {w}")  # WARN passes every level (pbrt.rs:51-53: quiet is "only WARN and higher")
         kw = ls.render_kwargs()
         if args.quick:
             kw["spp"] = (max(1, kw["spp"][0] // 2), max(1, kw["spp"][1] // 2))

@@ -1,7 +1,7 @@
 // pbrt_main.cpp -- the command line of the render path, the C++ counterpart of the reference binary
 // /root/reference/src/bin/pbrt.rs:24-85: same flags (-n/--nthreads, --quick, -q/--quiet, -v/--verbose,
-// -o/--outfile, positional scene files), same three log levels (quiet = errors, default = + info,
-// verbose = + warnings/debug; pbrt.rs:48-62).  Where the reference parses and pretty-prints its state
+// -o/--outfile, positional scene files), same three log levels (stderrlog verbosity 1 / 2 / 3, pbrt.rs:48-62: quiet = errors and
+// WARNINGS, default = + info, verbose = + debug).  Where the reference parses and pretty-prints its state
 // (pbrt.rs:72-83, WorldEnd renders nothing), this parses, renders on the GPU through the C ABI and
 // writes the image named by Film "string filename" (or -o).
 #include <algorithm>
@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
     if (pbrt_hip_load_file(path.c_str(), &loaded) != 0) { logf(1, "%s: %s", path.c_str(), pbrt_hip_last_error()); return 1; }
     std::vector<char> wbuf(1 << 16);
     if (pbrt_hip_loaded_warnings(loaded, wbuf.data(), wbuf.size()) > 0)
-      for (char *w = std::strtok(wbuf.data(), "\n"); w; w = std::strtok(nullptr, "\n")) logf(3, "warning: %s", w);
+      for (char *w = std::strtok(wbuf.data(), "\n"); w; w = std::strtok(nullptr, "\n")) logf(1, "warning: %s", w);  // WARN passes every level (pbrt.rs:51-53: quiet is "only WARN and higher")
     pbrt_hip_scene_desc desc;
     pbrt_hip_render_desc rd;
     char filename[4096];

@@ -2,6 +2,7 @@
 compute calls): symbols, error behaviour, the BVH builder, the sharding geometry, the inputs."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -353,6 +354,20 @@ def test_native_cli_usage():
     assert r.returncode == 0 and "--outfile" in r.stderr and "--nthreads" in r.stderr and "--quick" in r.stderr
     assert subprocess.run([CLI_PATH], capture_output=True).returncode == 1  # no scene files
     assert subprocess.run([CLI_PATH, "--bogus"], capture_output=True).returncode == 2
+
+
+def test_cli_log_levels_are_the_reference_binarys(tmp_path):
+    """bin/pbrt.rs:48-62: stderrlog verbosity 1 (quiet: "only WARN and higher"), 2 (default: + INFO), 3 (verbose: + DEBUG) -- a parser
+    warning passes every level, the info line only the default and the verbose one.  (No GPU here: the run ends at the render call.)"""
+    import subprocess
+    from pbrt_amd.build import CLI_PATH
+    scene = tmp_path / "s.pbrt"
+    scene.write_text('Camera "perspective" "float lensradius" 0.5\nWorldBegin Shape "sphere" WorldEnd\n')
+    for flags, info in (([], True), (["-q"], False), (["-v"], True)):
+        for cmd in ([CLI_PATH], [sys.executable, "-m", "pbrt_amd.cli"]):
+            r = subprocess.run(cmd + flags + [str(scene)], capture_output=True, text=True, cwd=ROOT)
+            assert "warning: Camera: \"lensradius\" ignored" in r.stderr, (cmd, flags, r.stderr)
+            assert ("1 spheres" in r.stderr) == info, (cmd, flags, r.stderr)
 
 
 def _check_quads(quads, need, P, idx, order):
