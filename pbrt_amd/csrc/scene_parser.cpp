@@ -280,6 +280,11 @@ struct Api {
     mat_identity(out->cam_to_world);
   }
   void warn(const std::string &s) { out->warnings.push_back(s); }
+  // api.rs:897-901 warn_if_animated_transform: the two CTMs differ (ActiveTransform StartTime / EndTime); the start transform is used
+  void warn_if_animated_transform(const char *what) {
+    if (std::memcmp(ctm[0].m, ctm[1].m, 64) != 0)
+      warn(std::string("Animated transformations set; ignoring for \"") + what + "\" and using the start transform only");
+  }
   void report_unused(const char *what, const ParamSet &ps) {
     for (const std::string &u : ps.unused()) warn(std::string(what) + ": parameter \"" + u + "\" not used");
   }
@@ -319,7 +324,7 @@ struct Api {
       if (p->strs.size() == 1) {
         auto it = spectrum_textures.find(p->strs[0]);
         if (it != spectrum_textures.end()) { for (int i = 0; i < 3; i++) rgb[i] = it->second[i]; return true; }
-        warn("texture \"" + p->strs[0] + "\" is not defined");
+        warn("Spectrum texture '" + p->strs[0] + "' is unknown");  // api.rs:939
       }
     }
     return false;
@@ -434,6 +439,7 @@ struct Api {
   }
 
   void shape(const std::string &name, const ParamSet &ps) {
+    warn_if_animated_transform("pbrt.shape");
     const float zero[3] = {0, 0, 0};
     if (in_object && gs.has_area_light && !warned_object_light) {
       warned_object_light = true;
@@ -557,6 +563,7 @@ struct Api {
   }
 
   void light_source(const std::string &name, const ParamSet &ps) {  // replaces make_light's todo!()s, api.rs:334-351
+    warn_if_animated_transform("pbrt.light_source");  // api.rs:687
     float scale[3] = {1, 1, 1};
     spectrum(ps, "scale", scale);
     pbrt_hip_light l{};
@@ -586,7 +593,7 @@ struct Api {
       l.type = 2;
       for (int i = 0; i < 3; i++) l.c[i] = L[i] * scale[i];
     } else {
-      warn("LightSource \"" + name + "\" is not supported by this path: skipped");
+      warn("light_source: light type '" + name + "' unknown.");  // api.rs:692 (spot, goniometric, projection: not on this path either)
       return;
     }
     out->lights.push_back(l);
@@ -741,14 +748,23 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     if (!ok && msg) *msg = p.msg;
     return ok ? ParseError::None : (p.err == ParseError::None ? ParseError::Syntax : p.err);
   };
-  auto in_world = [&](const char *what) {  // verify_world!, api.rs:313-332: log and ignore
+  // the reference's name for a directive's API call: "AttributeBegin" -> "pbrt.attribute_begin" (api.rs:421-814)
+  auto api_name = [](const char *directive) {
+    std::string r = "pbrt.";
+    for (const char *c = directive; *c; c++) {
+      if (*c >= 'A' && *c <= 'Z') { if (c != directive) r += '_'; r += (char)(*c - 'A' + 'a'); }
+      else r += *c;
+    }
+    return r;
+  };
+  auto in_world = [&](const char *what) {  // verify_world!, api.rs:320-332: log (its wording) and ignore
     if (api.state == ApiState::WorldBlock) return true;
-    api.warn(std::string(what) + " is only valid inside the world block: ignored");
+    api.warn("Scene description must be inside world block; \"" + api_name(what) + "\" not allowed. Ignoring.");
     return false;
   };
-  auto in_options = [&](const char *what) {  // verify_options!, api.rs:302-312
+  auto in_options = [&](const char *what) {  // verify_options!, api.rs:304-316
     if (api.state == ApiState::OptionsBlock) return true;
-    api.warn(std::string(what) + " is only valid in the options block: ignored");
+    api.warn("Options cannot be set inside world block; \"" + api_name(what) + "\" not allowed. Ignoring.");
     return false;
   };
   std::string tok;
@@ -789,7 +805,7 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     } else if (tok == "AttributeEnd") {
       if (in_world("AttributeEnd")) {
         if (api.pushed_gs.empty() || api.pushed_ctm.empty()) {
-          api.warn("Unmatched AttributeEnd encountered. Ignoring it.");  // api.rs:497-500
+          api.warn("Unmatched pbrt.attribute_end() encountered. Ignoring it.");  // api.rs:497
         } else {
           api.gs = api.pushed_gs.back(); api.pushed_gs.pop_back();
           api.ctm[0] = api.pushed_ctm.back().first; api.ctm[1] = api.pushed_ctm.back().second; api.pushed_ctm.pop_back();
@@ -834,7 +850,7 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     } else if (tok == "CoordSysTransform") {
       if (!p.quoted(&name)) return fin(false);
       auto it = api.named_cs.find(name);
-      if (it == api.named_cs.end()) api.warn("Couldn't find named coordinate system \"" + name + "\"");  // api.rs:727-730
+      if (it == api.named_cs.end()) api.warn("Couldn\xe2\x80\x99t find named coordinate system \"" + name + "\"");  // api.rs:745 (its apostrophe is U+2019)
       else { api.ctm[0] = it->second.first; api.ctm[1] = it->second.second; }
     } else if (tok == "Film") {
       if (!p.named_params(&name, &ps, api)) return fin(false);
@@ -962,7 +978,7 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
       if (in_world("TransformBegin")) { api.pushed_ctm.emplace_back(api.ctm[0], api.ctm[1]); api.pushed_bits.push_back(api.active_bits); }  // api.rs:504-509
     } else if (tok == "TransformEnd") {
       if (in_world("TransformEnd")) {
-        if (api.pushed_ctm.empty()) api.warn("Unmatched TransformEnd encountered. Ignoring it.");
+        if (api.pushed_ctm.empty()) api.warn("Unmatched pbrt.transform_end() encountered. Ignoring it.");  // api.rs:517
         else {
           api.ctm[0] = api.pushed_ctm.back().first; api.ctm[1] = api.pushed_ctm.back().second; api.pushed_ctm.pop_back();
           api.active_bits = api.pushed_bits.back(); api.pushed_bits.pop_back();

@@ -61,7 +61,8 @@ def test_named_coordinate_systems():  # api.rs:979-1020
     ls = loader.load_string('Identity Scale 2 2 2 CoordinateSystem "two" Identity Scale 3 3 3 CoordSysTransform "two"')
     assert np.array_equal(ls.ctm, np.diag([2, 2, 2, 1]).astype(np.float32))
     ls = loader.load_string('Scale 2 2 2 CoordSysTransform "nope"')  # api.rs:727-730: warn, keep the CTM
-    assert np.array_equal(ls.ctm, np.diag([2, 2, 2, 1]).astype(np.float32)) and any("nope" in w for w in ls.warnings)
+    assert np.array_equal(ls.ctm, np.diag([2, 2, 2, 1]).astype(np.float32))
+    assert "Couldn\u2019t find named coordinate system \"nope\"" in ls.warnings  # api.rs:745, its typographic apostrophe included
 
 
 def test_attribute_and_transform_stacks():  # api.rs:1022-1045 + :481-522
@@ -70,11 +71,15 @@ def test_attribute_and_transform_stacks():  # api.rs:1022-1045 + :481-522
     ls = loader.load_string("WorldBegin TransformBegin Translate 1 2 3 TransformEnd Translate 0 0 5")
     assert np.array_equal(ls.ctm[:3, 3], np.array([0, 0, 5], np.float32))
     ls = loader.load_string("WorldBegin AttributeEnd TransformEnd")  # unmatched: logged and ignored (api.rs:497-500)
-    assert sum("Unmatched" in w for w in ls.warnings) == 2
-    ls = loader.load_string("AttributeBegin")  # verify_world!: outside the world block -> ignored
-    assert any("world block" in w for w in ls.warnings)
-    ls = loader.load_string('WorldBegin Camera "perspective"')  # verify_options!
-    assert any("options block" in w for w in ls.warnings)
+    assert [w for w in ls.warnings if "Unmatched" in w] == ["Unmatched pbrt.attribute_end() encountered. Ignoring it.",  # api.rs:497
+                                                             "Unmatched pbrt.transform_end() encountered. Ignoring it."]  # api.rs:517
+    ls = loader.load_string("AttributeBegin")  # verify_world! (api.rs:320-332): outside the world block -> its message, ignored
+    assert 'Scene description must be inside world block; "pbrt.attribute_begin" not allowed. Ignoring.' in ls.warnings
+    ls = loader.load_string('WorldBegin Camera "perspective"')  # verify_options! (api.rs:304-316)
+    assert 'Options cannot be set inside world block; "pbrt.camera" not allowed. Ignoring.' in ls.warnings
+    ls = loader.load_string('LightSource "point" WorldBegin PixelFilter "box"')
+    assert [w for w in ls.warnings if "Ignoring" in w] == ['Scene description must be inside world block; "pbrt.light_source" not allowed. Ignoring.',
+                                                            'Options cannot be set inside world block; "pbrt.pixel_filter" not allowed. Ignoring.']
 
 
 def test_ctm_ops_match_the_transform_doctests():  # transform.rs:360-443,524-538 through the directives
@@ -386,3 +391,14 @@ def test_integrator_parameters_without_effect_are_reported():
     assert any('"strategy" "all"' in w for w in ls.warnings)
     ls = loader.load_string('Integrator "path" "float rrthreshold" 1 "string lightsamplestrategy" "uniform" "integer maxdepth" 7')
     assert not ls.warnings and ls.max_depth == 7
+
+
+def test_log_messages_are_the_references_where_it_has_them():
+    """api.rs:692 (unknown light), :939 (unknown spectrum texture), :897-901 (animated transforms: the start transform is used)."""
+    ls = loader.load_string('WorldBegin LightSource "laser" Material "matte" "texture Kd" "nothing" '
+                            'ActiveTransform EndTime Translate 1 0 0 ActiveTransform All Shape "sphere" LightSource "point" WorldEnd')
+    assert "light_source: light type 'laser' unknown." in ls.warnings
+    assert "Spectrum texture 'nothing' is unknown" in ls.warnings
+    assert 'Animated transformations set; ignoring for "pbrt.shape" and using the start transform only' in ls.warnings
+    assert 'Animated transformations set; ignoring for "pbrt.light_source" and using the start transform only' in ls.warnings
+    assert ls.scene.spheres[0, :3].tolist() == [0, 0, 0] and ls.scene.lights[0, 1:4].tolist() == [0, 0, 0]  # the start transform
