@@ -1605,6 +1605,20 @@ const char *parse_error_name(pbrt_hip::ParseError e) {
     default: return "None";
   }
 }
+// "<kind>: <the reference's Display text for that kind, parser.rs:31-58>[: detail]"
+std::string parse_error_text(pbrt_hip::ParseError e, const std::string &msg) {
+  const std::string kind = parse_error_name(e);
+  switch (e) {
+    case pbrt_hip::ParseError::Eof: return kind + ": premature EOF" + (msg.empty() ? "" : " (" + msg + ")");
+    case pbrt_hip::ParseError::UnterminatedString: return kind + ": unterminated string";
+    case pbrt_hip::ParseError::MixedParameters: return kind + ": mixed string and numeric parameters";
+    case pbrt_hip::ParseError::Unquoted: return kind + ": expected quoted string" + (msg.empty() ? "" : " (" + msg + ")");
+    case pbrt_hip::ParseError::Syntax:
+      return kind + (msg.rfind("input not float", 0) == 0 ? ": " + msg : ": syntax error: '" + msg + "'");
+    case pbrt_hip::ParseError::NotImplemented: return kind + ": have not yet implemented '" + msg + "'";
+    default: return kind + ": " + msg;
+  }
+}
 size_t copy_out(const std::string &s, char *buf, size_t cap) {
   if (buf && cap) {
     size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
@@ -1624,7 +1638,7 @@ int pbrt_hip_load_string(const char *text, size_t len, const char *base_dir, pbr
     std::unique_ptr<pbrt_hip_loaded> l(new pbrt_hip_loaded());
     std::string msg;
     pbrt_hip::ParseError e = pbrt_hip::parse_scene(text, len, base_dir ? base_dir : "", &l->s, &msg);
-    if (e != pbrt_hip::ParseError::None) return fail(PBRT_HIP_ERR_INVALID, std::string(parse_error_name(e)) + ": " + msg);
+    if (e != pbrt_hip::ParseError::None) return fail(PBRT_HIP_ERR_INVALID, parse_error_text(e, msg));
     *out = l.release();
     return PBRT_HIP_OK;
   } catch (const std::exception &e) {

@@ -626,7 +626,7 @@ struct Parser {
     if (have_unget) { have_unget = false; *tok = unget; return true; }
     for (;;) {
       if (files.empty()) {
-        if (required) fail(ParseError::Eof, "premature end of file");
+        if (required) fail(ParseError::Eof, "");
         return false;
       }
       ParseError e;
@@ -642,7 +642,7 @@ struct Parser {
     if (!next(&t, true)) return false;
     char *end = nullptr;
     const double v = std::strtod(t.c_str(), &end);
-    if (end == t.c_str() || *end) return fail(ParseError::Syntax, "expected a number, got '" + t + "'");
+    if (end == t.c_str() || *end) return fail(ParseError::Syntax, "input not float: '" + t + "'");  // parser.rs:37-38 NumberErr
     *out = (float)v;
     return true;
   }
@@ -653,8 +653,8 @@ struct Parser {
   }
   bool quoted(std::string *out) {
     std::string t;
-    if (!next(&t, true)) { if (err == ParseError::None) fail(ParseError::Unquoted, "expected a quoted string"); return false; }
-    if (!is_quoted(t)) return fail(ParseError::Unquoted, "expected a quoted string, got '" + t + "'");
+    if (!next(&t, true)) { if (err == ParseError::None) fail(ParseError::Unquoted, ""); return false; }
+    if (!is_quoted(t)) return fail(ParseError::Unquoted, "got '" + t + "'");
     *out = dequote(t);
     return true;
   }
@@ -688,7 +688,7 @@ struct Parser {
           if (v == "true" || v == "false") { item.strs.push_back(v); return true; }  // unquoted bools (pbrt-v3 accepts them)
           char *end = nullptr;
           const double x = std::strtod(v.c_str(), &end);
-          if (end == v.c_str() || *end) return fail(ParseError::Syntax, "expected a number, got '" + v + "'");
+          if (end == v.c_str() || *end) return fail(ParseError::Syntax, "input not float: '" + v + "'");
           item.nums.push_back(x);
         }
         return true;

@@ -53,6 +53,13 @@ def test_param_errors():  # parser.rs:31-58 Error kinds
         with pytest.raises(PbrtHipError) as e:
             loader.load_string(text)
         assert e.value.code == -1 and f" {kind}:" in str(e.value), (text, str(e.value))
+    # ... in the reference's own words (the Display strings of parser.rs:31-58)
+    for text, words in [("Bogus 1 2 3", "syntax error: 'Bogus'"), ("LookAt 1 2 x", "input not float"), ("Camera perspective", "expected quoted string"),
+                        ('MakeNamedMedium "a"', "have not yet implemented 'MakeNamedMedium'"), ("LookAt 1 2 3", "premature EOF"),
+                        ('Camera "persp\n', "unterminated string"), ('Camera "perspective" "float fov" [45 "x"]', "mixed string and numeric parameters")]:
+        with pytest.raises(PbrtHipError) as e:
+            loader.load_string(text)
+        assert words in str(e.value), (text, str(e.value))
 
 
 def test_named_coordinate_systems():  # api.rs:979-1020
