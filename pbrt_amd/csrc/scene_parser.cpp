@@ -76,21 +76,23 @@ const ParamItem *ParamSet::find(const char *name, const char *t1, const char *t2
   }
   return nullptr;
 }
+// find_one_*: the FIRST value of the named parameter, the default when there is none (paramset.rs:237-513: `pl.0.first().map_or(default, ..)`
+// -- pbrt-v3 itself wants exactly one value; the reference is the model here)
 float ParamSet::one_float(const char *name, float dflt) const {
   const ParamItem *p = find(name, "float");
-  return (p && p->nums.size() == 1) ? (float)p->nums[0] : dflt;
+  return (p && !p->nums.empty()) ? (float)p->nums[0] : dflt;
 }
 int ParamSet::one_int(const char *name, int dflt) const {
   const ParamItem *p = find(name, "integer");
-  return (p && p->nums.size() == 1) ? (int)p->nums[0] : dflt;
+  return (p && !p->nums.empty()) ? (int)p->nums[0] : dflt;
 }
 bool ParamSet::one_bool(const char *name, bool dflt) const {
   const ParamItem *p = find(name, "bool");
-  return (p && p->strs.size() == 1) ? p->strs[0] == "true" : dflt;
+  return (p && !p->strs.empty()) ? p->strs[0] == "true" : dflt;
 }
 std::string ParamSet::one_string(const char *name, const std::string &dflt) const {
   const ParamItem *p = find(name, "string");
-  return (p && p->strs.size() == 1) ? p->strs[0] : dflt;
+  return (p && !p->strs.empty()) ? p->strs[0] : dflt;
 }
 bool ParamSet::point3(const char *name, float out[3]) const {
   const ParamItem *p = find(name, "point3", "vector3", "normal");

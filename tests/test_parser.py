@@ -409,3 +409,12 @@ def test_log_messages_are_the_references_where_it_has_them():
     assert 'Animated transformations set; ignoring for "pbrt.shape" and using the start transform only' in ls.warnings
     assert 'Animated transformations set; ignoring for "pbrt.light_source" and using the start transform only' in ls.warnings
     assert ls.scene.spheres[0, :3].tolist() == [0, 0, 0] and ls.scene.lights[0, 1:4].tolist() == [0, 0, 0]  # the start transform
+
+
+def test_find_one_returns_the_first_value():
+    """paramset.rs:237-513: find_one_float / _int / _bool / _string return the FIRST value of a parameter (`pl.0.first()`), the default
+    when the parameter is absent or empty -- the reference's rule, not pbrt-v3's "exactly one value"."""
+    ls = loader.load_string('Camera "perspective" "float fov" [45 50]\nFilm "image" "integer xresolution" [320 1] "integer yresolution" [] "string filename" ["a.png" "b.png"]')
+    assert ls.scene.fov == 45.0 and ls.scene.xres == 320 and ls.scene.yres == 720 and ls.filename == "a.png"
+    ls = loader.load_string('Integrator "path" "bool mis" ["true" "false"] "integer maxdepth" [3 9]')
+    assert ls.integrator == 2 and ls.max_depth == 3
