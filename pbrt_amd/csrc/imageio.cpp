@@ -355,7 +355,8 @@ bool write_pfm(const char *name, const float *rgb, int w, int h) {
 // PFM, imageio.rs:87-140: header words "PF"|"Pf", width, height, scale separated by ' ', '\n' or '\t';
 // scale < 0 = little-endian floats, |scale| multiplies; rows bottom to top; 1-channel images are
 // replicated to RGB (RGBSpectrum::new(f), imageio.rs:129-133).
-constexpr uint64_t kMaxImagePixels = 1ull << 28;  // 16384 x 16384: 3 GiB of float RGB; anything larger is refused
+constexpr uint64_t kMaxImagePixels = 1ull << 28;  // READING (untrusted headers): 16384 x 16384, 3 GiB of float RGB; anything larger is refused
+constexpr uint64_t kMaxWritePixels = 1ull << 30;  // WRITING (the caller's own film): 32768 x 32768, the largest film the tests render
 bool read_word(FILE *f, std::string *w) {
   w->clear();
   for (;;) {
@@ -605,9 +606,13 @@ bool read_png(const char *name, std::vector<float> *rgb, int *w, int *h) {
 
 }  // namespace
 
+// The message behind pbrt_hip_last_error(): capi.cpp's when this file is part of the library; the sanitizer harnesses link this file alone.
+namespace pbrt_hip { int fail(int code, const std::string &msg) __attribute__((weak)); }
+static int say(int code, const std::string &msg) { return pbrt_hip::fail ? pbrt_hip::fail(code, msg) : code; }
+
 // imageio::read_image: two calls, the first with rgb == NULL returns the size
 extern "C" int pbrt_hip_read_image(const char *name, float *rgb, int32_t *width, int32_t *height) {
-  if (!name || !width || !height) return PBRT_HIP_ERR_INVALID;
+  if (!name || !width || !height) return say(PBRT_HIP_ERR_INVALID, "read_image: null argument");
   try {
   std::string n(name);
   size_t dot = n.rfind('.');
@@ -618,32 +623,34 @@ extern "C" int pbrt_hip_read_image(const char *name, float *rgb, int32_t *width,
   bool ok;
   if (ext == "png") ok = read_png(name, &px, &w, &h);
   else if (ext == "pfm") ok = read_pfm(name, &px, &w, &h);
-  else return PBRT_HIP_ERR_INVALID;  // imageio.rs:179-182: exr / tga not implemented, unknown extension
-  if (!ok) return PBRT_HIP_ERR_INTERNAL;
+  else if (ext == "exr" || ext == "tga") return say(PBRT_HIP_ERR_INVALID, "read_image: reading ." + ext + " files is not implemented");  // imageio.rs:179-180
+  else return say(PBRT_HIP_ERR_INVALID, "read_image: unknown file extension " + ext);  // imageio.rs:182
+  if (!ok) return say(PBRT_HIP_ERR_INTERNAL, std::string("read_image: cannot read '") + name + "' (missing, truncated or not a valid ." + ext + " file)");
   if (rgb) {
-    if (*width != w || *height != h) return PBRT_HIP_ERR_INVALID;
+    if (*width != w || *height != h) return say(PBRT_HIP_ERR_INVALID, "read_image: the size passed in is not the file's");
     std::memcpy(rgb, px.data(), px.size() * 4);
   }
   *width = w;
   *height = h;
   return PBRT_HIP_OK;
-  } catch (const std::exception &) {  // std::bad_alloc and friends never cross the C ABI
-    return PBRT_HIP_ERR_INTERNAL;
+  } catch (const std::exception &e) {  // std::bad_alloc and friends never cross the C ABI
+    return say(PBRT_HIP_ERR_INTERNAL, std::string("read_image: ") + e.what());
   }
 }
 
 extern "C" int pbrt_hip_write_image(const char *name, const float *rgb, int32_t width, int32_t height) {
-  if (!name || !rgb || width <= 0 || height <= 0) return PBRT_HIP_ERR_INVALID;
-  if ((uint64_t)width * (uint64_t)height > kMaxImagePixels) return PBRT_HIP_ERR_LIMIT;
+  if (!name || !rgb || width <= 0 || height <= 0) return say(PBRT_HIP_ERR_INVALID, "write_image: null argument or empty image");
+  if ((uint64_t)width * (uint64_t)height > kMaxWritePixels) return say(PBRT_HIP_ERR_LIMIT, "write_image: more than 2^30 pixels");
   try {
   std::string n(name);
   size_t dot = n.rfind('.');
   std::string ext = dot == std::string::npos ? "" : n.substr(dot + 1);
   for (auto &c : ext) c = (char)std::tolower((unsigned char)c);
-  if (ext == "png") return write_png(name, rgb, width, height) ? PBRT_HIP_OK : PBRT_HIP_ERR_INTERNAL;
-  if (ext == "pfm") return write_pfm(name, rgb, width, height) ? PBRT_HIP_OK : PBRT_HIP_ERR_INTERNAL;
-  return PBRT_HIP_ERR_INVALID;  // imageio.rs:272-280: exr / tga unimplemented, unknown extension
-  } catch (const std::exception &) {
-    return PBRT_HIP_ERR_INTERNAL;
+  if (ext == "png") return write_png(name, rgb, width, height) ? PBRT_HIP_OK : say(PBRT_HIP_ERR_INTERNAL, std::string("Failed to create file '") + name + "'");  // imageio.rs:248
+  if (ext == "pfm") return write_pfm(name, rgb, width, height) ? PBRT_HIP_OK : say(PBRT_HIP_ERR_INTERNAL, std::string("Failed to write PFM to '") + name + "'");  // imageio.rs:278
+  if (ext == "exr" || ext == "tga") return say(PBRT_HIP_ERR_INVALID, "writing ." + ext + " files is not implemented");  // imageio.rs:272-273
+  return say(PBRT_HIP_ERR_INVALID, "unknown file extension " + ext);  // imageio.rs:281
+  } catch (const std::exception &e) {
+    return say(PBRT_HIP_ERR_INTERNAL, std::string("write_image: ") + e.what());
   }
 }

@@ -175,8 +175,15 @@ def test_png_pfm_roundtrip(tmp_path, oracle):  # imageio.rs:325-390
     assert raw.startswith(b"PF\n5 6\n-1\n")  # imageio.rs:186-196, little-endian host
     data = np.frombuffer(raw[len(b"PF\n5 6\n-1\n"):], "<f4").reshape(6, 5, 3)[::-1]  # rows bottom to top
     assert np.array_equal(data, rgb)  # exact round trip, imageio.rs:363-389
-    with pytest.raises(pbrt_amd._lib.PbrtHipError):
-        pbrt_amd.write_image(tmp_path / "t.exr", rgb)  # imageio.rs:272: unimplemented
+    with pytest.raises(pbrt_amd._lib.PbrtHipError) as e:
+        pbrt_amd.write_image(tmp_path / "t.exr", rgb)  # imageio.rs:272: unimplemented!("writing .exr files is not implemented")
+    assert "writing .exr files is not implemented" in str(e.value)
+    with pytest.raises(pbrt_amd._lib.PbrtHipError) as e:
+        pbrt_amd.write_image(tmp_path / "t.jpeg", rgb)  # imageio.rs:281
+    assert "unknown file extension jpeg" in str(e.value)
+    with pytest.raises(pbrt_amd._lib.PbrtHipError) as e:
+        pbrt_amd.write_image(tmp_path / "no" / "such" / "dir.png", rgb)  # imageio.rs:248
+    assert "Failed to create file" in str(e.value)
 
 
 def _reference_test_image():  # imageio.rs:298-309: 64x64, (x/64, y/64, 1)
