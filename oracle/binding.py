@@ -212,6 +212,36 @@ def matrix_mul(a, b):
     lib().orc_matrix_mul(_p(a), _p(b), _p(out)); return out.reshape(4, 4)
 
 
+def clamp(v, lo, hi):
+    """lib.rs:115-127, for floats and for integers"""
+    l = lib()
+    if isinstance(v, int) and isinstance(lo, int) and isinstance(hi, int):
+        l.orc_clamp_i.restype = C.c_long
+        l.orc_clamp_i.argtypes = [C.c_long] * 3
+        return int(l.orc_clamp_i(v, lo, hi))
+    l.orc_clamp_f.restype = C.c_float
+    l.orc_clamp_f.argtypes = [C.c_float] * 3
+    return float(l.orc_clamp_f(v, lo, hi))
+
+
+def lerp(t, v1, v2):
+    """lib.rs:139-141"""
+    l = lib()
+    l.orc_lerp.restype = C.c_float
+    l.orc_lerp.argtypes = [C.c_float] * 3
+    return float(l.orc_lerp(t, v1, v2))
+
+
+def solve_linear_system_2x2(a, b):
+    """transform.rs:59-71 -> [x0, x1] or None"""
+    l = lib()
+    A = (C.c_float * 4)(a[0][0], a[0][1], a[1][0], a[1][1])
+    B = (C.c_float * 2)(*b)
+    X = (C.c_float * 2)()
+    l.orc_solve_2x2.restype = C.c_int
+    return [X[0], X[1]] if l.orc_solve_2x2(A, B, X) else None
+
+
 def quadratic(a, b, c):
     t0 = C.c_float(); t1 = C.c_float()
     ok = lib().orc_quadratic(a, b, c, C.byref(t0), C.byref(t1))

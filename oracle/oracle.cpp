@@ -738,6 +738,13 @@ void orc_look_at(const float pos[3], const float look[3], const float up[3], flo
 void orc_matrix_inverse(const float m[16], float out[16]) { Mat4 a; memcpy(a.m, m, 64); Mat4 r = inverse(a); memcpy(out, r.m, 64); }
 void orc_matrix_mul(const float a[16], const float b[16], float out[16]) { Mat4 x, y; memcpy(x.m, a, 64); memcpy(y.m, b, 64); Mat4 r = mul(x, y); memcpy(out, r.m, 64); }
 int orc_quadratic(float a, float b, float c, float *t0, float *t1) { return quadratic(a, b, c, t0, t1) ? 1 : 0; }
+float orc_clamp_f(float v, float lo, float hi) { return clamp_ref(v, lo, hi); }
+long orc_clamp_i(long v, long lo, long hi) { return clamp_ref(v, lo, hi); }
+float orc_lerp(float t, float v1, float v2) { return lerp_ref(t, v1, v2); }
+int orc_solve_2x2(const float a[4], const float b[2], float x[2]) {
+  const float m[2][2] = {{a[0], a[1]}, {a[2], a[3]}};
+  return solve_linear_system_2x2(m, b, x) ? 1 : 0;
+}
 float orc_gamma_correct(float v) { return gamma_correct(v); }
 uint8_t orc_to_byte(float v) { return to_byte(v); }
 

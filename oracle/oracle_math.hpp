@@ -188,6 +188,21 @@ static inline void look_at(Vec3 pos, Vec3 look, Vec3 up, Mat4 *w2c, Mat4 *c2w) {
   *w2c = inverse(m);
 }
 
+// lib.rs:115-127 clamp, :139-141 lerp; transform.rs:59-71 solve_linear_system_2x2 (not called on this path -- pbrt-v3 uses it for a
+// triangle's dp/du, which no kernel here needs -- but SURVEY 8(c) lists their doc-tests among the vectors to pin the restatement to)
+template <class T>
+static inline T clamp_ref(T val, T low, T high) { return val < low ? low : (val > high ? high : val); }
+static inline float lerp_ref(float t, float v1, float v2) { return (1.f - t) * v1 + t * v2; }
+static inline bool solve_linear_system_2x2(const float a[2][2], const float b[2], float x[2]) {
+  const float det = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+  if (std::fabs(det) < 1e-10f) return false;
+  const float x0 = (a[1][1] * b[0] - a[0][1] * b[1]) / det, x1 = (a[0][0] * b[1] - a[1][0] * b[0]) / det;
+  if (std::isnan(x0) || std::isnan(x1)) return false;
+  x[0] = x0;
+  x[1] = x1;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sin / cos on [-pi/4, pi/4] as fixed polynomials (Cephes single-precision kernels) so that CPU
 // and GPU agree bit for bit -- no libm / ocml call on the path.

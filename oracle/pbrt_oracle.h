@@ -121,6 +121,11 @@ void orc_look_at(const float pos[3], const float look[3], const float up[3], flo
 void orc_matrix_inverse(const float m[16], float out[16]);
 void orc_matrix_mul(const float a[16], const float b[16], float out[16]);
 int orc_quadratic(float a, float b, float c, float *t0, float *t1);
+/* lib.rs:115-141 / transform.rs:59-71 (their doc-tests are among the reference's known-answer vectors) */
+float orc_clamp_f(float v, float lo, float hi);
+long orc_clamp_i(long v, long lo, long hi);
+float orc_lerp(float t, float v1, float v2);
+int orc_solve_2x2(const float a[4], const float b[2], float x[2]);
 float orc_gamma_correct(float v);
 uint8_t orc_to_byte(float v);
 

@@ -159,6 +159,19 @@ def test_product_look_at_equals_oracle(oracle):
         assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
+def test_clamp_lerp_and_the_2x2_solver(oracle):
+    """lib.rs:104-137 (clamp, lerp) and transform.rs:36-58 (solve_linear_system_2x2): the doc-tests' literals.  (The solver is pbrt-v3's
+    helper for a triangle's dp/du; nothing on this path calls it, SURVEY 8(c) lists its vectors with the others.)"""
+    assert [oracle.clamp(-1.0, 0.0, 1.0), oracle.clamp(0.5, 0.0, 1.0), oracle.clamp(2.0, 0.0, 1.0)] == [0.0, 0.5, 1.0]
+    assert [oracle.clamp(-1, 0, 2), oracle.clamp(1, 0, 2), oracle.clamp(3, 0, 2)] == [0, 1, 2]
+    assert [oracle.lerp(0.0, 0.0, 1.0), oracle.lerp(0.5, 0.0, 1.0), oracle.lerp(1.0, 0.0, 1.0), oracle.lerp(0.75, 0.0, 2.0)] == [0.0, 0.5, 1.0, 1.5]
+    assert oracle.solve_linear_system_2x2([[3.0, -5.0], [1.0, -4.0]], [4.0, -1.0]) == [3.0, 1.0]
+    assert oracle.solve_linear_system_2x2([[2.0, -3.0], [0.0, 4.0]], [-8.0, 8.0]) == [-1.0, 2.0]
+    assert oracle.solve_linear_system_2x2([[5.0, -1.0], [3.0, 2.0]], [3.0, 20.0]) == [2.0, 7.0]
+    assert oracle.solve_linear_system_2x2([[2.0, -1.0], [-4.0, 2.0]], [7.0, 6.0]) is None
+    assert oracle.solve_linear_system_2x2([[2.0, -1.0], [-2.0, 1.0]], [7.0, 3.0]) is None
+
+
 # ---- imageio.rs ----
 def test_png_pfm_roundtrip(tmp_path, oracle):  # imageio.rs:325-390
     rng = np.random.default_rng(5)
