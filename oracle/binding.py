@@ -202,6 +202,16 @@ def look_at(pos, look, up):
     lib().orc_look_at(_p(a[0]), _p(a[1]), _p(a[2]), _p(m), _p(mi)); return m.reshape(4, 4), mi.reshape(4, 4)
 
 
+def matrix_transpose(m):
+    a = np.ascontiguousarray(m, np.float32).reshape(16); out = np.zeros(16, np.float32)
+    lib().orc_matrix_transpose(_p(a), _p(out)); return out.reshape(4, 4)
+
+
+def matrix_mul(a, b):
+    x = np.ascontiguousarray(a, np.float32).reshape(16); y = np.ascontiguousarray(b, np.float32).reshape(16); out = np.zeros(16, np.float32)
+    lib().orc_matrix_mul(_p(x), _p(y), _p(out)); return out.reshape(4, 4)
+
+
 def matrix_inverse(m):
     a = np.ascontiguousarray(m, np.float32); out = np.zeros(16, np.float32)
     lib().orc_matrix_inverse(_p(a), _p(out)); return out.reshape(4, 4)

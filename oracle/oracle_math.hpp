@@ -126,6 +126,12 @@ static inline Mat4 identity() {
   for (int i = 0; i < 4; i++) r.m[i][i] = 1.f;
   return r;
 }
+static inline Mat4 transpose(const Mat4 &a) {  // transform.rs:129-139
+  Mat4 r;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) r.m[i][j] = a.m[j][i];
+  return r;
+}
 static inline Mat4 mul(const Mat4 &a, const Mat4 &b) {
   Mat4 r;
   for (int i = 0; i < 4; i++)

@@ -139,6 +139,16 @@ def test_matrix_inverse_doctests(oracle):  # transform.rs:142-155
     assert np.allclose(oracle.matrix_mul(m, oracle.matrix_inverse(m)), eye, atol=EPS, rtol=0)
 
 
+def test_matrix_transpose_and_product_doctests(oracle):  # transform.rs:113-128 (transpose), :270-282 (Mul) with :142-155's products
+    m = np.array([[2, 0, 0, 0], [3, 1, 0, 0], [4, 0, 1, 0], [5, 6, 7, 1]], np.float32)
+    m_t = np.array([[2, 3, 4, 5], [0, 1, 0, 6], [0, 0, 1, 7], [0, 0, 0, 1]], np.float32)
+    assert np.array_equal(oracle.matrix_transpose(m), m_t)
+    i4 = np.eye(4, dtype=np.float32)
+    d = np.diag([2, 3, 4, 1]).astype(np.float32)
+    assert np.array_equal(oracle.matrix_mul(oracle.matrix_inverse(d), d), i4) and np.array_equal(oracle.matrix_mul(d, oracle.matrix_inverse(d)), i4)
+    assert np.array_equal(oracle.matrix_mul(oracle.matrix_inverse(i4), i4), i4)
+
+
 def test_look_at(oracle):  # transform.rs:485-520, camera of scenes/check-sphere.pbrt:1-3
     m, mi = oracle.look_at((3, 4, 1.5), (0.5, 0.5, 0), (0, 0, 1))
     assert np.array_equal(mi[:3, 3], np.array([3, 4, 1.5], np.float32))
