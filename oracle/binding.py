@@ -207,11 +207,6 @@ def matrix_transpose(m):
     lib().orc_matrix_transpose(_p(a), _p(out)); return out.reshape(4, 4)
 
 
-def matrix_mul(a, b):
-    x = np.ascontiguousarray(a, np.float32).reshape(16); y = np.ascontiguousarray(b, np.float32).reshape(16); out = np.zeros(16, np.float32)
-    lib().orc_matrix_mul(_p(x), _p(y), _p(out)); return out.reshape(4, 4)
-
-
 def matrix_inverse(m):
     a = np.ascontiguousarray(m, np.float32); out = np.zeros(16, np.float32)
     lib().orc_matrix_inverse(_p(a), _p(out)); return out.reshape(4, 4)

@@ -736,7 +736,6 @@ void orc_look_at(const float pos[3], const float look[3], const float up[3], flo
   memcpy(m_inv, c2w.m, 64);
 }
 void orc_matrix_transpose(const float m[16], float out[16]) { Mat4 a; memcpy(a.m, m, 64); Mat4 r = transpose(a); memcpy(out, r.m, 64); }
-void orc_matrix_mul(const float a[16], const float b[16], float out[16]) { Mat4 x, y; memcpy(x.m, a, 64); memcpy(y.m, b, 64); Mat4 r = mul(x, y); memcpy(out, r.m, 64); }
 void orc_matrix_inverse(const float m[16], float out[16]) { Mat4 a; memcpy(a.m, m, 64); Mat4 r = inverse(a); memcpy(out, r.m, 64); }
 void orc_matrix_mul(const float a[16], const float b[16], float out[16]) { Mat4 x, y; memcpy(x.m, a, 64); memcpy(y.m, b, 64); Mat4 r = mul(x, y); memcpy(out, r.m, 64); }
 int orc_quadratic(float a, float b, float c, float *t0, float *t1) { return quadratic(a, b, c, t0, t1) ? 1 : 0; }

@@ -121,7 +121,6 @@ void orc_look_at(const float pos[3], const float look[3], const float up[3], flo
 void orc_matrix_inverse(const float m[16], float out[16]);
 void orc_matrix_mul(const float a[16], const float b[16], float out[16]);
 void orc_matrix_transpose(const float m[16], float out[16]);               /* transform.rs:129-139 */
-void orc_matrix_mul(const float a[16], const float b[16], float out[16]);  /* transform.rs:270-282 */
 int orc_quadratic(float a, float b, float c, float *t0, float *t1);
 /* lib.rs:115-141 / transform.rs:59-71 (their doc-tests are among the reference's known-answer vectors) */
 float orc_clamp_f(float v, float lo, float hi);
