@@ -187,6 +187,9 @@ def test_film_scale_and_filter_radius_leave_the_library():
     assert ls.filter_width == (1.5, 0.5) and ls.max_sample_luminance == 0.0
     ls = loader.load_string("WorldBegin\nWorldEnd\n")
     assert ls.film_scale == 1.0 and ls.filter_width == (0.5, 0.5)
+    # box.rs:45-55 / api.rs:1058-1064 (test_make_filter): "xwidth" 1 alone -> radius (1, 0.5), inverse radius (1, 2)
+    ls = loader.load_string('PixelFilter "box" "float xwidth" 1')
+    assert ls.filter_width == (1.0, 0.5) and (1 / ls.filter_width[0], 1 / ls.filter_width[1]) == (1.0, 2.0)
     # Film "float maxsampleluminance" (film.rs:75,279) reaches the render desc too; pbrt-v3's default (infinity) is 0 here
     ls = loader.load_string('Film "image" "float maxsampleluminance" 12.5 "integer xresolution" 8 "integer yresolution" 8')
     assert ls.max_sample_luminance == 12.5 and ls.render_kwargs()["max_sample_luminance"] == 12.5
