@@ -326,6 +326,24 @@ def test_maximum_triangle_count_matches_oracle(gpu, oracle):
     assert e.value.code == -4 and "2^24" in str(e.value)
 
 
+@pytest.mark.parametrize("res", [(1, 1), (1, 65), (65, 1), (63, 64), (129, 2), (3, 200)])
+def test_tiny_and_thin_films(gpu, oracle, res):
+    """Films of one pixel, one row, one column, one pixel short of a super-tile, a few pixels over two: the ragged ends of the 64 x 64
+    super-tiles and of the item hand-out, alone and as one of three ranks (some of which own nothing), default and wide filter."""
+    sd = scenes.cornell_scene(*res)
+    kw = dict(max_depth=4, spp=(3, 2), seed=6)
+    o = oracle.OracleScene(sd)
+    ref, _ = o.render(**kw)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(counters=True, **kw)
+        parts = sum(sc.render(rank=r, world_size=3, **kw)[0] for r in range(3))
+        wide, _ = sc.render(filter_width=(1.5, 2.0), **kw)
+    assert film.shape == (res[1], res[0], 4) and st["samples"] == res[0] * res[1] * 6
+    assert_bit_equal(film, ref, f"{res[0]} x {res[1]} film")
+    assert_bit_equal(parts, ref, "three ranks")
+    assert_bit_equal(wide, o.render(filter_width=(1.5, 2.0), **kw)[0], "wide box filter")
+
+
 def test_large_film_matches_oracle(gpu, oracle):
     """A 16 384 x 16 384 film (268 M pixels, 4.3 GB; 65 536 super-tiles; the partial sums in three passes under the 2 GiB cap) at one sample
     per pixel: weight 1 everywhere, finite, and three 16 x 16 windows -- both far corners and one inside -- equal to the oracle's.
