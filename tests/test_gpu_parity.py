@@ -344,6 +344,35 @@ def test_tiny_and_thin_films(gpu, oracle, res):
     assert_bit_equal(wide, o.render(filter_width=(1.5, 2.0), **kw)[0], "wide box filter")
 
 
+@pytest.mark.parametrize("case", ["fov 179", "fov 0.01", "scaled", "sheared + mirrored", "far away"])
+def test_unusual_cameras(gpu, oracle, case):
+    """Cameras off the beaten track: the widest and the narrowest fields of view, a camera-to-world matrix with a scale (ray directions that
+    are not unit vectors: `Scale` before `Camera` in a scene file), with a shear and a mirror, and a camera 10^5 scene sizes away."""
+    sd = SMALL_SCENES["mesh1k"]()
+    c2w = sd.cam_to_world.copy()
+    if case == "fov 179":
+        sd.fov = 179.0
+    elif case == "fov 0.01":
+        sd.fov = 0.01
+    elif case == "scaled":
+        c2w[:3, :3] *= np.float32(2.5)
+    elif case == "sheared + mirrored":
+        c2w[:3, :3] = c2w[:3, :3] @ np.array([[-1, 0.3, 0], [0, 1, 0.2], [0, 0, 1]], np.float32)
+    else:
+        c2w[:3, 3] = c2w[:3, 3] + c2w[:3, 2] * np.float32(-3e5)  # back along the viewing direction
+        sd.fov = 0.0005
+    sd.cam_to_world = c2w
+    sd = sd.normalized()
+    kw = dict(max_depth=5, spp=(2, 2), seed=4)
+    ref, rst = oracle.OracleScene(sd).render(**kw)
+    with gpu.Scene(sd) as sc:
+        film, st = sc.render(counters=True, **kw)
+    assert_bit_equal(film, ref, case)
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+        assert st[k] == rst[k], (case, k)
+    assert np.isfinite(film).all()
+
+
 def test_large_film_matches_oracle(gpu, oracle):
     """A 16 384 x 16 384 film (268 M pixels, 4.3 GB; 65 536 super-tiles; the partial sums in three passes under the 2 GiB cap) at one sample
     per pixel: weight 1 everywhere, finite, and three 16 x 16 windows -- both far corners and one inside -- equal to the oracle's.
