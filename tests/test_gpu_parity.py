@@ -3,6 +3,7 @@ same seeded inputs.  Bar: BIT-EXACT -- every fp32 operation of the path is +,-,*
 comparison, executed in the same order on both sides with FMA contraction off,
 so the film, the hit records and the visit counters must be identical, not merely close.
 (BASELINE.json asks for PSNR >= 50 dB; identical images are PSNR = inf.)"""
+import dataclasses
 import os
 
 import numpy as np
@@ -371,6 +372,48 @@ def test_unusual_cameras(gpu, oracle, case):
     for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
         assert st[k] == rst[k], (case, k)
     assert np.isfinite(film).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_degenerate_scene_features(gpu, oracle, seed):
+    """Things scenes should not contain and do: a point light sitting exactly on a vertex, lights with zero and with enormous intensity,
+    a distant light whose direction is the zero vector, zero-area emitters, materials with Kd = 0 and Kd > 1 (energy-creating), spheres that
+    coincide, contain the camera, are 1e-6 and 1e6 across, hundreds of lights -- film, hit records and occlusion equal to the oracle's, and
+    nothing that is not a number in the film (the sample filter of SURVEY A11 drops what the arithmetic cannot hold)."""
+    from pbrt_amd import LIGHT_DISTANT, LIGHT_POINT
+    rng = np.random.default_rng(1000 + seed)
+    sd = SMALL_SCENES["mesh1k"]()
+    P, idx = sd.P.copy(), sd.idx.copy()
+    lights = [[LIGHT_POINT, *P[int(rng.integers(0, len(P)))], 5, 5, 5],            # on a vertex: r = 0 for the paths that end there
+              [LIGHT_POINT, *rng.uniform(-1, 1, 3), 0, 0, 0],                         # no intensity
+              [LIGHT_POINT, *rng.uniform(-1, 1, 3), 1e30, 1e30, 1e30],                # overflows the film's floats
+              [LIGHT_DISTANT, 0, 0, 0, 2, 2, 2]]                                       # no direction
+    lights += [[LIGHT_POINT, *rng.uniform(-1.5, 1.5, 3), *rng.uniform(0, 0.3, 3)] for _ in range(300 if seed % 2 else 0)]
+    mats = sd.materials.copy()
+    mats[0, 1:4] = 0.0                      # black
+    mats[1 % len(mats), 1:4] = 1.7          # reflects more than arrives
+    tri = int(rng.integers(0, len(idx)))
+    idx[tri] = idx[tri][[0, 0, 1]]          # a zero-area triangle ...
+    mats = np.concatenate([mats, [[0, 0.5, 0.5, 0.5, 4, 4, 4]]]).astype(np.float32)
+    mat_id = sd.mat_id.copy()
+    mat_id[tri] = len(mats) - 1             # ... that emits
+    eye = sd.cam_to_world[:3, 3]
+    spheres = [[0.3, 0.2, 0.1, 0.25, 0], [0.3, 0.2, 0.1, 0.25, 1 % len(mats)],        # twice the same sphere: the smaller primitive number wins
+               [*rng.uniform(-1, 1, 3), 1e-6, 0], [0, 0, 0, 1e6, 0], [*eye, 0.05, 0]]  # a speck; everything is inside this one; round the camera (seed 3: a black film)
+    sd = dataclasses.replace(sd, idx=idx, mat_id=mat_id, materials=mats, mat_tex=np.zeros(len(mats), np.uint32), lights=np.array(lights, np.float32),
+                             spheres=np.array(spheres[: 2 + seed % 4], np.float32).reshape(-1, 5)).normalized()
+    kw = dict(max_depth=6, spp=(2, 2), seed=seed, integrator=[INTEGRATOR_PATH, INTEGRATOR_DIRECT, 2][seed % 3], sampler=["stratified", "halton"][seed % 2])
+    ref, _ = oracle.OracleScene(sd).render(**kw)
+    o, d, tmax = random_rays(2000, seed, inside=1.8)
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(**kw)
+        hit, occ = sc.intersect(o, d, tmax), sc.occluded(o, d, tmax)
+    assert_bit_equal(film, ref, f"degenerate scene {seed}")
+    assert np.isfinite(film).all()
+    rs = oracle.OracleScene(sd)
+    for a, b, what in zip(hit[:4], rs.intersect(o, d, tmax)[:4], ("t", "prim", "b1", "b2")):
+        assert_bit_equal(a, b, f"degenerate scene {seed}: {what}")
+    assert np.array_equal(occ != 0, rs.occluded(o, d, tmax) != 0)
 
 
 def test_large_film_matches_oracle(gpu, oracle):
