@@ -376,7 +376,7 @@ def test_unusual_cameras(gpu, oracle, case):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_degenerate_scene_features(gpu, oracle, seed):
-    """Things scenes should not contain and do: a point light sitting exactly on a vertex, lights with zero and with enormous intensity,
+    """Things scenes should not contain and do: a point light a hair off a vertex, lights with zero and with enormous intensity,
     a distant light whose direction is the zero vector, zero-area emitters, materials with Kd = 0 and Kd > 1 (energy-creating), spheres that
     coincide, contain the camera, are 1e-6 and 1e6 across, hundreds of lights -- film, hit records and occlusion equal to the oracle's, and
     nothing that is not a number in the film (the sample filter of SURVEY A11 drops what the arithmetic cannot hold)."""
@@ -384,7 +384,10 @@ def test_degenerate_scene_features(gpu, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     sd = SMALL_SCENES["mesh1k"]()
     P, idx = sd.P.copy(), sd.idx.copy()
-    lights = [[LIGHT_POINT, *P[int(rng.integers(0, len(P)))], 5, 5, 5],            # on a vertex: r = 0 for the paths that end there
+    # (a light NEAR a vertex, 1e-3 off it: exactly ON one, every shadow ray aims at the corner of a triangle's own box, where what fp32
+    # Moeller-Trumbore accepts can lie outside that box and the answer depends on the tree -- DESIGN.md 3.4, "the limit of the tie rule";
+    # tests/test_oracle_selfcheck.py::test_ill_conditioned_hit_at_a_vertex_is_outside_the_tie_rule shows it inside the oracle alone)
+    lights = [[LIGHT_POINT, *(P[int(rng.integers(0, len(P)))] + np.float32(1e-3)), 5, 5, 5],
               [LIGHT_POINT, *rng.uniform(-1, 1, 3), 0, 0, 0],                         # no intensity
               [LIGHT_POINT, *rng.uniform(-1, 1, 3), 1e30, 1e30, 1e30],                # overflows the film's floats
               [LIGHT_DISTANT, 0, 0, 0, 2, 2, 2]]                                       # no direction

@@ -498,3 +498,24 @@ def test_checkerboard_on_a_sphere_closed_form(oracle, res):
     from util import check_checker_sphere, checker_sphere_scene
     film, _ = oracle.OracleScene(checker_sphere_scene(*res)).render(max_depth=1, spp=(4, 4), seed=3)
     check_checker_sphere(oracle.film_write_rgb(film))
+
+
+def test_ill_conditioned_hit_at_a_vertex_is_outside_the_tie_rule(oracle):
+    """The limit of "a hit does not depend on the tree" (DESIGN.md 3.4), recorded where it was found: a shadow ray aimed exactly at a
+    mesh vertex (a point light placed ON the vertex) meets the triangle that owns the vertex edge-on (det 1.6e-6).  In float64 the ray
+    passes outside the triangle (u = -4e-4) and would reach its plane at t = 2.72481, beyond tmax = 2.72460; fp32 Moeller-Trumbore
+    computes u = 0.0, t = 2.72448 < tmax and accepts.  That "hit" lies OUTSIDE the triangle's own bounding box, so a walk over tight
+    boxes culls the triangle and a walk that reaches its leaf through a wider box does not: the oracle's BVH and its own brute force over
+    all triangles disagree, and so may two trees.  The tie rule orders hits that every walk sees; it cannot make a walk see a hit that
+    is outside every box.  (180 000 random scenes never aimed a ray at a vertex; scenes that do are where the two sides may differ.)"""
+    sd = SMALL_SCENES["mesh1k"]()
+    light = sd.P[1304]  # the vertex
+    po = np.array([[-0.8261664, 1.9999, 1.5779929]], np.float32)
+    dv = (light - po[0]).astype(np.float32)
+    dist = np.float32(np.sqrt(np.float32((dv * dv).sum(dtype=np.float32))))
+    wi = (dv / dist).astype(np.float32)[None]
+    tmax = np.array([dist * np.float32(1 - 1e-4)], np.float32)
+    sc = oracle.OracleScene(sd)
+    assert sc.occluded(po, wi, tmax)[0] == 0 and sc.occluded(po, wi, tmax, brute_force=True)[0] == 1
+    from util import brute_force_hits_f64
+    assert brute_force_hits_f64(sd, po, wi, tmax)[1][0] == -1  # in float64 nothing is hit
