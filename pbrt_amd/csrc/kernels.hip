@@ -604,7 +604,19 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const V3 qv = cross(tv, e1);
           const float v = dot(d, qv) * idet;
           const float th = dot(e2, qv) * idet;
-          const bool valid = !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax);
+#ifdef PBRT_OWN_BOX_TEST  // A-B switch (tools/experiments/README.md, round 5): what making a hit a function of (ray, triangle) alone would cost
+          // the triangle's own box through the node test's arithmetic (true 1 / d): the hit must lie in the padded interval the ray spends in it
+          const V3 blo = {fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z)};
+          const V3 bhi = {fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z)};
+          const float bx0 = (blo.x - o.x) * inv1.x, bx1 = (bhi.x - o.x) * inv1.x, by0 = (blo.y - o.y) * inv1.y, by1 = (bhi.y - o.y) * inv1.y;
+          const float bz0 = (blo.z - o.z) * inv1.z, bz1 = (bhi.z - o.z) * inv1.z;
+          const float btn = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
+          const float btf = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
+          const bool in_own_box = btn <= th * kBoxPad && th <= btf * kBoxPad;
+#else
+          const bool in_own_box = true;
+#endif
+          const bool valid = in_own_box && !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax);
           const uint32_t id = __float_as_uint(a.w);
           const bool occl = valid && T.any != 0u;  // any-hit ray: the walk ends at the first valid hit
           const bool closer = valid && T.any == 0u && (th < T.h.t || (th == T.h.t && id < T.h.prim));
