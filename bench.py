@@ -21,13 +21,16 @@ Rank 0 prints ONE JSON line.  Every figure of `roofline` (dominant kernel = rend
 P = profiles/pmc_<workload>.json (the committed rocprofv3 --pmc passes of THIS kernel's ISA and builder), R = rays_per_launch
 (counted live by the exact-counter instantiation) and T = kernel_ms (HIP events on the launch stream, average of the timed
 steps) -- by one formula each:
-  achieved          = P.valu_issue_quadcycles_per_ray x R / T                     [G vector-issue quad-cycles/s]
+  busy              = P.valu_issue_quadcycles_per_ray x R / T                     [G vector-issue quad-cycles/s: `achieved_busy`]
   peak              = CUs x 4 SIMDs x 2.4 GHz / 4                                  (614.4 G for 256 CUs)
-  frac              = achieved / peak             the share of all SIMD quad-cycles in which a vector instruction issued: a BUSY
-                                                  fraction (utilisation of the issue port), not useful work
-  frac_at_measured_clock = achieved / (CUs x 4 x clock_ghz_measured / 4)
+  frac_busy         = busy / peak                 the share of all SIMD quad-cycles in which a vector instruction issued: how often
+                                                  the issue port was OCCUPIED, whatever the lanes did
   lane_utilisation  = P.lane_utilisation          active lanes per issued vector instruction / 64
-  frac_useful       = frac x lane_utilisation     the share of the chip's lane-issue slots that did work for a ray
+  achieved          = busy x lane_utilisation     [G lane-weighted vector-issue quad-cycles/s]
+  frac              = achieved / peak = frac_busy x lane_utilisation   THE roofline fraction (round 6): the share of
+                                                  the chip's lane-issue slots that did work for a ray.  (Until round 5 `frac` was the busy
+                                                  fraction, half of it on idle lanes; `frac_useful` is kept as an alias of `frac`.)
+  frac_at_measured_clock, frac_busy_at_measured_clock = the same against CUs x 4 x clock_ghz_measured / 4
   l1.frac           = P.l1_accesses_per_ray x R / T / 693.6 G   (16-byte gathers against tools/ubench/gather_wide.hip's roof)
   l2_miss.requests_per_s = (hbm.kernel_fetches_per_ray + hbm.kernel_tris_per_ray) x R / T x (1 - P.l2_hit_rate)
                                                   64-byte records that miss the XCD's L2, against l2_miss.peak = 58.1 G records/s
@@ -36,8 +39,13 @@ steps) -- by one formula each:
                                                   SURVEY 8(d)'s contract figure (exceeds 1 when hbm.cache_resident: the hot working
                                                   set -- quad nodes + triangle records -- then fits the 256 MiB Infinity Cache and
                                                   the production walk moves fewer bytes, kernel_*)
-  hbm_counter_frac  = P.traffic_bytes_raw / P.avg_ms / 8 TB/s                      north_star's "rocprof achieved HBM GB/s":
-                                                  (FETCH_SIZE + WRITE_SIZE) x 1024 of the dedicated --pmc passes
+  traffic           = P.FETCH_SIZE_KB_per_launch x 1024 x P.fetch_size_calibration.factor + P.WRITE_SIZE_KB_per_launch x 1024
+                                                  memory-side bytes per launch; the factor is MEASURED for this access shape (64-byte
+                                                  records gathered at random: tools/fetch_size_calibration.sh, profiles/r06_fetch_size_calibration.txt)
+  hbm_counter_frac  = traffic / P.avg_ms / 8 TB/s                                  north_star's "rocprof achieved HBM GB/s"
+The per-ray counters of P belong to ONE tree: beside the kernel's machine code (P.kernel_isa_id) and the builder's name the profile
+records the production walk's fetches and triangle tests per ray on that tree (P.tree), and everything that rests on P is withheld when
+the live counting pass differs by more than 0.5 % (a builder edit changes the tree and leaves the render kernel's ISA alone: ADVICE r05).
 `cpu_baseline` (N=1): the CPU oracle timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
@@ -257,6 +265,14 @@ def main():
 
     mode, world = launch_mode(args.gpus, args.single_process, os.environ)  # (before torch / HIP are even imported)
     in_process = mode == "in-process"
+    # The identity of the profiled kernel in the library on disk -- file parsing, done HERE, before torch or HIP are imported: a profile
+    # that carries the kernel's mangled symbol needs no demangler at all, an older one runs c++filt now, while no GPU is initialised
+    # (no child process from a GPU-initialised process; under rocprofv3 every child inherits the profiler's preload).
+    from pbrt_amd import isa_id
+    from pbrt_amd.build import LIB_PATH
+    pmc_path = os.path.join(args.profiles, f"pmc_{args.workload}.json")
+    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
+    kernel_id_loaded = isa_id.kernel_id(LIB_PATH, pmc["kernel"], pmc.get("kernel_symbol")) if pmc is not None and pmc.get("kernel") else None
 
     import torch
     import torch.distributed as dist
@@ -358,10 +374,14 @@ def main():
             dist_info["ranks_on_distinct_gpus"] = len(set(ids))
         except Exception as e:  # noqa: BLE001
             dist_info["ranks_on_distinct_gpus_error"] = repr(e)[:200]
+    per_rank = None  # every rank's kernel time (mean of its timed steps) and sample count: what makes an N-GPU record diagnosable
     if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # (in ranks mode the line used to carry rank 0's kernel time only -- imbalance between the ranks' shares and the
+        # cost of the gather would have been invisible in the first real 8-GPU record)
+        per_rank = pdist.rank_kernel_stats(kernel_ms, local_samples, world, "cuda" if backend == "nccl" else "cpu")
     total_samples = res * res * spp[0] * spp[1]
     value = total_samples * args.steps / elapsed / 1e6
     if in_process:  # the host copy of the film for the checks below (outside the timed region)
@@ -374,8 +394,6 @@ def main():
             "kernel": "render_kernel"}
     avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
     roof["kernel_ms"] = avg_kernel_ms
-    pmc_path = os.path.join(args.profiles, f"pmc_{args.workload}.json")
-    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
     # A profile prices the KERNEL it was taken on and no other: the committed counters carry the id of that kernel's machine code
     # (pbrt_amd/isa_id.py: a hash of the production instantiation's .text bytes and kernel descriptor in the gfx950 code object);
     # when the loaded library's kernel of that name hashes differently -- a changed source line, flag or compiler that reaches
@@ -383,9 +401,6 @@ def main():
     # reach that kernel (the parser, another instantiation, the builder's host code) leave the profile valid (VERDICT r04 item 7;
     # the tree the rays walk is checked separately, by builder).  A profile without an ISA id falls back to the source hash.
     lib_id = pbrt_amd.build_id()
-    from pbrt_amd import isa_id
-    from pbrt_amd._lib import LIB_PATH
-    kernel_id_loaded = isa_id.kernel_id(LIB_PATH, pmc["kernel"]) if pmc is not None and pmc.get("kernel") else None
     if pmc is not None and pmc.get("kernel_isa_id"):
         pmc_stale = pmc["kernel_isa_id"] != kernel_id_loaded
     else:
@@ -438,21 +453,43 @@ def main():
             "kernel_bytes_per_sample": kbytes, "kernel_fetches_per_ray": wst["nodes_visited"] / rays,
             "kernel_tris_per_ray": wst["tris_tested"] / rays, "kernel_gbps": kbytes * local_samples / (avg_kernel_ms * 1e-3) / 1e9,
         }
+        tree = (pmc or {}).get("tree") or {}
+        if pmc and tree.get("kernel_fetches_per_ray"):
+            # the committed per-ray counters are those of ONE tree's walk.  The render kernel's ISA does not change when the BUILDER is
+            # edited (bvh_gpu.hip, reinsert_core.hpp, the collapse), the tree does: the profile records the production walk's work per
+            # ray on its tree, and a live walk that differs by more than 0.5 % is another tree
+            live = (wst["nodes_visited"] / rays, wst["tris_tested"] / rays)
+            rel = 0.0
+            if tree.get("spp") in (None, spp[0] * spp[1]):  # (per-ray work is compared on the same frame: other sample counts trace other rays)
+                rel = max(abs(live[0] / tree["kernel_fetches_per_ray"] - 1.0), abs(live[1] / tree["kernel_tris_per_ray"] - 1.0) if tree.get("kernel_tris_per_ray") else 0.0)
+            if tree.get("quad_nodes") not in (None, info["quad_nodes"]):  # (the builders are deterministic: another node count IS another tree)
+                rel = max(rel, 1.0)
+            if rel > 0.005:
+                roof["stale_profile"] = (f"{os.path.relpath(pmc_path, ROOT)} was taken on a tree that costs {tree['kernel_fetches_per_ray']:.3f} fetches + "
+                                         f"{tree.get('kernel_tris_per_ray', float('nan')):.3f} triangle tests per ray; this build's tree costs {live[0]:.3f} + {live[1]:.3f} "
+                                         "(the builder changed): roofline.frac / valu / l1 / traffic withheld -- rerun tools/measure_round.sh")
+                roof.pop("profile_kernel", None)
+                pmc = None
         if pmc and pmc.get("valu_issue_quadcycles_per_ray"):
             # VALU roof, MEASURED: the SQ counts the quad-cycles in which a SIMD issued a vector instruction (one, or two of
             # the full-rate class: profiles/r03c_issue_counter_calibration.txt); per ray from the committed profile OF THIS
             # BUILD (checked above), x the rays this launch traced, counted live, / the kernel's time; the roof is every
             # quad-cycle of every SIMD at the nominal clock.  No instruction census and no per-class prices are involved.
-            roof["unit"] = "G vector-issue quad-cycles/s"
+            # frac (round 6): the USEFUL share -- busy x the lanes that were active when the port issued; frac_busy says how often the
+            # port was occupied, half of it on idle lanes
+            lanes = pmc.get("lane_utilisation")
+            roof["unit"] = "G lane-weighted vector-issue quad-cycles/s (quad-cycles in which a SIMD issued a vector instruction x active lanes / 64)"
             roof["peak"] = peak = n_simd * CLOCK_GHZ / 4.0
-            roof["achieved"] = pmc["valu_issue_quadcycles_per_ray"] * rays_per_s / 1e9
-            roof["frac"] = roof["achieved"] / peak
+            roof["achieved_busy"] = pmc["valu_issue_quadcycles_per_ray"] * rays_per_s / 1e9
+            roof["frac_busy"] = roof["achieved_busy"] / peak
+            if lanes is not None:
+                roof["lane_utilisation"] = lanes
+                roof["achieved"] = roof["achieved_busy"] * lanes
+                roof["frac"] = roof["frac_useful"] = roof["achieved"] / peak
             if clock:  # the same against the clock this box held during the timed steps
-                roof["frac_at_measured_clock"] = roof["achieved"] / (n_simd * clock["ghz_median"] / 4.0)
-            # frac is a BUSY fraction of the issue port; the lanes that were active when it issued make it useful work
-            if pmc.get("lane_utilisation") is not None:
-                roof["lane_utilisation"] = pmc["lane_utilisation"]
-                roof["frac_useful"] = roof["frac"] * pmc["lane_utilisation"]
+                roof["frac_busy_at_measured_clock"] = roof["achieved_busy"] / (n_simd * clock["ghz_median"] / 4.0)
+                if lanes is not None:
+                    roof["frac_at_measured_clock"] = roof["achieved"] / (n_simd * clock["ghz_median"] / 4.0)
             if pmc.get("l2_hit_rate") is not None:
                 # the third roof the kernel sits under: 64-byte records (quad nodes, triangle records) that miss the XCD's L2
                 recs = (wst["nodes_visited"] + wst["tris_tested"]) / rays * rays_per_s / 1e9
@@ -481,14 +518,22 @@ def main():
             roof["valu"]["source"] = f"{os.path.relpath(pmc_path, ROOT)} (rocprofv3 --pmc passes of tools/measure_round.sh; counters calibrated in profiles/r03c_issue_counter_calibration.txt)"
     # HBM-side traffic cannot be read in-process: it comes from the separate rocprofv3 --pmc passes of this same
     # workload whose summary is committed under profiles/; null when there is none.
-    if pmc and world == 1 and not args.spp and "traffic_bytes_raw" in pmc:
-        roof["traffic"] = pmc["traffic_bytes_raw"]
-        roof["hbm_counter_frac"] = pmc["traffic_bytes_raw"] / (pmc["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        roof["traffic_note"] = (f"(FETCH_SIZE + WRITE_SIZE) x 1024 per frame from {os.path.relpath(pmc_path, ROOT)} "
+    # (per FRAME of the workload's own sample count: an overridden --spp gets it only from a profile that says it was taken at that count)
+    if pmc and world == 1 and "traffic_bytes_raw" in pmc and (not args.spp or (pmc.get("tree") or {}).get("spp") == spp[0] * spp[1]):
+        cal = pmc.get("fetch_size_calibration") or {}
+        factor = cal.get("factor")
+        if factor and pmc.get("FETCH_SIZE_KB_per_launch") is not None:
+            roof["traffic"] = (pmc["FETCH_SIZE_KB_per_launch"] * factor + pmc.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024
+            roof["fetch_size_calibration"] = cal
+        else:
+            roof["traffic"] = pmc["traffic_bytes_raw"]
+        roof["traffic_bytes_raw"] = pmc["traffic_bytes_raw"]
+        roof["hbm_counter_frac"] = roof["traffic"] / (pmc["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["traffic_note"] = (f"(FETCH_SIZE x factor + WRITE_SIZE) x 1024 per frame from {os.path.relpath(pmc_path, ROOT)} "
                                 f"(round {pmc.get('round', '?')} kernel, {pmc['avg_ms']:.0f} ms per frame); FETCH_SIZE counts L2-miss requests "
-                                "incl. Infinity-Cache hits and is uncalibrated for 16-B gathers (x2 if the wide-stream correction applied); "
-                                "hbm_counter_frac = that traffic / that time / 8 TB/s")
-
+                                "incl. Infinity-Cache hits; factor = known bytes / FETCH_SIZE bytes MEASURED for 64-byte records gathered at random "
+                                + (f"({cal.get('source', '?')})" if factor else "(no calibration in the profile: raw)")
+                                + "; hbm_counter_frac = that traffic / that time / 8 TB/s")
     roof["clock_ghz_measured"] = clock["ghz_median"] if clock else None
     roof["clock"] = clock
     out = {
@@ -513,6 +558,13 @@ def main():
         cols = list(zip(*per_gpu_ms))
         out["per_gpu_kernel_ms"] = {"mean_per_gpu": [round(statistics.mean(c), 3) for c in cols],
                                     "max": round(max(map(max, cols)), 3), "min": round(min(map(min, cols)), 3)}
+        per_rank = {"mean_per_rank": out["per_gpu_kernel_ms"]["mean_per_gpu"], "max_step_per_rank": [round(max(c), 3) for c in cols]}
+    if per_rank is not None:
+        # the same keys however the N GPUs are driven: exchange_ms = what a step costs beyond its slowest rank's kernel (the gather /
+        # reduce, the assembly, launch and host overhead); imbalance = slowest / mean of the ranks' kernel times
+        out["per_rank_kernel_ms"], out["exchange_ms"] = pdist.step_breakdown(per_rank, out["ms_per_step"])
+        out["scaling_note"] = ("unmeasured on hardware until a SCALE run with N > 1 distinct GPUs exists (dist.ranks_on_distinct_gpus); "
+                               "roofline.kernel_ms is rank 0's, per_rank_kernel_ms every rank's")
     if rank == 0:
         if world == 1 and not in_process and not args.no_cpu_baseline and args.workload != "big":
             out["cpu_baseline"] = cpu_baseline(kind, n, res, integrator, depth, spp,

@@ -46,8 +46,10 @@ typedef struct {
   float k[3];
   float le[3]; /* emitted radiance; non-zero turns every triangle using it into an area light
                   (replaces api.rs:476-478 area_light_source -> todo!()) */
-  uint32_t kd_tex; /* matte only: 0 = Kd is k; t > 0 = Kd is textures[t - 1] evaluated at the hit's (u, v) -- on triangles; a
-                      sphere keeps k, which the parser sets to the mean of the texture's colours ("texture Kd": check-sphere.pbrt:26) */
+  uint32_t kd_tex; /* matte only: 0 = Kd is k; t > 0 = Kd is textures[t - 1] evaluated at the hit's (u, v): a triangle's corner (u, v)
+                      (tri_uv) interpolated like the hit point; a SPHERE's own (u, v) = (phi / 2 pi, 1 - theta / pi) with phi = atan2(n.y, n.x)
+                      in [0, 2 pi), theta = acos(n.z) of the unit normal n about the WORLD's z axis (pbrt-v3 Sphere::Intersect for an
+                      unrotated sphere: a sphere here is a centre and a radius, its CTM's rotation is not carried -- the parser warns) */
 } pbrt_hip_material;
 
 /* Texture "name" "spectrum" "checkerboard" (check-sphere.pbrt:24-25; the reference: api.rs:524-580 stores nothing, texture.rs is an

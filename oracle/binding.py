@@ -261,6 +261,12 @@ def to_byte(v):
     return lib().orc_to_byte(v)
 
 
+def debug_own_box_rule(on):
+    """tests only: False = Triangle::Intersect without the own-box rule (the spec until round 5); True = the default"""
+    lib().orc_debug_own_box_rule.argtypes = [C.c_int]
+    lib().orc_debug_own_box_rule(1 if on else 0)
+
+
 def quad_walk_count_visits(per_node):
     """per_node: a uint64 array with one word per quad node that the following quad_walk calls add their node steps to, or None"""
     lib().orc_quad_walk_count_visits.argtypes = [C.c_void_p]

@@ -403,8 +403,9 @@ class PathIntegrator {
           sphere_uv(ng.x, ng.y, ng.z, &u, &v);
         }
         const float ss = tx.su * u + tx.du, tt = tx.sv * v + tx.dv;
-        const int cell = (int)std::floor(ss) + (int)std::floor(tt);
-        k = (cell & 1) == 0 ? v3(tx.tex1[0], tx.tex1[1], tx.tex1[2]) : v3(tx.tex2[0], tx.tex2[1], tx.tex2[2]);
+        // (the parity in float on both sides: an (int) cast of a huge s is undefined here and saturates on the GPU)
+        const float cf = std::floor(ss) + std::floor(tt);
+        k = (cf - 2.0f * std::floor(0.5f * cf)) == 0.f ? v3(tx.tex1[0], tx.tex1[1], tx.tex1[2]) : v3(tx.tex2[0], tx.tex2[1], tx.tex2[2]);
       }
       Vec3 wi;
       if (m->type == 0) {  // matte
@@ -651,6 +652,7 @@ struct orc_scene {
 extern "C" {
 
 int orc_sobol_dims(void) { return kSobolDims; }
+void orc_debug_own_box_rule(int on) { Scene::own_box_rule() = on != 0; }
 // Halton sampler: u and the integer head of dimension d for indices 0 .. n - 1 under `key` in a frame whose largest sample index is
 // spp_mask (tests of the radical inverse); returns b^D, the head's modulus (0 for base 2)
 uint32_t orc_halton_points(uint32_t d, uint32_t key, uint32_t spp_mask, uint32_t n, float *u, uint32_t *v) {

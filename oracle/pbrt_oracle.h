@@ -167,6 +167,9 @@ void orc_quad_walk(const uint32_t *quads, uint32_t n_quads, uint32_t root_ref, c
                    uint32_t *tris, uint32_t *max_stack, int n_threads, const float *exact_boxes /* diagnostics: NULL */);
 /* measurement aid: the walks that follow add their node steps to per_node[node] (n_quads words; NULL stops counting) */
 void orc_quad_walk_count_visits(uint64_t *per_node);
+/* tests only: 0 switches the own-box rule of Triangle::Intersect off in the oracle's BVH walk and brute force -- the
+ * spec as it was until round 5, where the two can disagree --, anything else switches it back on (the default) */
+void orc_debug_own_box_rule(int on);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,8 @@ constexpr float kInf = __builtin_huge_valf();
 constexpr float kRayTMin = 1e-4f;
 constexpr float kSpawnEps = 1e-4f;
 constexpr float kShadowShrink = 0.9999f;
-constexpr float kBoxPad = 0x1.000006p+0f;  // 1 + 2*gamma(3)
+constexpr float kBoxPad = 0x1.0001p+0f;   // 1 + 2^-16: the node test's far-side pad (pbrt-v3 pads by 1 + 2 gamma(3))
+constexpr float kOwnPad = 0x1.00008p+0f;  // 1 + 2^-17: the own-box rule's pad (3.5), strictly inside kBoxPad
 constexpr float kInvPi = 0.31830988618379067154f;
 constexpr float kPiOver4 = 0.78539816339744830961f;
 constexpr float kOneMinusEps = 0x1.fffffcp-1f;  // 1 - f32::EPSILON = 1 - 2^-23, core/rng.rs:19 (NOT pbrt-v3's 1 - 2^-24)
@@ -604,17 +605,20 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const V3 qv = cross(tv, e1);
           const float v = dot(d, qv) * idet;
           const float th = dot(e2, qv) * idet;
-#ifdef PBRT_OWN_BOX_TEST  // A-B switch (tools/experiments/README.md, round 5): what making a hit a function of (ray, triangle) alone would cost
-          // the triangle's own box through the node test's arithmetic (true 1 / d): the hit must lie in the padded interval the ray spends in it
-          const V3 blo = {fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z)};
-          const V3 bhi = {fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z)};
-          const float bx0 = (blo.x - o.x) * inv1.x, bx1 = (bhi.x - o.x) * inv1.x, by0 = (blo.y - o.y) * inv1.y, by1 = (bhi.y - o.y) * inv1.y;
-          const float bz0 = (blo.z - o.z) * inv1.z, bz1 = (bhi.z - o.z) * inv1.z;
-          const float btn = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fminf(bz0, bz1));
-          const float btf = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fmaxf(bz0, bz1));
-          const bool in_own_box = btn <= th * kBoxPad && th <= btf * kBoxPad;
-#else
+          // The own-box rule (round 6): the node test of 3.4 on the triangle's OWN box with tfar = this hit's t -- slab
+          // distances of the three vertices with the TRUE 1 / d (two roundings each, as the canonical node test; p0 - o = -tv exactly),
+          // their min / max per axis, the interval [1e-4, t], pad kOwnPad < kBoxPad.  Monotone arithmetic: every enclosing box of every
+          // tree passes whenever this does, so an accepted hit is reached by every walk and a hit is a function of (ray, triangle) alone.
+#ifdef PBRT_NO_OWN_BOX_RULE  // A-B switch: the leaf pass as it was until round 5 (what the rule costs; films differ where it rejects)
           const bool in_own_box = true;
+#else
+          const V3 w1 = xyz(b) - o, w2 = xyz(c) - o;
+          const float x0 = (-tv.x) * inv1.x, x1 = w1.x * inv1.x, x2 = w2.x * inv1.x;
+          const float y0 = (-tv.y) * inv1.y, y1 = w1.y * inv1.y, y2 = w2.y * inv1.y;
+          const float z0 = (-tv.z) * inv1.z, z1 = w1.z * inv1.z, z2 = w2.z * inv1.z;
+          const float otn = fmaxf(fmaxf(fminf(fminf(x0, x1), x2), fminf(fminf(y0, y1), y2)), fmaxf(fminf(fminf(z0, z1), z2), kRayTMin));
+          const float otf = fminf(fminf(fmaxf(fmaxf(x0, x1), x2), fmaxf(fmaxf(y0, y1), y2)), fminf(fmaxf(fmaxf(z0, z1), z2), th));
+          const bool in_own_box = otn <= otf * kOwnPad;
 #endif
           const bool valid = in_own_box && !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax);
           const uint32_t id = __float_as_uint(a.w);

@@ -533,6 +533,9 @@ struct Api {
     if (it == objects.end()) { warn("Unable to find instance named \"" + name + "\""); return true; }
     const ObjectDef &d = it->second;
     if (out->idx.size() / 3 + d.idx.size() / 3 > kMaxSceneTriangles || out->spheres.size() + d.spheres.size() > kMaxSceneTriangles) return false;
+    // ... and its VERTICES: every instance copies the object's whole P array (unreferenced vertices included), so a vertex-heavy object
+    // with few faces, instanced 10^5 times, stays under the triangle bound and asks for terabytes: the same refusal
+    if (out->P.size() / 3 + d.P.size() / 3 > 3 * kMaxSceneTriangles) return false;
     const float *M = ctm[0].m;
     const uint32_t base = (uint32_t)(out->P.size() / 3);
     for (size_t v = 0; v + 2 < d.P.size(); v += 3) {

@@ -128,3 +128,27 @@ def render_sharded(scene, rank, world_size, group=None, **render_kw):
     film = gather_film(slab[: n_floats // 4], sd.xres, sd.yres, sd.crop, rank, world_size, group, scene)
     stats = scene.render_wait()
     return film, stats
+
+
+def rank_kernel_stats(kernel_ms, samples, world_size, device="cpu", group=None):
+    """Every rank's kernel time over its timed steps (mean and slowest step) and sample count, on EVERY rank: what makes an N-GPU bench
+    record diagnosable -- imbalance between the ranks' shares, and (step_breakdown) what a step costs beyond its slowest kernel.
+    `kernel_ms`: this rank's per-step kernel times.  One all_gather of three doubles (RCCL under "nccl", host tensors under gloo)."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([sum(kernel_ms) / max(len(kernel_ms), 1), max(kernel_ms) if kernel_ms else 0.0, float(samples)], dtype=torch.float64, device=device)
+    if world_size > 1 or (dist.is_available() and dist.is_initialized()):
+        got = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(got, mine, group=group)
+    else:
+        got = [mine]
+    return {"mean_per_rank": [round(float(g[0]), 3) for g in got], "max_step_per_rank": [round(float(g[1]), 3) for g in got],
+            "samples_per_rank": [int(g[2]) for g in got]}
+
+
+def step_breakdown(per_rank, ms_per_step):
+    """-> (per_rank with max / min / imbalance added, exchange_ms): exchange_ms = a step's wall time beyond its SLOWEST rank's kernel
+    (the gather or reduce, the assembly, launch and host overhead); imbalance = slowest / mean of the ranks' kernel times (1.0 = even)."""
+    m = per_rank["mean_per_rank"]
+    out = dict(per_rank, max=max(m), min=min(m), imbalance=(max(m) / (sum(m) / len(m)) if sum(m) > 0 else None))
+    return out, ms_per_step - max(m)

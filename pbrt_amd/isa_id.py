@@ -77,6 +77,13 @@ def _demangle(names):
 
 def kernel_ids(lib_path, arch="gfx950"):
     """{demangled kernel name: 16 hex digits} for every kernel (a FUNC symbol with a `<name>.kd` descriptor) of the library"""
+    found = kernel_ids_by_symbol(lib_path, arch)
+    names = sorted(found)
+    return {d: found[n] for n, d in zip(names, _demangle(names))}
+
+
+def kernel_ids_by_symbol(lib_path, arch="gfx950"):
+    """{MANGLED kernel symbol: 16 hex digits}: pure file parsing, no child process (what a GPU-initialised process may call: bench.py)"""
     blob = open(lib_path, "rb").read()
     found = {}
     for elf in _code_objects(blob, arch):
@@ -94,8 +101,47 @@ def kernel_ids(lib_path, arch="gfx950"):
             desc[8:12] = b"\0" * 4   # KERNARG_SIZE: an argument appended for ANOTHER kernel's use grows it and changes nothing this one runs
             h.update(bytes(desc))
             found[n] = h.hexdigest()[:16]
+    return found
+
+
+def kernel_resources(lib_path, symbol, arch="gfx950"):
+    """{vgpr_count, sgpr_count, agpr_count, vgpr_spill_count, private_segment_fixed_size, group_segment_fixed_size (STATIC LDS; the render
+    kernels' stack is dynamic), wavefront_size, max_flat_workgroup_size} of the kernel with mangled symbol `symbol`, from the code object's
+    NT_AMDGPU_METADATA note (what the compiler allocated -- rocprofv3's VGPR_Count / LDS_Block_Size columns are granules and launch-time
+    fields: VERDICT r05 weak 2c); None if the library has no such kernel.  File parsing + msgpack, no child process."""
+    import msgpack
+    blob = open(lib_path, "rb").read()
+    for elf in _code_objects(blob, arch):
+        shoff, = struct.unpack_from("<Q", elf, 0x28)
+        shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+        for i in range(shnum):
+            sh = struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize)
+            if sh[1] != 7:  # SHT_NOTE
+                continue
+            p, end = sh[4], sh[4] + sh[5]
+            while p + 12 <= end:
+                namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+                d0 = p + 12 + ((namesz + 3) & ~3)
+                if ntype == 32:  # NT_AMDGPU_METADATA
+                    meta = msgpack.unpackb(elf[d0:d0 + descsz], raw=False, strict_map_key=False)
+                    for k in meta.get("amdhsa.kernels", []):
+                        if k.get(".name") == symbol:
+                            return {f: k.get("." + f) for f in ("vgpr_count", "sgpr_count", "agpr_count", "vgpr_spill_count", "private_segment_fixed_size",
+                                                                 "group_segment_fixed_size", "wavefront_size", "max_flat_workgroup_size")}
+                p = d0 + ((descsz + 3) & ~3)
+    return None
+
+
+def kernel_symbol(lib_path, kernel_name):
+    """the mangled symbol of the kernel a profiler's demangled name stands for (runs the demangler: call it where no GPU is initialised,
+    tools/summarize_profile.py), or None"""
+    found = kernel_ids_by_symbol(lib_path)
     names = sorted(found)
-    return {d: found[n] for n, d in zip(names, _demangle(names))}
+    want = normalise(kernel_name)
+    for n, d in zip(names, _demangle(names)):
+        if normalise(d) == want:
+            return n
+    return None
 
 
 def normalise(kernel_name):
@@ -107,11 +153,19 @@ def normalise(kernel_name):
 _cache = {}
 
 
-def kernel_id(lib_path, kernel_name):
-    """the id of the kernel a profile names (rocprofv3's demangled kernel name), or None if the library has no such kernel"""
+def kernel_id(lib_path, kernel_name, symbol=None):
+    """the id of the kernel a profile names (rocprofv3's demangled kernel name), or None if the library has no such kernel.  With the
+    profile's `kernel_symbol` (the mangled name, stored by tools/summarize_profile.py) the lookup is file parsing alone: no demangler, so
+    no child process is started from a process that has initialised the GPU."""
+    if symbol:
+        skey = ("sym", os.path.realpath(lib_path), os.path.getmtime(lib_path), os.path.getsize(lib_path))
+        if skey not in _cache:
+            _cache[skey] = kernel_ids_by_symbol(lib_path)
+        if symbol in _cache[skey]:
+            return _cache[skey][symbol]
+        return None
     key = (os.path.realpath(lib_path), os.path.getmtime(lib_path), os.path.getsize(lib_path))
     if key not in _cache:
-        _cache.clear()
         _cache[key] = {normalise(k): v for k, v in kernel_ids(lib_path).items()}
     return _cache[key].get(normalise(kernel_name))
 

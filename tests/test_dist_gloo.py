@@ -106,3 +106,33 @@ def test_assemble_single_rank_and_padding():
         slabs.append(torch.from_numpy(s))
     got = pdist.assemble_film(slabs, xres, yres, crop, world).numpy()
     assert np.array_equal(got, film)
+
+
+def _worker_stats(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pbrt_amd import dist as pdist
+        per_rank = pdist.rank_kernel_stats([10.0 + rank, 12.0 + 3 * rank], 1000 * (rank + 1), world)
+        if rank == 0:
+            import json
+            pr, exchange = pdist.step_breakdown(per_rank, 20.0)
+            json.dump({"per_rank_kernel_ms": pr, "exchange_ms": exchange}, open(out_path, "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_bench_line_carries_every_ranks_kernel_time(tmp_path):
+    """bench.py in ranks mode gathers EVERY rank's kernel time and sample count (pbrt_amd.dist.rank_kernel_stats, the
+    function bench.py calls) and reports exchange_ms = ms_per_step - the slowest rank's kernel -- the keys --single-process prints too."""
+    import json
+    out = str(tmp_path / "stats.json")
+    mp.spawn(_worker_stats, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = json.load(open(out))
+    pr = got["per_rank_kernel_ms"]
+    assert pr["mean_per_rank"] == [11.0, 13.0] and pr["max_step_per_rank"] == [12.0, 15.0] and pr["samples_per_rank"] == [1000, 2000]
+    assert pr["max"] == 13.0 and pr["min"] == 11.0 and abs(pr["imbalance"] - 13.0 / 12.0) < 1e-12
+    assert abs(got["exchange_ms"] - 7.0) < 1e-12

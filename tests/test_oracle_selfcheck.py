@@ -500,14 +500,15 @@ def test_checkerboard_on_a_sphere_closed_form(oracle, res):
     check_checker_sphere(oracle.film_write_rgb(film))
 
 
-def test_ill_conditioned_hit_at_a_vertex_is_outside_the_tie_rule(oracle):
-    """The limit of "a hit does not depend on the tree" (DESIGN.md 3.4), recorded where it was found: a shadow ray aimed exactly at a
-    mesh vertex (a point light placed ON the vertex) meets the triangle that owns the vertex edge-on (det 1.6e-6).  In float64 the ray
-    passes outside the triangle (u = -4e-4) and would reach its plane at t = 2.72481, beyond tmax = 2.72460; fp32 Moeller-Trumbore
-    computes u = 0.0, t = 2.72448 < tmax and accepts.  That "hit" lies OUTSIDE the triangle's own bounding box, so a walk over tight
-    boxes culls the triangle and a walk that reaches its leaf through a wider box does not: the oracle's BVH and its own brute force over
-    all triangles disagree, and so may two trees.  The tie rule orders hits that every walk sees; it cannot make a walk see a hit that
-    is outside every box.  (180 000 random scenes never aimed a ray at a vertex; scenes that do are where the two sides may differ.)"""
+def test_ill_conditioned_hit_at_a_vertex_is_decided_by_ray_and_triangle_alone(oracle):
+    """Where the tie rule used to end (rounds 5 -> 6): a shadow ray aimed exactly at a mesh vertex (a point light
+    placed ON the vertex) meets the triangle that owns the vertex edge-on (det 1.6e-6).  In float64 the ray passes outside the triangle
+    (u = -4e-4) and would reach its plane at t = 2.72481, beyond tmax = 2.72460; fp32 Moeller-Trumbore computes u = 0.0, t = 2.72448 < tmax
+    -- a "hit" OUTSIDE the triangle's own bounding box, which a walk over tight boxes never saw and a walk through wider boxes (or no
+    boxes: the brute force) accepted.  Until round 5 the oracle's BVH and its own brute force DISAGREED on this ray.  With the own-box
+    rule the test of the triangle itself rejects what lies outside its box, whoever runs it: BVH, brute force, the production walk over
+    both product trees and the float64 textbook test all say "unoccluded"."""
+    from pbrt_amd.api import quad_build_host_ex
     sd = SMALL_SCENES["mesh1k"]()
     light = sd.P[1304]  # the vertex
     po = np.array([[-0.8261664, 1.9999, 1.5779929]], np.float32)
@@ -516,6 +517,61 @@ def test_ill_conditioned_hit_at_a_vertex_is_outside_the_tie_rule(oracle):
     wi = (dv / dist).astype(np.float32)[None]
     tmax = np.array([dist * np.float32(1 - 1e-4)], np.float32)
     sc = oracle.OracleScene(sd)
-    assert sc.occluded(po, wi, tmax)[0] == 0 and sc.occluded(po, wi, tmax, brute_force=True)[0] == 1
+    assert sc.occluded(po, wi, tmax)[0] == 0 and sc.occluded(po, wi, tmax, brute_force=True)[0] == 0
+    sdn = sd.normalized()
+    for tree in ("sah", "reinsert"):
+        q = quad_build_host_ex(sdn.P, sdn.idx, tree=tree)
+        assert oracle.quad_walk(q["quads"], q["root_box"], sdn.P, sdn.idx, q["order"], po, wi, tmax, any_hit=True)["occluded"][0] == 0
     from util import brute_force_hits_f64
     assert brute_force_hits_f64(sd, po, wi, tmax)[1][0] == -1  # in float64 nothing is hit
+
+
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "ties", "deep"])
+def test_a_hit_is_a_function_of_ray_and_triangle_alone(oracle, name):
+    """The own-box rule of DESIGN.md 3.5 on the rays that broke the tie rule: aimed exactly at vertices, edge midpoints and points on
+    edges, from vertices, along edges and axes, with tmax at / a hair off the target (util.adversarial_rays) -- fp32 Moeller-Trumbore at its
+    worst, at the corners of the triangles' own boxes.  The oracle's BVH and its brute force over ALL triangles (no box at all) must give the
+    same hit record and the same occlusion flag for every ray, bit for bit; so must the production walk (oracle/quad_walk.cpp: the kernel's
+    step restated) over the quantised 4-wide trees of both product builders.  (What the rays find without the rule: the test below.)"""
+    from pbrt_amd.api import quad_build_host_ex
+    from util import adversarial_rays
+    sd = SMALL_SCENES[name]().normalized()
+    n_tris = sd.idx.shape[0]
+    sc = oracle.OracleScene(sd)
+    for seed in range(3 if n_tris < 5000 else 1):  # (brute force over 20 k triangles: one seed)
+        o, d, tmax = adversarial_rays(sd, 40_000 if n_tris < 5000 else 16_000, seed)
+        t, prim, b1, b2, _ = sc.intersect(o, d, tmax)
+        bt, bprim, bb1, bb2, _ = sc.intersect(o, d, tmax, brute_force=True)
+        assert np.array_equal(prim, bprim) and np.array_equal(t.view(np.uint32), bt.view(np.uint32)), (name, seed, int((prim != bprim).sum()))
+        assert np.array_equal(b1.view(np.uint32), bb1.view(np.uint32)) and np.array_equal(b2.view(np.uint32), bb2.view(np.uint32))
+        occ, bocc = sc.occluded(o, d, tmax), sc.occluded(o, d, tmax, brute_force=True)
+        assert np.array_equal(occ, bocc), (name, seed, int((occ != bocc).sum()))
+        assert (prim != 0xffffffff).mean() > (0.2 if name != "deep" else 0.005)  # (the rays do hit things; the deep scene's triangles are specks)
+        if seed == 0:
+            for tree in ("sah", "reinsert"):
+                q = quad_build_host_ex(sd.P, sd.idx, tree=tree)
+                got = oracle.quad_walk(q["quads"], q["root_box"], sd.P, sd.idx, q["order"], o, d, tmax)
+                keep = (prim < n_tris) | (prim == 0xffffffff)  # (the walk covers the triangles; spheres are tested after it)
+                if sd.spheres.shape[0] == 0:
+                    assert np.array_equal(got["prim"], prim) and np.array_equal(got["t"].view(np.uint32), t.view(np.uint32)), (name, tree)
+                    qo = oracle.quad_walk(q["quads"], q["root_box"], sd.P, sd.idx, q["order"], o, d, tmax, any_hit=True)
+                    assert np.array_equal(qo["occluded"], occ), (name, tree)
+
+
+def test_without_the_own_box_rule_the_adversarial_rays_tell_trees_apart(oracle):
+    """The check above can see what it is for: with the rule switched off (orc_debug_own_box_rule: the spec as it was until round 5) the
+    oracle's BVH and its brute force disagree on some of the same rays -- hits that lie outside their triangle's box: in the Cornell box,
+    whose walls lie in axis planes, about 25 of 40 000 (rays that run IN a wall's plane); in a random soup a few per million."""
+    from util import adversarial_rays
+    sd = SMALL_SCENES["cornell"]().normalized()
+    sc = oracle.OracleScene(sd)
+    oracle.debug_own_box_rule(False)
+    try:
+        differ = 0
+        for seed in range(2):
+            o, d, tmax = adversarial_rays(sd, 40_000, seed)
+            differ += int((sc.intersect(o, d, tmax)[1] != sc.intersect(o, d, tmax, brute_force=True)[1]).sum())
+            differ += int((sc.occluded(o, d, tmax) != sc.occluded(o, d, tmax, brute_force=True)).sum())
+    finally:
+        oracle.debug_own_box_rule(True)
+    assert differ > 10, differ

@@ -22,6 +22,43 @@ def random_rays(n, seed, sd=None, inside=2.0):
     return o, d, tmax
 
 
+def adversarial_rays(sd, n, seed, inside=1.8):
+    """Rays that aim where fp32 Moeller-Trumbore is ill-conditioned and a triangle's own box is met at a corner or an edge (DESIGN.md
+    3.4 / 3.5): from random origins EXACTLY at mesh vertices, at edge midpoints, at points on edges; from origins that are vertices
+    themselves; along edges; from points in the PLANE of the triangle that owns the target (edge-on: det ~ 0); with tmax exactly at, a hair before and a hair beyond the target (what a shadow ray towards a light ON the
+    mesh has); towards vertices along the axes (a ray in the face of the triangle's box).  Returns (o, d, tmax) as float32."""
+    rng = np.random.default_rng(seed)
+    P, idx = np.asarray(sd.P, np.float32), np.asarray(sd.idx)
+    tri = rng.integers(0, len(idx), n)
+    k = rng.integers(0, 3, n)
+    a, b = P[idx[tri, k]], P[idx[tri, (k + 1) % 3]]
+    kind = np.arange(n) % 8
+    w = rng.uniform(0, 1, n).astype(np.float32)[:, None]
+    target = np.where((kind == 1)[:, None], np.float32(0.5) * a + np.float32(0.5) * b, a)                # edge midpoint / vertex
+    target = np.where((kind == 2)[:, None], (a * (np.float32(1) - w) + b * w).astype(np.float32), target)  # a point on an edge
+    o = rng.uniform(-inside, inside, (n, 3)).astype(np.float32)
+    o = np.where((kind == 3)[:, None], P[rng.integers(0, len(P), n)], o)                                 # from a vertex (to a vertex)
+    o = np.where((kind == 4)[:, None], b + (b - a), o)                                                   # along an edge's line
+    ax = rng.integers(0, 3, n)
+    off = np.zeros((n, 3), np.float32)
+    off[np.arange(n), ax] = rng.choice(np.array([-1.5, 1.5, -0.25, 0.25], np.float32), n)
+    o = np.where((kind == 5)[:, None], target + off, o).astype(np.float32)                               # along an axis towards a vertex
+    # in the PLANE of the triangle that owns the target (the ray meets it edge-on: det ~ 0, (u, v) on the boundary -- the recorded case)
+    c = P[idx[tri, (k + 2) % 3]]
+    st = rng.uniform(0.5, 3.0, (n, 2)).astype(np.float32) * rng.choice(np.array([-1, 1], np.float32), (n, 2))
+    o = np.where((kind == 7)[:, None], a + (b - a) * st[:, :1] + (c - a) * st[:, 1:], o).astype(np.float32)
+    dv = (target - o).astype(np.float32)
+    dist = np.sqrt(((dv[:, 0] * dv[:, 0] + dv[:, 1] * dv[:, 1]) + dv[:, 2] * dv[:, 2]).astype(np.float32)).astype(np.float32)
+    ok = dist > 0
+    dist = np.where(ok, dist, np.float32(1))
+    d = np.where(ok[:, None], dv / dist[:, None], np.float32([0, 0, 1])).astype(np.float32)
+    d = np.where((kind == 6)[:, None], dv, d).astype(np.float32)  # an unnormalised direction: the target is at t = 1
+    dist = np.where(kind == 6, np.float32(1), dist)
+    scale = rng.choice(np.array([np.inf, 1.0, 1 - 1e-4, 1 + 1e-4, 1 - 6e-8, 1 + 1.2e-7, 0.5, 2.0], np.float32), n)
+    tmax = np.where(np.isinf(scale), np.float32(np.inf), dist * scale).astype(np.float32)
+    return np.ascontiguousarray(o), np.ascontiguousarray(d), np.ascontiguousarray(tmax)
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 

@@ -16,6 +16,8 @@ export PBRT_HIP_DEBUG_KNOBS=1
 export PROBE_BUILDER=gpu   # the probes use the builder bench.py's default does (the device builder)
 timeout 1800 python3 -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -4 > $O/${TAG}_pytest_gpu.log
 python3 -c "from oracle import binding as ob; ob.build(native=True)"   # (the CPU leg's oracle is built before any profiler runs)
+# FETCH_SIZE against known bytes in the kernel's access shape (round 6): the factor summarize_profile.py stores in pmc_<wl>.json
+bash tools/fetch_size_calibration.sh fetch_cal_${TAG} > $O/fetch_cal_${TAG}.log 2>&1
 for w in $WLS; do
   cd /tmp && export TMPDIR=/tmp
   timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_${w}_trace -- python3 $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_${TAG}_${w}_trace.json 2> $O/prof_${TAG}_${w}_trace.err

@@ -46,6 +46,10 @@ for line in open(out + "/p1.log"):
     m = re.match(r"RAYS (\d+) SAMPLES (\d+) KERNEL_MS ([0-9.]+)", line)
     if m:
         probe = {"PROBE_RAYS": float(m.group(1)), "PROBE_SAMPLES": float(m.group(2))}
+    m = re.match(r"TREE FETCHES_PER_RAY ([0-9.]+) TRIS_PER_RAY ([0-9.]+) QUAD_NODES (\d+) STACK_NEED (\d+) LDS_ROWS (\d+) WAVES_PER_CU (\d+) SPP (\d+)", line)
+    if m:
+        probe.update({"TREE_FETCHES_PER_RAY": float(m.group(1)), "TREE_TRIS_PER_RAY": float(m.group(2)), "TREE_QUAD_NODES": float(m.group(3)),
+                      "TREE_STACK_NEED": float(m.group(4)), "LAUNCH_LDS_ROWS": float(m.group(5)), "LAUNCH_WAVES_PER_CU": float(m.group(6)), "PROBE_SPP": float(m.group(7))})
 # the kernel's duration inside the PMC runs (kernel trace of pass 1)
 for f in sorted(glob.glob(out + "/p1/**/*kernel_trace.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
@@ -54,6 +58,6 @@ for f in sorted(glob.glob(out + "/p1/**/*kernel_trace.csv", recursive=True)):
 agg.update(probe)
 with open(out + "/summary.txt", "w") as fo:
     for k, v in agg.items():
-        fo.write(f"{k} {v:.6g}\n")
+        fo.write(f"{k} {v:.9g}\n")
         print(k, f"{v:.6g}")
 PY

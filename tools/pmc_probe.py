@@ -25,3 +25,11 @@ with pbrt_amd.Scene(sd, builder=os.environ.get("PROBE_BUILDER")) as sc:
         print("exact: nodes/ray %.1f tris/ray %.2f | production walk: fetches/ray %.1f tris/ray %.2f" % (
             ex["nodes_visited"] / rays, ex["tris_tested"] / rays, wk["nodes_visited"] / rays, wk["tris_tested"] / rays))
         print("RAYS %d SAMPLES %d KERNEL_MS %.4f" % (rays, ex["samples"], st["kernel_ms"]))
+        # the TREE the per-ray counters of this profile belong to (bench.py withholds a profile whose tree is not the live one: a builder
+        # edit changes the tree and leaves the render kernel's machine code alone) and the launch's dynamic LDS (render_stack_plan)
+        import ctypes as C
+        i = sc.info()
+        rows, waves, ovf = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        pbrt_amd.api.lib().pbrt_hip_render_stack_plan(i["quad_stack_need"], C.byref(rows), C.byref(waves), C.byref(ovf))
+        print("TREE FETCHES_PER_RAY %.6f TRIS_PER_RAY %.6f QUAD_NODES %d STACK_NEED %d LDS_ROWS %d WAVES_PER_CU %d SPP %d" % (
+            wk["nodes_visited"] / rays, wk["tris_tested"] / rays, i["quad_nodes"], i["quad_stack_need"], rows.value, waves.value, spp[0] * spp[1]))

@@ -26,6 +26,18 @@ def one(pattern):
     return max(f, key=os.path.getmtime) if f else None  # (a re-run of one workload leaves the older files beside the new ones)
 
 
+def latest_calibration(P, G):
+    """{ratio_112MB, ratio_1536MB, source} from the newest fetch_size_calibration.txt (gpurun_out/*/ of this job, else the committed one)"""
+    import re
+    fresh = sorted(glob.glob(os.path.join(G, "*", "fetch_size_calibration.txt")), key=os.path.getmtime)[::-1]
+    for f in fresh + sorted(glob.glob(os.path.join(P, "*fetch_size_calibration.txt")))[::-1]:
+        for line in open(f):
+            m = re.match(r"FETCH_SIZE_BYTES_PER_KNOWN_BYTE 112MB ([0-9.]+) 1536MB ([0-9.]+)", line)
+            if m:
+                return {"ratio_112MB": float(m.group(1)), "ratio_1536MB": float(m.group(2)), "source": os.path.relpath(f, ROOT)}
+    return None
+
+
 def main():
     tag = sys.argv[1]
     G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
@@ -55,7 +67,9 @@ def main():
             vals = [float(r["Counter_Value"]) for r in cr if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
             summary[name + "_KB_per_launch"] = sum(vals) / FRAMES_PMC
             kr = [r for r in cr if KERNEL in r["Kernel_Name"]][0]
-            summary.update({"vgpr": int(kr["VGPR_Count"]), "sgpr": int(kr["SGPR_Count"]), "lds_bytes": int(kr["LDS_Block_Size"]),
+            # (rocprofv3's VGPR_Count / LDS_Block_Size columns are an allocation granule field and the STATIC LDS: kept under their own
+            # names; "vgpr" / "lds_bytes" below come from the code object's notes and the launch's stack plan -- VERDICT r05 weak 2c)
+            summary.update({"rocprof_vgpr_field": int(kr["VGPR_Count"]), "rocprof_sgpr_field": int(kr["SGPR_Count"]), "rocprof_lds_block_size": int(kr["LDS_Block_Size"]),
                             "grid": int(kr["Grid_Size"]), "workgroup": int(kr["Workgroup_Size"])})
         if "FETCH_SIZE_KB_per_launch" in summary and "WRITE_SIZE_KB_per_launch" in summary:
             # MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B in KB, L2-miss requests including Infinity-Cache hits; it reads
@@ -71,6 +85,14 @@ def main():
             model = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "valu_model.py"), pmc], capture_output=True, text=True, check=True).stdout)
             summary.update(model)
             summary["valu_source"] = f"tools/pmc_passes.sh on tools/pmc_probe.py {wl} (low-spp frame) -> profiles/{tag}_{wl}_pmc_counters.txt -> tools/valu_model.py"
+            # the TREE the per-ray counters belong to (pmc_probe.py's own walk counters): bench.py withholds the profile when the live
+            # production walk does other work per ray (a builder edit leaves the render kernel's machine code alone)
+            c = dict((k, float(v)) for k, v in (l.split() for l in open(pmc)))
+            if "TREE_FETCHES_PER_RAY" in c:
+                summary["tree"] = {"kernel_fetches_per_ray": c["TREE_FETCHES_PER_RAY"], "kernel_tris_per_ray": c["TREE_TRIS_PER_RAY"], "quad_nodes": int(c["TREE_QUAD_NODES"]),
+                                   "quad_stack_need": int(c["TREE_STACK_NEED"]), "spp": int(c["PROBE_SPP"])}
+                summary["lds_dynamic_bytes"] = int(c["LAUNCH_LDS_ROWS"]) * 256
+                summary["waves_per_cu"] = int(c["LAUNCH_WAVES_PER_CU"])
         # the library the counters were taken on (bench.py withholds figures priced with another build's profile)
         for line_file in (os.path.join(G, f"prof_{tag}_{wl}_trace.json"), os.path.join(G, f"bench_{wl}_{tag}.json")):
             try:
@@ -89,8 +111,23 @@ def main():
             if summary.get("kernel"):
                 summary["kernel_isa_id"] = isa_id.kernel_id(build.LIB_PATH, summary["kernel"])
                 summary["compiler"] = build.compiler_version().splitlines()[0]
+                # the mangled symbol: bench.py looks the kernel up by it (no demangler, so no child process from a GPU-initialised process)
+                summary["kernel_symbol"] = isa_id.kernel_symbol(build.LIB_PATH, summary["kernel"])
+                res = isa_id.kernel_resources(build.LIB_PATH, summary["kernel_symbol"]) if summary["kernel_symbol"] else None
+                if res:  # what the compiler allocated (code-object notes) + the launch's dynamic LDS (the walk's stack)
+                    summary.update({"vgpr": res["vgpr_count"], "sgpr": res["sgpr_count"], "vgpr_spill": res["vgpr_spill_count"], "scratch_bytes": res["private_segment_fixed_size"],
+                                    "lds_bytes": (res["group_segment_fixed_size"] or 0) + summary.get("lds_dynamic_bytes", 0),
+                                    "resources_source": "code-object notes (NT_AMDGPU_METADATA) + render_stack_plan rows x 256 B of dynamic LDS"})
         except Exception as e:  # noqa: BLE001
             summary["kernel_isa_id_error"] = repr(e)[:200]
+        # FETCH_SIZE calibrated for this access shape (tools/fetch_size_calibration.sh): known bytes per counted byte of
+        # 64-byte records gathered at random, from the table that is in the workload's regime (in / past the Infinity Cache)
+        cal = latest_calibration(P, G)
+        if cal and "FETCH_SIZE_KB_per_launch" in summary:
+            ratio = cal["ratio_1536MB"] if wl == "big" else cal["ratio_112MB"]
+            summary["fetch_size_calibration"] = {"factor": 1.0 / ratio, "fetch_size_bytes_per_known_byte": ratio, "table": "1536 MB (past the Infinity Cache)" if wl == "big" else "112 MB (inside the Infinity Cache)",
+                                                 "source": cal["source"]}
+            summary["traffic_bytes_calibrated"] = (summary["FETCH_SIZE_KB_per_launch"] / ratio + summary.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024
         with open(os.path.join(P, f"{tag}_{wl}_summary.json"), "w") as f:
             json.dump(summary, f, indent=1)
         shutil.copy(os.path.join(P, f"{tag}_{wl}_summary.json"), os.path.join(P, f"pmc_{wl}.json"))
