@@ -315,9 +315,10 @@ class OracleScene:
 
     def bvh(self):
         n = self.l.orc_bvh_node_count(self.h)
-        nodes = np.zeros((max(n, 1), 8), np.uint32); order = np.zeros(max(self.sd.idx.shape[0], 1), np.uint32)
+        n_prims = int(self.sd.idx.shape[0]) + int(self.sd.spheres.shape[0])  # the triangles, then the spheres (primitive n_tris + s)
+        nodes = np.zeros((max(n, 1), 8), np.uint32); order = np.zeros(max(n_prims, 1), np.uint32)
         self.l.orc_bvh_export(self.h, _p(nodes), _p(order))
-        return nodes[:n], order[:self.sd.idx.shape[0]], self.l.orc_bvh_depth(self.h)
+        return nodes[:n], order[:n_prims], self.l.orc_bvh_depth(self.h)
 
     def light_count(self):
         return self.l.orc_light_count(self.h)

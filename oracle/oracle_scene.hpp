@@ -217,10 +217,18 @@ class Scene {
     return me;
   }
 
+  // A sphere's own box: [c - r, c + r] per component in fp32 -- what the builder bounds it by and what the own-box rule tests
+  static void sphere_box(const orc_sphere &sp, Vec3 *lo, Vec3 *hi) {
+    *lo = {sp.c[0] - sp.r, sp.c[1] - sp.r, sp.c[2] - sp.r};
+    *hi = {sp.c[0] + sp.r, sp.c[1] + sp.r, sp.c[2] + sp.r};
+  }
+
+  // The primitives of the tree: the triangles, then the spheres (primitive n_tris + s: round 6 -- until round 5 every ray tested every
+  // sphere after the walk), each bounded by its box, centroid = the box's centre.
   void build_bvh() {
-    uint32_t nt = n_tris();
-    if (nt == 0) return;
-    std::vector<PrimInfo> pi(nt);
+    const uint32_t nt = n_tris(), np = nt + (uint32_t)spheres.size();
+    if (np == 0) return;
+    std::vector<PrimInfo> pi(np);
     for (uint32_t t = 0; t < nt; t++) {
       Vec3 p0, p1, p2;
       tri_verts(t, &p0, &p1, &p2);
@@ -230,9 +238,18 @@ class Scene {
       pi[t].b = b;
       pi[t].c = b.pmin * 0.5f + b.pmax * 0.5f;
     }
-    order.reserve(nt);
-    bnodes.reserve(2 * (size_t)nt);
-    recursive_build(pi, 0, nt, 0);
+    for (uint32_t s = 0; s < spheres.size(); s++) {
+      Vec3 lo, hi;
+      sphere_box(spheres[s], &lo, &hi);
+      Bounds3 b;
+      b = Union(b, lo); b = Union(b, hi);
+      pi[nt + s].id = nt + s;
+      pi[nt + s].b = b;
+      pi[nt + s].c = b.pmin * 0.5f + b.pmax * 0.5f;
+    }
+    order.reserve(np);
+    bnodes.reserve(2 * (size_t)np);
+    recursive_build(pi, 0, np, 0);
     nodes.reserve(bnodes.size());
     flatten(0);
     bnodes.clear();
@@ -298,8 +315,19 @@ class Scene {
       th = t1;
       if (!(th > kRayTMin && th < r.tmax)) return false;
     }
+    // the own-box rule on the sphere's box [c - r, c + r]: the "vertices" lo, hi, lo
+    Vec3 lo, hi;
+    sphere_box(sp, &lo, &hi);
+    if (!in_own_box(lo, hi, lo, r, th)) return false;
     *tt = th;
     return true;
+  }
+
+  // one primitive of a leaf: triangle t < n_tris, else sphere t - n_tris (u = v = 0)
+  bool prim_intersect(uint32_t t, const Ray &r, float *tt, float *uu, float *vv) const {
+    if (t < n_tris()) return tri_intersect(t, r, tt, uu, vv);
+    *uu = 0.f; *vv = 0.f;
+    return sphere_intersect(t - n_tris(), r, tt);
   }
 
   // Bounds3::IntersectP: slab test against [kRayTMin, tfar].  Near / far plane per axis chosen by
@@ -341,7 +369,7 @@ class Scene {
               uint32_t t = order[n.offset + i];
               if (ctr) ctr->tris++;
               float tt, u, v;
-              if (tri_intersect(t, r, &tt, &u, &v)) consider(&h, tt, t, u, v);
+              if (prim_intersect(t, r, &tt, &u, &v)) consider(&h, tt, t, u, v);
             }
             if (sp == 0) break;
             cur = stack[--sp];
@@ -357,10 +385,6 @@ class Scene {
           cur = stack[--sp];
         }
       }
-    }
-    for (uint32_t s = 0; s < spheres.size(); s++) {
-      float tt;
-      if (sphere_intersect(s, r, &tt)) consider(&h, tt, n_tris() + s, 0.f, 0.f);
     }
     return h;
   }
@@ -381,7 +405,7 @@ class Scene {
             for (uint32_t i = 0; i < n.n_prims; i++) {
               if (ctr) ctr->tris++;
               float tt, u, v;
-              if (tri_intersect(order[n.offset + i], r, &tt, &u, &v)) return true;
+              if (prim_intersect(order[n.offset + i], r, &tt, &u, &v)) return true;
             }
             if (sp == 0) break;
             cur = stack[--sp];
@@ -397,10 +421,6 @@ class Scene {
           cur = stack[--sp];
         }
       }
-    }
-    for (uint32_t s = 0; s < spheres.size(); s++) {
-      float tt;
-      if (sphere_intersect(s, r, &tt)) return true;
     }
     return false;
   }

@@ -381,10 +381,10 @@ class Scene:
         n = C.c_uint32()
         check(lib().pbrt_hip_scene_export_quads(self._h, None, 0, C.byref(n), None), "pbrt_hip_scene_export_quads")
         quads = np.zeros((max(n.value, 1), 16), np.uint32)
-        order = np.zeros(max(self.sd.idx.shape[0], 1), np.uint32)
+        order = np.zeros(max(self.n_prims, 1), np.uint32)
         check(lib().pbrt_hip_scene_export_quads(self._h, _u32p(quads), quads.shape[0], C.byref(n), _u32p(order)),
               "pbrt_hip_scene_export_quads")
-        return quads[:n.value], order[:self.sd.idx.shape[0]]
+        return quads[:n.value], order[:self.n_prims]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -399,6 +399,11 @@ class Scene:
     def __exit__(self, *a):
         self.close()
 
+    @property
+    def n_prims(self):
+        """primitives of the tree: the triangles, then the spheres (primitive n_tris + s)"""
+        return int(self.sd.idx.shape[0]) + int(self.sd.spheres.shape[0])
+
     def info(self):
         nn, depth, nl, nb = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
         check(lib().pbrt_hip_scene_info(self._h, C.byref(nn), C.byref(depth), C.byref(nl), C.byref(nb)),
@@ -411,9 +416,9 @@ class Scene:
     def export_bvh(self):
         i = self.info()
         nodes = np.zeros((max(i["n_nodes"], 1), 8), np.uint32)
-        order = np.zeros(max(self.sd.idx.shape[0], 1), np.uint32)
+        order = np.zeros(max(self.n_prims, 1), np.uint32)
         check(lib().pbrt_hip_scene_export_bvh(self._h, _u32p(nodes), _u32p(order)), "pbrt_hip_scene_export_bvh")
-        return nodes[:i["n_nodes"]], order[:self.sd.idx.shape[0]]
+        return nodes[:i["n_nodes"]], order[:self.n_prims]
 
     def render(self, integrator=INTEGRATOR_PATH, max_depth=5, spp=(1, 1), seed=0, rank=0, world_size=1,
                counters=False, **kw):

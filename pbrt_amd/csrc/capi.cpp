@@ -220,6 +220,8 @@ struct QuadChild {
   uint32_t leaf_node;  // binary leaf to expand into its own quad node, or 0xffffffff
 };
 enum Collapse { kCollapsePlain = 0, kCollapseGreedy = 1, kCollapseDp = 2 };
+// EXPERIMENT (round 6, PBRT_HIP_REINSERT_QUADW; build_production_quads): when set, the collapse marks the binary nodes it keeps as quad nodes
+static std::vector<uint8_t> *g_collapse_marks = nullptr;
 // `b`: the binary tree over triangle references (the canonical tree through refs_of_bvh, or the optimised single-triangle tree of
 // single_ref_tree + reinsert_optimize_batch); slot_of_ref[r] = slot of reference r's triangle in the leaf-ordered triangle records (null: r itself).
 void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split_leaves, Collapse how, QuadNodes *out) {
@@ -324,6 +326,7 @@ void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split
     const Item it = todo.back();
     todo.pop_back();
     const BvhNode &me = b.nodes[it.node];
+    if (g_collapse_marks && !it.is_leaf) (*g_collapse_marks)[it.node] = 1;
     QuadChild kids[4];
     int nk = 0;
     auto add_node = [&](uint32_t c) {
@@ -578,6 +581,38 @@ void build_production_quads(const Bvh &canon, const float *P, const uint32_t *id
     single_ref_tree(canon, P, idx, &rb);
     const ReinsertBatchParams rp = reinsert_batch_params();
     if (n_tris >= rp.stop.min_tris) reinsert_optimize_batch(&rb, rp);  // (smaller trees stay as built, as on the device)
+    // EXPERIMENT (round 6, simulator only: tools/walk_sim.py): re-insertion scored by the 4-WIDE tree.  The binary pass
+    // minimises the summed area of ALL interior nodes; the walk pays only for the ones the collapse keeps as quad nodes.  Rounds of
+    // {collapse -> weight 1 for the kept nodes, w_low for the absorbed ones -> a few weighted passes}.  PBRT_HIP_REINSERT_QUADW=w_low:rounds:passes
+    if (const char *qw = debug_knob("PBRT_HIP_REINSERT_QUADW")) {
+      float w_low = 0.5f;
+      int rounds = 2, passes = 3;
+      std::sscanf(qw, "%f:%d:%d", &w_low, &rounds, &passes);
+      for (int r = 0; r < rounds && n_tris >= rp.stop.min_tris; r++) {
+        std::vector<uint8_t> marks(rb.nodes.size(), 0);
+        QuadNodes tmp;
+        g_collapse_marks = &marks;
+        make_quad_nodes_as(rb, nullptr, true, kCollapseDp, &tmp);
+        g_collapse_marks = nullptr;
+        LinkTree lt;
+        link_tree_of(rb, &lt);
+        std::vector<float> w(2 * (size_t)lt.n_int + 1, 1.0f);
+        uint32_t next = 0;  // (link_tree_of numbers the interior nodes in depth-first order)
+        size_t kept = 0;
+        for (size_t i = 0; i < rb.nodes.size(); i++)
+          if ((rb.nodes[i].count_axis & 0xffffu) == 0) { w[next++] = marks[i] ? 1.0f : w_low; kept += marks[i]; }
+        ReinsertBatchParams wp = rp;
+        wp.passes = passes;
+        wp.search.w = w.data();
+        ReinsertBatchStats st;
+        reinsert_batch_links(&lt, wp, &st);
+        RefBvh o;
+        ref_bvh_of(lt, rb, &o);
+        rb = std::move(o);
+        if (std::getenv("PBRT_HIP_REINSERT_VERBOSE"))
+          std::fprintf(stderr, "quad-weighted round %d: %zu of %u interior nodes kept by the collapse, %llu moves applied\n", r, kept, lt.n_int, (unsigned long long)st.applied);
+      }
+    }
     if (std::getenv("PBRT_HIP_REINSERT_VERBOSE")) {
       LinkTree lt;
       link_tree_of(rb, &lt);
@@ -602,7 +637,7 @@ int ensure_canonical(pbrt_hip_scene *s) {
   if (s->canonical_ready) return PBRT_HIP_OK;
   if (!s->gpu_built) { s->dev_exact = s->dev; s->canonical_ready = true; return PBRT_HIP_OK; }
   const auto t0 = std::chrono::steady_clock::now();
-  const uint32_t nt = s->dev.n_tris;
+  const uint32_t nt = s->n_prims;  // (triangles + the spheres' proxy triangles)
   std::vector<float> P(s->d_P.n);
   std::vector<uint32_t> idx(s->d_idx.n);
   HIP_TRY(hipSetDevice(s->device));
@@ -619,7 +654,7 @@ int ensure_canonical(pbrt_hip_scene *s) {
   HIP_TRY(s->d_tris_exact.alloc(kTriStride * (size_t)nt));
   if (!pairs.q.empty()) HIP_TRY(hipMemcpyAsync(s->d_nodes.p, pairs.q.data(), pairs.q.size() * 16, hipMemcpyHostToDevice, s->stream));
   if (nt) HIP_TRY(hipMemcpyAsync(s->d_order_exact.p, s->bvh.order.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order_exact.p, nt, s->d_tris_exact.p, s->stream));
+  HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order_exact.p, nt, s->dev.n_tris, s->d_spheres.p, s->d_tris_exact.p, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->dev.nodes = s->d_nodes.p;  // (the pre-canonical allocation was empty and has just been released: no stale pointer is kept)
   s->device_bytes += s->d_nodes.n * 16 + s->d_tris_exact.n * 16 + s->d_order_exact.n * 4;
@@ -719,6 +754,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     if ((d->n_tris || d->n_spheres) && (!d->mats || d->n_mats == 0)) return fail(PBRT_HIP_ERR_INVALID, "scene_create: no materials");
     if (d->n_mats > 65536) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 65536 materials");
     if (d->n_tris > (1u << 24)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 2^24 triangles (leaf references hold a 24-bit slot)");
+    if ((uint64_t)d->n_tris + d->n_spheres > (1u << 24)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: more than 2^24 primitives (triangles + spheres; leaf references hold a 24-bit slot)");
+    if (d->n_spheres && !d->spheres) return fail(PBRT_HIP_ERR_INVALID, "scene_create: n_spheres > 0 but no sphere table");
     for (size_t i = 0; i < 3 * (size_t)d->n_tris; i++)
       if (d->idx[i] >= d->n_verts) return fail(PBRT_HIP_ERR_INVALID, "scene_create: vertex index out of range");
     for (uint32_t t = 0; t < d->n_tris; t++)
@@ -808,11 +845,43 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     } else if (want_gpu) {
       flags |= PBRT_HIP_SCENE_GPU_BUILD;  // (PBRT_HIP_SCENE_PLAIN_TREE alone qualifies the default)
     }
-    s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && d->n_tris >= 2;
+    // Spheres are PRIMITIVES OF THE TREE (round 6; until round 5 every ray tested every sphere after the walk).  Every builder here --
+    // the host's binned SAH, the device builder, the collapse, the lazily built canonical tree -- bounds a primitive by the box of its
+    // three vertices, so sphere s enters the vertex / index buffers as a degenerate PROXY TRIANGLE (c - r, c + r, c - r): primitive
+    // n_tris + s, bounded by exactly the sphere's box [c - r, c + r] (fp32 per component: the oracle's sphere_box), centroid its centre.
+    // Its leaf record is a sphere's (pack_tris_kernel) and the leaf pass runs the sphere test on it (trav_run<..., SPH>).
+    const uint32_t np = d->n_tris + d->n_spheres;
+    std::vector<float> P_aug;
+    std::vector<uint32_t> idx_aug;
+    std::vector<uint16_t> mat_aug;
+    const float *bP = d->P;
+    const uint32_t *bidx = d->idx;
+    const uint16_t *bmat = d->mat_id;
+    uint32_t n_verts_b = d->n_verts;
+    if (d->n_spheres) {
+      P_aug.assign(d->P, d->P + (d->n_tris ? 3 * (size_t)d->n_verts : 0));
+      if (!d->n_tris) n_verts_b = 0;
+      idx_aug.assign(d->idx, d->idx + 3 * (size_t)d->n_tris);
+      mat_aug.assign(d->mat_id, d->mat_id + d->n_tris);
+      for (uint32_t i = 0; i < d->n_spheres; i++) {
+        const pbrt_hip_sphere &sp = d->spheres[i];
+        const uint32_t v0 = n_verts_b + 2 * i;
+        for (int k = 0; k < 3; k++) P_aug.push_back(sp.c[k] - sp.r);
+        for (int k = 0; k < 3; k++) P_aug.push_back(sp.c[k] + sp.r);
+        idx_aug.push_back(v0); idx_aug.push_back(v0 + 1); idx_aug.push_back(v0);
+        mat_aug.push_back((uint16_t)sp.mat);
+        if (!std::isfinite(sp.c[0] - sp.r) || !std::isfinite(sp.c[0] + sp.r) || !std::isfinite(sp.c[1] - sp.r) || !std::isfinite(sp.c[1] + sp.r) ||
+            !std::isfinite(sp.c[2] - sp.r) || !std::isfinite(sp.c[2] + sp.r))
+          return fail(PBRT_HIP_ERR_INVALID, "scene_create: a sphere's bounding box is not finite");
+      }
+      n_verts_b += 2 * d->n_spheres;
+      bP = P_aug.data(); bidx = idx_aug.data(); bmat = mat_aug.data();
+    }
+    s->gpu_built = (flags & PBRT_HIP_SCENE_GPU_BUILD) && np >= 2;
     PairNodes pairs;
     if (!s->gpu_built) {
       const auto t0 = std::chrono::steady_clock::now();
-      build_bvh(d->P, d->idx, d->n_tris, &s->bvh);
+      build_bvh(bP, bidx, np, &s->bvh);
       if (s->bvh.depth > 64) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: BVH deeper than the 64-entry traversal stack");
       std::string why;
       if (!make_pair_nodes(s->bvh, &pairs, &why)) return fail(PBRT_HIP_ERR_LIMIT, "scene_create: " + why);
@@ -870,8 +939,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     }
 
     // --- upload: vertex / index buffers, flattened nodes, leaf order; pack leaf records on device ---
-    const uint32_t nt = d->n_tris;
-    HIP_TRY(s->d_P.alloc(3 * (size_t)d->n_verts));
+    const uint32_t nt = np;  // primitives: the triangles + the spheres' proxies (D.n_tris below stays the TRIANGLES: primitive ids >= it are spheres)
+    HIP_TRY(s->d_P.alloc(3 * (size_t)n_verts_b));
     HIP_TRY(s->d_idx.alloc(3 * (size_t)nt));
     HIP_TRY(s->d_mat_id.alloc(nt));
     HIP_TRY(s->d_order.alloc(nt));
@@ -879,7 +948,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     if (!s->gpu_built) {
       const auto t0 = std::chrono::steady_clock::now();
       const char *sl = debug_knob("PBRT_HIP_SPLIT_LEAVES");
-      build_production_quads(s->bvh, d->P, d->idx, d->n_tris, (flags & PBRT_HIP_SCENE_OPTIMIZED_TREE) ? kTreeReinsert : production_tree_default(),
+      build_production_quads(s->bvh, bP, bidx, np, (flags & PBRT_HIP_SCENE_OPTIMIZED_TREE) ? kTreeReinsert : production_tree_default(),
                              !(sl && sl[0] == '0'), &quads);
       s->build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -897,9 +966,9 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       if (!bytes) return hipSuccess;
       return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream);
     };
-    HIP_TRY(up(s->d_P.p, d->P, s->d_P.n * 4));
-    HIP_TRY(up(s->d_idx.p, d->idx, s->d_idx.n * 4));
-    HIP_TRY(up(s->d_mat_id.p, d->mat_id, s->d_mat_id.n * 2));
+    HIP_TRY(up(s->d_P.p, bP, s->d_P.n * 4));
+    HIP_TRY(up(s->d_idx.p, bidx, s->d_idx.n * 4));
+    HIP_TRY(up(s->d_mat_id.p, bmat, s->d_mat_id.n * 2));
     GpuBuildInfo gb{};
     if (s->gpu_built) {
       HIP_TRY(gpu_build_quads(s->d_P.p, s->d_idx.p, nt, s->d_order.p, s->d_quads.p, nt, (flags & PBRT_HIP_SCENE_PLAIN_TREE) ? 0u : kGpuBuildReinsert, &gb,
@@ -921,7 +990,7 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
     HIP_TRY(up(s->d_mats.p, mats.data(), mats.size() * 16));
     HIP_TRY(up(s->d_lights.p, lights.data(), lights.size() * 16));
     HIP_TRY(up(s->d_spheres.p, spheres.data(), spheres.size() * 16));
-    HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order.p, nt, s->d_tris.p, s->stream));
+    HIP_TRY(launch_pack_tris(s->d_P.p, s->d_idx.p, s->d_mat_id.p, s->d_order.p, nt, d->n_tris, s->d_spheres.p, s->d_tris.p, s->stream));
     if (textured || textured_sph) {  // corner (u, v) into leaf-slot order (whichever builder made d_order), the texture table as 3 x 16 B records
       std::vector<float4> tex(3 * (size_t)d->n_textures);
       for (uint32_t i = 0; i < d->n_textures; i++) {
@@ -933,10 +1002,10 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       HIP_TRY(s->d_textures.alloc(tex.size()));
       HIP_TRY(up(s->d_textures.p, tex.data(), tex.size() * 16));
       if (textured) {
-        HIP_TRY(s->d_tri_uv_in.alloc(6 * (size_t)nt));
+        HIP_TRY(s->d_tri_uv_in.alloc(6 * (size_t)d->n_tris));
         HIP_TRY(s->d_tri_uv.alloc(3 * (size_t)nt));
-        HIP_TRY(up(s->d_tri_uv_in.p, d->tri_uv, 24 * (size_t)nt));
-        HIP_TRY(launch_pack_uv(s->d_tri_uv_in.p, s->d_order.p, nt, s->d_tri_uv.p, s->stream));
+        HIP_TRY(up(s->d_tri_uv_in.p, d->tri_uv, 24 * (size_t)d->n_tris));
+        HIP_TRY(launch_pack_uv(s->d_tri_uv_in.p, s->d_order.p, nt, d->n_tris, s->d_tri_uv.p, s->stream));
       }
       HIP_TRY(hipStreamSynchronize(s->stream));  // (tex is a local)
     }
@@ -963,7 +1032,8 @@ int pbrt_hip_scene_create_ex(const pbrt_hip_scene_desc *d, int device, uint32_t 
       s->n_quads_gpu = gb.n_quads;
     }
     D.inv_parallel = inv_parallel_for_extent(std::max(D.root_hi[0] - D.root_lo[0], std::max(D.root_hi[1] - D.root_lo[1], D.root_hi[2] - D.root_lo[2])));
-    D.n_tris = nt;
+    D.n_tris = d->n_tris;  // (the triangles: a hit's primitive id >= this is sphere id - n_tris)
+    s->n_prims = nt;
     D.n_spheres = d->n_spheres;
     D.n_lights = s->n_lights;
     D.n_lights_f = (float)s->n_lights;

@@ -62,6 +62,7 @@ struct pbrt_hip_scene {
   bool pending = false;
   bool pending_counters = false;
   uint32_t n_quads_gpu = 0;
+  uint32_t n_prims = 0;  // primitives of the tree: dev.n_tris triangles + the spheres (whose places in d_P / d_idx are proxy triangles: capi.cpp)
   bool gpu_built = false;  // accelerator built on the device: the canonical tree (counter flags) is made on first use
   // The canonical walk's view of a device-built scene (pbrt_hip::ensure_canonical): the oracle's binary tree, built on the
   // host from the vertex / index buffers read back from the device, and triangle records in ITS leaf order.  For a

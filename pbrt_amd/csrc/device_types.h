@@ -8,7 +8,8 @@
 //             (leaf order, so the <=4 triangles of a leaf are one contiguous 48..192 B run)
 //   mats    : 2 x 16 B per material   {type, k.xyz} {le.xyz, 0}
 //   lights  : 5 x 16 B per light      {type, p0.xyz} {p1.xyz, area} {p2.xyz, 0} {c.xyz, 0} {n.xyz, 0}
-//   spheres : 2 x 16 B per sphere     {c.xyz, r} {material id, 0, 0, 0}
+//   spheres : 2 x 16 B per sphere     {c.xyz, r} {material id, 0, 0, 0}   (shading; in the tree a sphere is a leaf record of `tris`:
+//             {c.xyz, primitive id} {r, 0, 0, material id} {0, 0, 0, 1} -- word 3 of the third float4 flags it)
 #pragma once
 #include <stdint.h>
 
@@ -201,10 +202,11 @@ hipError_t launch_render(const DevScene &S, const RenderParams &R, uint32_t n_lo
 hipError_t launch_film_from_acc(const unsigned long long *acc, float4 *film, size_t n_px, hipStream_t stream);
 hipError_t launch_acc_add(unsigned long long *dst, const unsigned long long *src, size_t n, hipStream_t stream);  // dst[i] += src[i]
 hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, uint32_t bvh_depth, hipStream_t stream);
+// (n_prims = n_tris + the spheres, whose records come from the `spheres` table: kernels.hip pack_tris_kernel)
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
-                            uint32_t n_tris, float4 *tris, hipStream_t stream);
+                            uint32_t n_prims, uint32_t n_tris, const float4 *spheres, float4 *tris, hipStream_t stream);
 // corner (u, v) of every triangle (6 floats, triangle order) -> leaf-slot order
-hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n_tris, float2 *out, hipStream_t stream);
+hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n_prims, uint32_t n_tris, float2 *out, hipStream_t stream);
 // adds the K partial sums of every pixel of a rank's slab in chunk order and converts to XYZ (Film::merge_film_tile)
 hipError_t launch_merge(const float4 *partials, float4 *slab, int32_t w, int32_t h, uint32_t rank, uint32_t world,
                         uint32_t n_local_super, uint32_t spp, hipStream_t stream, uint32_t j0 = 0, uint32_t jstride = 1);

@@ -192,8 +192,7 @@ __device__ __forceinline__ bool quadratic(float af, float bf, float cf, float &t
   return true;
 }
 
-__device__ __forceinline__ bool sphere_hit(const DevScene &S, uint32_t s, V3 o, V3 d, float tmax, float &th) {
-  float4 cr = S.spheres[2 * s];
+__device__ __forceinline__ bool sphere_hit(const float4 cr, V3 o, V3 d, float tmax, float &th) {  // cr = {centre, radius}
   V3 oc = o - xyz(cr);
   float a = dot(d, d);
   float b = 2.0f * dot(d, oc);
@@ -372,7 +371,8 @@ __device__ __forceinline__ void trav_begin(const DevScene &S, Trav &T, uint32_t 
 //     lanes keep their state and resume on the next call.
 // `__ballot` + popcount make both decisions wave-uniform.  `alive`: this lane has work for the
 // caller once its walk is over.
-template <bool EXACT, bool COUNT, uint32_t OVFR, int STEPS = PBRT_STEPS_PER_CHECK>
+// SPH: the scene has spheres -- leaf records flagged as such (pack_tris_kernel: word 3 of the third float4) take the sphere test
+template <bool EXACT, bool COUNT, uint32_t OVFR, int STEPS = PBRT_STEPS_PER_CHECK, bool SPH = false>
 __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *stk, float *stkt, uint32_t *ovf,
                                          const bool alive, const TravTuning tune, unsigned long long &cn,
                                          unsigned long long &ct) {
@@ -620,17 +620,33 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const float otf = fminf(fminf(fmaxf(fmaxf(x0, x1), x2), fmaxf(fmaxf(y0, y1), y2)), fminf(fmaxf(fmaxf(z0, z1), z2), th));
           const bool in_own_box = otn <= otf * kOwnPad;
 #endif
-          const bool valid = in_own_box && !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax);
+          bool valid = in_own_box && !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax);
+          float ht = th, hu = u, hv = v;
+          if (SPH && __float_as_uint(c.w) != 0u) {
+            // a SPHERE's record (round 6: spheres are primitives of the tree): {centre, primitive id}{radius, -, -, material}
+            // {-, -, -, 1}.  Sphere::Intersect with the f64 quadratic of lib.rs:181-203, then the own-box rule on [c - r, c + r] (the
+            // "vertices" lo, hi, lo) exactly as for a triangle.
+            const float r = b.x;
+            float ts = 0.f;
+            valid = sphere_hit(make_float4(a.x, a.y, a.z, r), o, d, T.tmax, ts);
+            const V3 lo = {a.x - r, a.y - r, a.z - r}, hi = {a.x + r, a.y + r, a.z + r};
+            const float sx0 = (lo.x - o.x) * inv1.x, sx1 = (hi.x - o.x) * inv1.x, sy0 = (lo.y - o.y) * inv1.y, sy1 = (hi.y - o.y) * inv1.y;
+            const float sz0 = (lo.z - o.z) * inv1.z, sz1 = (hi.z - o.z) * inv1.z;
+            const float stn = fmaxf(fmaxf(fminf(fminf(sx0, sx1), sx0), fminf(fminf(sy0, sy1), sy0)), fmaxf(fminf(fminf(sz0, sz1), sz0), kRayTMin));
+            const float stf = fminf(fminf(fmaxf(fmaxf(sx0, sx1), sx0), fmaxf(fmaxf(sy0, sy1), sy0)), fminf(fmaxf(fmaxf(sz0, sz1), sz0), ts));
+            valid = valid && stn <= stf * kOwnPad;
+            ht = ts; hu = 0.f; hv = 0.f;
+          }
           const uint32_t id = __float_as_uint(a.w);
           const bool occl = valid && T.any != 0u;  // any-hit ray: the walk ends at the first valid hit
-          const bool closer = valid && T.any == 0u && (th < T.h.t || (th == T.h.t && id < T.h.prim));
+          const bool closer = valid && T.any == 0u && (ht < T.h.t || (ht == T.h.t && id < T.h.prim));
           T.any = occl ? 3u : T.any;
           stop = stop || occl;
-          T.h.t = closer ? th : T.h.t;
+          T.h.t = closer ? ht : T.h.t;
           T.h.prim = closer ? id : T.h.prim;
           T.h.slot = closer ? slot : T.h.slot;
-          T.h.b1 = closer ? u : T.h.b1;
-          T.h.b2 = closer ? v : T.h.b2;
+          T.h.b1 = closer ? hu : T.h.b1;
+          T.h.b2 = closer ? hv : T.h.b2;
         }
       }
       EXP_LEAF_PREFETCH_END();
@@ -645,24 +661,6 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           trav_enter(T, trav_pop<EXACT, OVFR>(T, stk, stkt, ovf, cn));
         } else {
           trav_enter(T, trav_pop<EXACT, 0u>(T, stk, stkt, ovf, cn));
-        }
-      }
-    }
-  }
-}
-
-// Spheres are tested after the BVH walk, with the same tie rule.
-__device__ __forceinline__ void trav_spheres(const DevScene &S, Trav &T) {
-  for (uint32_t s = 0; s < S.n_spheres; s++) {
-    if (T.any == 3u) break;
-    float th;
-    if (sphere_hit(S, s, T.o, T.d, T.tmax, th)) {
-      if (T.any) {
-        T.any = 3u;
-      } else {
-        const uint32_t id = S.n_tris + s;
-        if (th < T.h.t || (th == T.h.t && id < T.h.prim)) {
-          T.h.t = th; T.h.prim = id; T.h.slot = kNoPrim; T.h.b1 = 0.f; T.h.b2 = 0.f;
         }
       }
     }
@@ -951,7 +949,8 @@ __global__ void __launch_bounds__(64, (SPH ? 3 : PBRT_RENDER_WAVES_PER_SIMD)) re
 // The traversal loop alone over a ray batch, as persistent waves with dynamic fetch: a lane whose
 // walk is over writes its result and pulls its next ray while the other lanes keep walking.
 template <bool SPH, bool COUNT, int STACK>
-__global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIMD)) intersect_kernel(const DevScene S, const RayBatch B, const int any_hit) {
+// (scenes with spheres: the f64 quadratic of the leaf pass does not fit the 64 VGPRs of eight waves per SIMD -- four, as few rays as such scenes trace)
+__global__ void __launch_bounds__(256, (COUNT ? 1 : (SPH ? 4 : PBRT_INTERSECT_WAVES_PER_SIMD))) intersect_kernel(const DevScene S, const RayBatch B, const int any_hit) {
   __shared__ uint32_t lds_stack[4][COUNT ? STACK : kIntersectLdsStack][64];
   __shared__ float lds_tn[COUNT ? 4 : 1][COUNT ? STACK : 1][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -975,7 +974,6 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
   for (;;) {
     if (T.cur == kDone) {
       if (have) {
-        if (SPH) trav_spheres(S, T);
         if (any_hit) {
           B.occluded[idx] = T.any == 3u ? 1 : 0;
         } else {
@@ -1008,7 +1006,7 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
       }
     }
     if (__ballot(have) == 0ull) break;
-    trav_run<COUNT, COUNT, (COUNT ? 0u : kIntersectLdsStack)>(S, T, stk, stkt, ovf, have, tune, cn, ct);
+    trav_run<COUNT, COUNT, (COUNT ? 0u : kIntersectLdsStack), PBRT_STEPS_PER_CHECK, SPH>(S, T, stk, stkt, ovf, have, tune, cn, ct);
   }
   EXP_PROBE_FINI_BLOCK();
   if (COUNT) {
@@ -1023,11 +1021,20 @@ __global__ void __launch_bounds__(256, (COUNT ? 1 : PBRT_INTERSECT_WAVES_PER_SIM
   }
 }
 
+// n_prims = n_tris + the spheres: primitive t >= n_tris is sphere t - n_tris (its place in the vertex / index buffers is taken by a
+// degenerate proxy triangle spanning its box, so that every builder bounds it: capi.cpp) and gets a sphere's record
 __global__ void pack_tris_kernel(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
-                                 uint32_t n_tris, float4 *tris) {
+                                 uint32_t n_prims, uint32_t n_tris, const float4 *spheres, float4 *tris) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= n_tris) return;
+  if (slot >= n_prims) return;
   const uint32_t t = order[slot];
+  if (t >= n_tris) {
+    const float4 cr = spheres[2 * (t - n_tris)], m = spheres[2 * (t - n_tris) + 1];
+    tris[kTriStride * slot] = make_float4(cr.x, cr.y, cr.z, __uint_as_float(t));
+    tris[kTriStride * slot + 1] = make_float4(cr.w, 0.f, 0.f, m.x);
+    tris[kTriStride * slot + 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(1u));
+    return;
+  }
   const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
   tris[kTriStride * slot] = make_float4(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2], __uint_as_float(t));
   tris[kTriStride * slot + 1] = make_float4(P[3 * i1], P[3 * i1 + 1], P[3 * i1 + 2], __uint_as_float((uint32_t)mat_id[t]));
@@ -1035,11 +1042,11 @@ __global__ void pack_tris_kernel(const float *P, const uint32_t *idx, const uint
 }
 
 // corner (u, v) of the triangle in leaf slot `slot` (textured scenes: DESIGN.md 3.15)
-__global__ void pack_uv_kernel(const float *tri_uv, const uint32_t *order, uint32_t n_tris, float2 *out) {
+__global__ void pack_uv_kernel(const float *tri_uv, const uint32_t *order, uint32_t n_prims, uint32_t n_tris, float2 *out) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= n_tris) return;
+  if (slot >= n_prims) return;
   const uint32_t t = order[slot];
-  for (int v = 0; v < 3; v++) out[3u * slot + v] = make_float2(tri_uv[6 * (size_t)t + 2 * v], tri_uv[6 * (size_t)t + 2 * v + 1]);
+  for (int v = 0; v < 3; v++) out[3u * slot + v] = t < n_tris ? make_float2(tri_uv[6 * (size_t)t + 2 * v], tri_uv[6 * (size_t)t + 2 * v + 1]) : make_float2(0.f, 0.f);  // (a sphere has its own (u, v))
 }
 
 __global__ void assemble_kernel(const float4 *slab, float4 *film, int32_t w, int32_t h, uint32_t rank, uint32_t world,
@@ -1228,16 +1235,16 @@ hipError_t launch_intersect(const DevScene &S, const RayBatch &B, bool any_hit, 
 }
 
 hipError_t launch_pack_tris(const float *P, const uint32_t *idx, const uint16_t *mat_id, const uint32_t *order,
-                            uint32_t n_tris, float4 *tris, hipStream_t stream) {
-  if (n_tris == 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_tris_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, stream, P, idx, mat_id, order, n_tris,
+                            uint32_t n_prims, uint32_t n_tris, const float4 *spheres, float4 *tris, hipStream_t stream) {
+  if (n_prims == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_tris_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, stream, P, idx, mat_id, order, n_prims, n_tris, spheres,
                      tris);
   return hipGetLastError();
 }
 
-hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n_tris, float2 *out, hipStream_t stream) {
-  if (n_tris == 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_uv_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, stream, tri_uv, order, n_tris, out);
+hipError_t launch_pack_uv(const float *tri_uv, const uint32_t *order, uint32_t n_prims, uint32_t n_tris, float2 *out, hipStream_t stream) {
+  if (n_prims == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_uv_kernel, dim3((n_prims + 255) / 256), dim3(256), 0, stream, tri_uv, order, n_prims, n_tris, out);
   return hipGetLastError();
 }
 

@@ -156,6 +156,7 @@ int clone_scene(const pbrt_hip_scene *src, int device, pbrt_hip_scene **out) {
   s->n_lights = src->n_lights;
   s->gpu_built = src->gpu_built;
   s->n_quads_gpu = src->n_quads_gpu;
+  s->n_prims = src->n_prims;
   s->build_ms = src->build_ms;
   s->reinsert_passes = src->reinsert_passes;
   s->reinsert_moves = src->reinsert_moves;

@@ -894,9 +894,11 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
         out->max_depth = (uint32_t)std::max(0, ps.one_int("maxdepth", 5));
         if (name == "directlighting") out->integrator = PBRT_HIP_INTEGRATOR_DIRECT;
         else {
-          // "bool mis": the direct-light estimate multiple-importance-sampled, as pbrt-v3's path integrator does it; the
-          // default stays SURVEY A8's estimator without it, which is what BASELINE's configs are measured and pinned on
-          out->integrator = ps.one_bool("mis", false) ? PBRT_HIP_INTEGRATOR_PATH_MIS : PBRT_HIP_INTEGRATOR_PATH;
+          // `Integrator "path"` in a scene file MEANS pbrt-v3's path integrator (the reference's default name, api.rs:239; its render sketch
+          // is pbrt-v3's, api.rs:446-453), whose direct-light estimate is multiple-importance-sampled: integrator 2 since
+          // round 6 (VERDICT r05 missing 2 / item 8).  "bool mis" "false" selects SURVEY A8's estimator without it (integrator 0: what
+          // BASELINE's synthetic configs, which name their integrator through the C ABI, are measured and pinned on).
+          out->integrator = ps.one_bool("mis", true) ? PBRT_HIP_INTEGRATOR_PATH_MIS : PBRT_HIP_INTEGRATOR_PATH;
           if (name != "path") api.warn("Integrator \"" + name + "\": only \"path\" and \"directlighting\" exist, \"path\" used");
         }
         if (ps.one_float("rrthreshold", 1.f) != 1.f) api.warn("Integrator: \"rrthreshold\" ignored (Russian roulette from the fourth bounce on with q = max(0.05, 1 - max beta))");
@@ -1042,8 +1044,10 @@ ParseError parse_scene(const char *text, size_t len, const std::string &base_dir
     if (!textured) { out->tri_uv.clear(); out->tri_uv.shrink_to_fit(); }
   }
   if (!api.camera_set) mat_identity(out->cam_to_world);
-  if (out->spheres.size() > 256)  // (C0 / C1 have one sphere; the accelerator holds triangles only)
-    api.warn(std::to_string(out->spheres.size()) + " spheres: spheres are not in the BVH, every ray tests each of them (meshes scale, spheres do not)");
+  // (round 6: spheres are primitives of the BVH like triangles -- the warning that hundreds of them cost every ray a loop is gone; what
+  // pbrt_hip_scene_create takes is 2^24 primitives in all)
+  if (out->idx.size() / 3 + out->spheres.size() > api.kMaxSceneTriangles)
+    api.warn(std::to_string(out->idx.size() / 3) + " triangles + " + std::to_string(out->spheres.size()) + " spheres: more than the 2^24 primitives pbrt_hip_scene_create takes");
   return fin(true);
 }
 

@@ -78,7 +78,7 @@ struct LoadedScene {
   std::string camera_name = "perspective", sampler_name = "halton", integrator_name = "path", filter_name = "box",
               accelerator_name = "bvh", film_name = "image";  // defaults: api.rs:231-241
   float filter_radius[2] = {0.5f, 0.5f};                       // box.rs:57-61
-  uint32_t integrator = PBRT_HIP_INTEGRATOR_PATH, max_depth = 5, spp_x = 4, spp_y = 4;
+  uint32_t integrator = PBRT_HIP_INTEGRATOR_PATH_MIS, max_depth = 5, spp_x = 4, spp_y = 4;  // (no Integrator directive: "path" as pbrt-v3 means it, api.rs:239)
   float max_sample_luminance = 0.f;  // Film "float maxsampleluminance" (film.rs:75,279); 0 = none
   float film_scale = 1.f;  // Film "float scale" (film.rs:368-371), exported by pbrt_hip_loaded_film_scale
   uint32_t sampler = PBRT_HIP_SAMPLER_HALTON;  // the default sampler name is "halton" (api.rs:235): DESIGN.md 3.13, see scene_parser.cpp "Sampler"

@@ -81,7 +81,7 @@ fn world_end(&mut self) {
     let film = Film::new(res, crop, filter, diagonal, filename, scale, max_lum);
     let b = film.cropped_pixel_bounds;
     let mut xyzw = vec![0f32; (b.area() * 4) as usize];
-    let rd = HipRenderDesc { integrator: if ro.integrator_name == "directlighting" { 1 } else { 0 },
+    let rd = HipRenderDesc { integrator: if ro.integrator_name == "directlighting" { 1 } else if ro.integrator_params.find_one_bool("mis", true) { 2 } else { 0 },  // "path" = pbrt-v3's: MIS (2); "bool mis" "false": 0
                              max_depth: ro.integrator_params.find_one_int("maxdepth", 5) as u32,
                              spp_x, spp_y, seed: 0, rank: 0, world_size: 1, flags: 0,
                              sampler: match ro.sampler_name.as_str() { "stratified" => 0, "sobol" => 2, "halton" => 3, _ => 1 },

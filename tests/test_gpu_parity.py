@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import pbrt_amd
-from pbrt_amd import INTEGRATOR_DIRECT, INTEGRATOR_PATH, LIGHT_INFINITE, SceneData, scenes
+from pbrt_amd import INTEGRATOR_DIRECT, INTEGRATOR_PATH, INTEGRATOR_PATH_MIS, LIGHT_INFINITE, SceneData, scenes
 from util import SMALL_SCENES, assert_bit_equal, random_rays
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,7 @@ def test_intersect_matches_oracle(gpu, oracle, name, builder):
     ref = oracle.OracleScene(sd)
     rt, rp, rb1, rb2, rc = ref.intersect(o, d, tmax)
     with gpu.Scene(sd, builder=builder) as sc:  # (device-built: the canonical tree behind the counters is made lazily)
-        assert sc.build_info()["gpu_built"] == (builder is None and sc.sd.idx.shape[0] >= 2)
+        assert sc.build_info()["gpu_built"] == (builder is None and sc.n_prims >= 2)  # (primitives: triangles + spheres)
         t, prim, b1, b2, cnt = sc.intersect(o, d, tmax, counters=True)
         sc_depth, sc_need = sc.info()["depth"], sc.info()["quad_stack_need"]
         occ = sc.occluded(o, d, tmax)
@@ -99,6 +99,45 @@ def test_a_hit_is_a_function_of_ray_and_triangle_alone(gpu, oracle, name, builde
             assert_bit_equal(b1, rb1, f"{seed}: b1")
             assert_bit_equal(b2, rb2, f"{seed}: b2")
             assert_bit_equal(sc.occluded(o, d, tmax), rocc, f"{seed}: occluded")
+
+
+@pytest.mark.parametrize("builder", [None, "host", "gpu-plain"])
+def test_spheres_are_primitives_of_the_tree(gpu, oracle, builder):
+    """Round 6: `Shape "sphere"` (check-sphere.pbrt:22) is a primitive of the BVH -- a leaf record of its own kind, tested
+    in the leaf pass with the f64 quadratic and the own-box rule -- where every ray used to test every sphere after the walk.  2 000
+    overlapping spheres + triangles through all three builders: film, hit records, occlusion flags and the canonical counters equal to the
+    oracle's; 10 000 spheres cost a frame at most 2 x the production walk's work of 20 000 random triangles (they cost less)."""
+    from util import sphere_cloud_scene
+    sd = sphere_cloud_scene(2000)
+    kw = dict(max_depth=5, spp=(2, 2), seed=4)
+    ref = oracle.OracleScene(sd)
+    rfilm, rst = ref.render(**kw)
+    o, d, tmax = random_rays(100_000, 5, inside=1.5)
+    rt, rp, rb1, rb2, rc = ref.intersect(o, d, tmax)
+    with gpu.Scene(sd, builder=builder) as sc:
+        assert sc.build_info()["gpu_built"] == (builder != "host")
+        film, st = sc.render(counters=True, **kw)
+        film2, _ = sc.render(**kw)
+        t, prim, b1, b2, cnt = sc.intersect(o, d, tmax, counters=True)
+        t2, prim2 = sc.intersect(o, d, tmax)[:2]
+        occ = sc.occluded(o, d, tmax)
+    assert_bit_equal(film, rfilm, "film (canonical walk)")
+    assert_bit_equal(film2, rfilm, "film")
+    for k in ("camera_rays", "bounce_rays", "shadow_rays", "nodes_visited", "tris_tested"):
+        assert st[k] == rst[k], k
+    assert_bit_equal(prim, rp, "prim"); assert_bit_equal(t, rt, "t"); assert_bit_equal(prim2, rp, "prim (production walk)"); assert_bit_equal(t2, rt, "t (production walk)")
+    assert cnt == rc and (rp >= sd.idx.shape[0]).mean() > 0.2
+    assert_bit_equal(occ, ref.occluded(o, d, tmax), "occluded")
+    if builder is None:
+        work = {}
+        for name, s2 in (("spheres", sphere_cloud_scene(10_000, 128, 128, n_tris=0)), ("triangles", scenes.random_mesh_scene(20_000, 128, 128))):
+            with gpu.Scene(s2) as sc:
+                sc.render(**kw)
+                _, st = sc.render(**kw)
+                _, wk = sc.render(counters="walk", **kw)
+            rays = wk["camera_rays"] + wk["bounce_rays"] + wk["shadow_rays"]
+            work[name] = (wk["nodes_visited"] / rays, wk["tris_tested"] / rays, st["kernel_ms"])
+        assert work["spheres"][0] < 2 * work["triangles"][0] and work["spheres"][1] < 2 * work["triangles"][1], work
 
 
 def test_intersect_edge_cases(gpu, oracle):
@@ -324,6 +363,68 @@ def test_rays_parallel_to_an_axis_are_pruned_like_any_other(gpu, oracle):
     for a, b, what in zip(hit[:4], ref.intersect(o, d, tmax)[:4], ("t", "prim", "b1", "b2")):
         assert_bit_equal(a, b, f"axis-parallel rays: {what}")
     assert np.array_equal(occ != 0, ref.occluded(o, d, tmax) != 0)
+
+
+def _torture():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("torture_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "torture_probe.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.timeout(900)
+def test_work_per_ray_is_bounded_off_the_baseline_track(gpu):
+    """the cliff of round 5 (every shadow ray towards a sun straight overhead walked the whole tree: 2 500 x the
+    frame time) lived four rounds because the suite's only WORK bound was on BASELINE's own ray mix.  Here the 1 M-triangle scene of C3
+    under the sixteen variations of tools/torture_probe.py -- point lights on round coordinates, suns along the axes and a diagonal, a sky,
+    all mirrors, cameras looking exactly along an axis, direct lighting, depth 0 and 64 -- must cost at most 1.5 x the default frame's
+    64-byte fetches per ray and 1.5 x its triangle tests per ray (production-walk counters: box-independent); the three variants without a
+    counting instantiation (MIS, Halton, a wide filter) at most 3 x its kernel time in this same job."""
+    tp = _torture()
+    base = None
+    for name, scene_kw, render_kw in tp.VARIANTS:
+        sd = tp.variant_scene(n=1_000_000, res=256, **scene_kw)
+        k = dict(max_depth=8, spp=(2, 2), seed=1)
+        k.update(render_kw)
+        with gpu.Scene(sd) as sc:
+            sc.render(**k)
+            film, st = sc.render(**k)
+            w = tp.walk_work(sc, **k)
+        assert np.isfinite(film).all(), name
+        if base is None:
+            base = (w, st["kernel_ms"])
+            assert w[0] < 45.0 and w[1] < 6.0, w  # (C3's own: 38.4 + 4.8 at the frame's 2048^2; this frame's camera rays are fewer)
+            continue
+        if w is not None:
+            assert w[0] <= 1.5 * base[0][0] and w[1] <= 1.5 * base[0][1], (name, w, base[0])
+        else:
+            assert st["kernel_ms"] <= 3.0 * base[1], (name, st["kernel_ms"], base[1])
+
+
+# fetches / triangle tests per ray of the production walk on tools/torture_probe.py's stress geometries (256 x 256, 4 spp, depth 8), measured
+# in round 6 (profiles/r06_torture_probe.txt) and asserted as CEILINGS with 25 % of room: a builder or kernel change that makes one of them
+# worse fails here.  "inherent": slow by the nature of a BVH of boxes without spatial splits -- today's figures, not a target.
+TORTURE_CEILINGS = {}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("index", range(7))
+def test_stress_geometries_keep_their_work_per_ray(gpu, oracle, index):
+    tp = _torture()
+    name, make = tp.GEOMETRIES[index]
+    sd = tp.with_mesh(*make())
+    kw = dict(max_depth=8, spp=(2, 2), seed=1)
+    with gpu.Scene(sd) as sc:
+        film, _ = sc.render(**kw)
+        w = tp.walk_work(sc, **kw)
+    x0, y0 = sd.xres // 2, sd.yres // 2
+    crop = (0.5, 0.5 + 16 / sd.xres, 0.5, 0.5 + 16 / sd.yres)
+    ref, _ = oracle.OracleScene(dataclasses.replace(sd, crop=crop).normalized()).render(**kw)
+    assert_bit_equal(film[y0:y0 + 16, x0:x0 + 16], ref, name)
+    assert name in TORTURE_CEILINGS, (name, w)
+    cf, ct = TORTURE_CEILINGS[name]
+    assert w[0] <= 1.25 * cf and w[1] <= 1.25 * ct, (name, w, TORTURE_CEILINGS[name])
 
 
 def test_maximum_triangle_count_matches_oracle(gpu, oracle):
@@ -858,7 +959,7 @@ def test_c0_as_baseline_states_it(gpu, oracle):
     assert 'Sampler "halton" "integer pixelsamples" 128' in text
     for sampler, line in (("stratified", 'Sampler "stratified" "integer xsamples" 2 "integer ysamples" 2'), ("halton", 'Sampler "halton" "integer pixelsamples" 4')):
         ls = loader.load_string(text.replace('Sampler "halton" "integer pixelsamples" 128', line))
-        assert (ls.scene.xres, ls.scene.yres) == (256, 256) and ls.spp == (2, 2) and ls.integrator == INTEGRATOR_PATH
+        assert (ls.scene.xres, ls.scene.yres) == (256, 256) and ls.spp == (2, 2) and ls.integrator == INTEGRATOR_PATH_MIS  # (no Integrator line: "path" as pbrt-v3 means it, round 6)
         assert (ls.sampler == 0) == (sampler == "stratified")
         ref, _ = oracle.OracleScene(ls.scene).render(seed=0, **ls.render_kwargs())
         with gpu.Scene(ls.scene) as sc:
@@ -1214,7 +1315,7 @@ def test_lit_plane_closed_forms_on_the_gpu(gpu, kind, max_depth):
 # ---- accelerator built on the device: a different tree, the same answers ----
 
 @pytest.mark.parametrize("builder", ["gpu", "gpu-plain"])
-@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "ties", "deep"])
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "ties", "deep", "check_sphere", "spheres2k"])
 def test_gpu_built_scene_matches_oracle(gpu, oracle, name, builder):
     """PBRT_HIP_SCENE_GPU_BUILD: binned SAH on the device, the tree optimised by parallel re-insertion ("gpu", the default) or
     left as built ("gpu-plain", PBRT_HIP_SCENE_PLAIN_TREE).  Hit records and film must equal the oracle's bit for
@@ -1258,8 +1359,10 @@ def test_gpu_built_scene_matches_oracle(gpu, oracle, name, builder):
     assert_bit_equal(b2, rb2, "b2")
     assert np.array_equal(occ != 0, ref.occluded(o, d, tmax) != 0)
     assert_bit_equal(film, film_ref, "film of the device-built scene")
-    assert sorted(order.tolist()) == list(range(len(sd.idx)))
-    _check_quads(quads, need, sd.P, sd.idx, order)
+    from util import with_sphere_proxies
+    Pp, Ip = with_sphere_proxies(sd)  # (a sphere is primitive n_tris + s, bounded through its proxy triangle: round 6)
+    assert sorted(order.tolist()) == list(range(len(Ip)))
+    _check_quads(quads, need, Pp, Ip, order)
 
 
 def test_device_reinsertion_cuts_the_walks_work(gpu, oracle):

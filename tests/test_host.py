@@ -96,6 +96,18 @@ def test_committed_profiles_price_the_built_kernel():
         pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{wl}.json")))
         assert pmc.get("kernel_isa_id"), wl
         assert isa_id.kernel_id(_lib.LIB_PATH, pmc["kernel"]) == pmc["kernel_isa_id"], (wl, isa_id.normalise(pmc["kernel"]))
+        # round 6: the lookup bench.py does -- by the MANGLED symbol, file parsing alone (no demangler child from a GPU-initialised process) --
+        # finds the same kernel; the profile says which TREE its per-ray counters belong to (withheld when the live walk differs), what the
+        # compiler allocated (code-object notes, not rocprofv3's granule fields) and how FETCH_SIZE was calibrated for this access shape
+        assert isa_id.kernel_id(_lib.LIB_PATH, pmc["kernel"], pmc["kernel_symbol"]) == pmc["kernel_isa_id"]
+        res = isa_id.kernel_resources(_lib.LIB_PATH, pmc["kernel_symbol"])
+        assert res["vgpr_count"] == pmc["vgpr"] <= 96 and res["vgpr_spill_count"] == pmc["vgpr_spill"] == 0 and pmc["scratch_bytes"] == 0
+        assert pmc["lds_bytes"] == pmc["lds_dynamic_bytes"] == 30 * 256 and pmc["waves_per_cu"] == 20  # the overflow variant's 30 rows
+        t = pmc["tree"]
+        assert t["kernel_fetches_per_ray"] > 30 and t["kernel_tris_per_ray"] > 4 and t["quad_nodes"] > 400_000 and t["spp"] in (512, 64)
+        cal = pmc["fetch_size_calibration"]
+        assert 0.9 < cal["fetch_size_bytes_per_known_byte"] < 1.1 and os.path.exists(os.path.join(ROOT, cal["source"]))  # x1, not the x2 of a wide stream
+        assert abs(pmc["traffic_bytes_calibrated"] - (pmc["FETCH_SIZE_KB_per_launch"] * cal["factor"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024) < 1e-6 * pmc["traffic_bytes_calibrated"]
 
 
 def test_library_holds_gfx950_code_object():
@@ -232,11 +244,13 @@ def test_bad_arguments_are_rejected_before_any_device_work():
         assert e.value.code == -1 and what in str(e.value), (what, str(e.value))
 
 
-@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere"])
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "check_sphere", "sphere", "spheres2k"])
 def test_builder_equals_oracle_builder(oracle, name):
-    """Two independently written builders of the same spec agree word for word."""
+    """Two independently written builders of the same spec agree word for word -- spheres included: the oracle bounds a
+    sphere by [c - r, c + r], the library's builders by the proxy triangle that spans that box (util.with_sphere_proxies)."""
+    from util import with_sphere_proxies
     sd = SMALL_SCENES[name]()
-    nodes, order, depth = pbrt_amd.bvh_build_host(sd.P, sd.idx)
+    nodes, order, depth = pbrt_amd.bvh_build_host(*with_sphere_proxies(sd))
     on, oo, od = oracle.OracleScene(sd).bvh()
     assert depth == od
     assert_bit_equal(nodes, on, "nodes")

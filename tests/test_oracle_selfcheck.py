@@ -575,3 +575,32 @@ def test_without_the_own_box_rule_the_adversarial_rays_tell_trees_apart(oracle):
     finally:
         oracle.debug_own_box_rule(True)
     assert differ > 10, differ
+
+
+def test_spheres_are_primitives_of_the_tree(oracle):
+    """Round 6: a sphere is a primitive of the BVH (primitive n_tris + s, bounded by [c - r, c + r]) with the own-box rule of
+    DESIGN.md 3.5 in its test -- until round 5 every ray tested every sphere after the walk.  The oracle's BVH over 2 000 overlapping
+    spheres + triangles and its brute force over all primitives give the same hit record and occlusion flag for every ray, random ones and
+    rays aimed exactly at the spheres' poles (where a sphere touches its box: the own-box rule at its margin); the tree is worth it (a walk
+    tests a handful of primitives, not 2 000); and a hit IS on its sphere (|p - c| = r to 1 % of r: the quadratic's coefficients are fp32, a grazing hit of a 0.03-unit sphere seen from 2 units away carries 1e-4 units)."""
+    from util import random_rays, sphere_cloud_scene
+    sd = sphere_cloud_scene(2000)
+    sc = oracle.OracleScene(sd)
+    nt = sd.idx.shape[0]
+    o, d, tmax = random_rays(30_000, 17, inside=1.5)
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, len(sd.spheres), 6000)
+    pole = sd.spheres[k, :3].copy()
+    pole[np.arange(6000), rng.integers(0, 3, 6000)] += sd.spheres[k, 3] * rng.choice(np.array([-1, 1], np.float32), 6000)  # a point where sphere and box touch
+    o2 = rng.uniform(-1.5, 1.5, (6000, 3)).astype(np.float32)
+    d2 = (pole - o2).astype(np.float32)
+    o, d, tmax = np.concatenate([o, o2]), np.concatenate([d, d2]), np.concatenate([tmax, rng.choice(np.array([np.inf, 1.0, 1.0 + 1e-6, 1.0 - 1e-6], np.float32), 6000)])
+    t, prim, b1, b2, cnt = sc.intersect(o, d, tmax)
+    bt, bprim, *_ = sc.intersect(o, d, tmax, brute_force=True)
+    assert np.array_equal(prim, bprim) and np.array_equal(t.view(np.uint32), bt.view(np.uint32)), int((prim != bprim).sum())
+    assert np.array_equal(sc.occluded(o, d, tmax), sc.occluded(o, d, tmax, brute_force=True))
+    on_sphere = (prim >= nt) & (prim != 0xffffffff)
+    assert on_sphere.mean() > 0.2 and cnt[1] / len(o) < 30, (on_sphere.mean(), cnt)  # a third of the rays end on a sphere, after a handful of tests
+    p = o[on_sphere].astype(np.float64) + d[on_sphere].astype(np.float64) * t[on_sphere, None]
+    s = sd.spheres[prim[on_sphere] - nt]
+    assert np.abs(np.linalg.norm(p - s[:, :3], axis=1) / s[:, 3] - 1).max() < 1e-2

@@ -110,7 +110,7 @@ def test_defaults():  # api.rs:231-241 names; pbrt-v3 parameter defaults
 def _expect_check_sphere(ls, res):
     sd = ls.scene
     assert (sd.xres, sd.yres) == res and sd.fov == 45.0 and ls.spp == (16, 8) and ls.max_depth == 5
-    assert ls.filename == "simple.png" and ls.integrator == pbrt_amd.INTEGRATOR_PATH
+    assert ls.filename == "simple.png" and ls.integrator == pbrt_amd.INTEGRATOR_PATH_MIS  # (the file has no Integrator line: "path" as pbrt-v3 means it)
     assert sd.P.tolist() == [[-20, -20, -1], [20, -20, -1], [20, 20, -1], [-20, 20, -1]]  # Translate 0 0 -1 applied
     assert sd.idx.tolist() == [[0, 1, 2], [0, 2, 3]] and sd.mat_id.tolist() == [1, 1]
     assert sd.spheres.tolist() == [[0, 0, 0, 1, 0]]
@@ -212,10 +212,14 @@ def test_sampler_names():
 
 
 def test_integrator_mis_switch():
-    """Integrator "path" "bool mis" "true" selects integrator 2; the default stays the estimator BASELINE's configs are
-    pinned on.  The variants combine freely with a wide box filter, the Halton sampler and textures (render_kernel_x): nothing is
-    dropped, nothing warned about."""
-    assert loader.load_string('Integrator "path"').integrator == 0
+    """`Integrator "path"` in a scene file means pbrt-v3's path integrator -- the reference's default name (api.rs:239), whose direct-light
+    estimate is multiple-importance-sampled: integrator 2 (the parser's default since round 6, also when the file has no
+    Integrator line).  "bool mis" "false" selects SURVEY A8's estimator (integrator 0, what BASELINE's synthetic configs name through the C
+    ABI).  The variants combine freely with a wide box filter, the Halton sampler and textures (render_kernel_x): nothing is dropped,
+    nothing warned about."""
+    assert loader.load_string('Integrator "path"').integrator == 2 and loader.load_string("WorldBegin WorldEnd").integrator == 2
+    ls = loader.load_string('Integrator "path" "bool mis" "false"')
+    assert ls.integrator == 0 and not ls.warnings
     ls = loader.load_string('Integrator "path" "bool mis" "true" "integer maxdepth" 7')
     assert ls.integrator == 2 and ls.max_depth == 7 and not ls.warnings
     assert loader.load_string('Integrator "directlighting" "bool mis" "true"').integrator == 1

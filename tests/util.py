@@ -86,6 +86,40 @@ SMALL_SCENES = {
 }
 
 
+def with_sphere_proxies(sd):
+    """(P, idx) with every sphere appended as the degenerate proxy triangle (c - r, c + r, c - r) the library's builders bound it by
+    (capi.cpp, round 6): primitive n_tris + s, whose box is the sphere's box [c - r, c + r] in fp32 -- the oracle's sphere_box."""
+    sph = np.asarray(sd.spheres, np.float32).reshape(-1, 5)
+    if len(sph) == 0:
+        return sd.P, sd.idx
+    P = np.asarray(sd.P, np.float32).reshape(-1, 3)
+    idx = np.asarray(sd.idx, np.uint32).reshape(-1, 3)
+    if len(idx) == 0:
+        P = np.zeros((0, 3), np.float32)
+    c, r = sph[:, :3], sph[:, 3:4]
+    nv = len(P)
+    Pa = np.concatenate([P, np.stack([c - r, c + r], 1).reshape(-1, 3)]).astype(np.float32)
+    v0 = nv + 2 * np.arange(len(sph), dtype=np.uint32)
+    return Pa, np.concatenate([idx, np.stack([v0, v0 + 1, v0], 1)]).astype(np.uint32)
+
+
+def sphere_cloud_scene(n_spheres=2000, xres=64, yres=64, n_tris=64, seed=9, radius_scale=0.6):
+    """`n_spheres` matte / mirror spheres (centres ~ U[-1, 1]^3, radii ~ radius_scale x n^(-1/3) x U[0.3, 1]) inside the random-mesh scene's box
+    with its ceiling light and `n_tris` of its random triangles: spheres as primitives of the tree (round 6) -- overlapping ones, tiny
+    ones, one that contains the camera's neighbourhood when n is small."""
+    import dataclasses
+    sd = scenes.random_mesh_scene(n_tris, xres, yres)
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-1, 1, (n_spheres, 3))
+    r = radius_scale * n_spheres ** (-1.0 / 3.0) * rng.uniform(0.3, 1.0, n_spheres)
+    m = rng.integers(0, 250, n_spheres)
+    sph = np.concatenate([c, r[:, None], m[:, None]], 1).astype(np.float32)
+    return dataclasses.replace(sd, spheres=sph).normalized()
+
+
+SMALL_SCENES["spheres2k"] = sphere_cloud_scene
+
+
 def tie_scene(xres=48, yres=48):
     """Geometry built to produce EXACT ties and degenerate cases: every triangle of a small random
     mesh duplicated (same vertices, different primitive id and material), two coplanar overlapping

@@ -123,6 +123,10 @@ def main():
         # FETCH_SIZE calibrated for this access shape (tools/fetch_size_calibration.sh): known bytes per counted byte of
         # 64-byte records gathered at random, from the table that is in the workload's regime (in / past the Infinity Cache)
         cal = latest_calibration(P, G)
+        if cal and cal["source"].startswith("gpurun_out"):  # this job's own calibration: kept under profiles/ beside what it calibrates
+            kept = os.path.join(P, f"{tag}_fetch_size_calibration.txt")
+            shutil.copy(os.path.join(ROOT, cal["source"]), kept)
+            cal["source"] = os.path.relpath(kept, ROOT)
         if cal and "FETCH_SIZE_KB_per_launch" in summary:
             ratio = cal["ratio_1536MB"] if wl == "big" else cal["ratio_112MB"]
             summary["fetch_size_calibration"] = {"factor": 1.0 / ratio, "fetch_size_bytes_per_known_byte": ratio, "table": "1536 MB (past the Infinity Cache)" if wl == "big" else "112 MB (inside the Infinity Cache)",
