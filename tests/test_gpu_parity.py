@@ -405,7 +405,15 @@ def test_work_per_ray_is_bounded_off_the_baseline_track(gpu):
 # fetches / triangle tests per ray of the production walk on tools/torture_probe.py's stress geometries (256 x 256, 4 spp, depth 8), measured
 # in round 6 (profiles/r06_torture_probe.txt) and asserted as CEILINGS with 25 % of room: a builder or kernel change that makes one of them
 # worse fails here.  "inherent": slow by the nature of a BVH of boxes without spatial splits -- today's figures, not a target.
-TORTURE_CEILINGS = {}
+TORTURE_CEILINGS = {  # name: (64-byte fetches, triangle tests) per ray, measured (gpurun_out/r06c: the suite's own first run printed them)
+    "random soup": (35.33, 4.83),
+    "flat grid of quads in z = 0": (3.59, 1.45),
+    "20 stacked floors of quads": (15.85, 1.92),
+    "needles spanning the scene (inherent)": (7890.3, 6143.3),   # every needle's box is the scene: nothing prunes (spatial splits would)
+    "a cluster of 1e-5 triangles in a corner": (33.40, 21.51),
+    "20 000 coincident triangles (inherent)": (102.75, 238.76),  # 20 000 equal boxes: a walk that reaches one reaches a leaf chain of them
+    "40 concentric spherical shells": (11.49, 3.66),
+}
 
 
 @pytest.mark.timeout(900)
@@ -1483,6 +1491,10 @@ def _random_scene(seed):
         else:
             lights.append([kind, *rng.uniform(-3, 3, 3), *rng.uniform(2.0, 30.0, 3)])
     spheres = [[*rng.uniform(-1, 1, 3), rng.uniform(0.1, 0.7), int(rng.integers(0, n_mats))] for _ in range(int(rng.integers(0, 3)))]
+    if seed >= 48 and seed % 7 == 3:   # (soak seeds, round 6) a cloud of small spheres: primitives of the tree like the triangles
+        spheres += [[*rng.uniform(-1, 1, 3), rng.uniform(0.02, 0.2), int(rng.integers(0, n_mats))] for _ in range(int(rng.integers(40, 200)))]
+    if seed >= 48 and seed % 11 == 7 and n_tris > 0:  # ... and a point light exactly ON a mesh vertex: the own-box rule's rays
+        lights.append([0, *P[int(rng.integers(0, len(P)))], *rng.uniform(2.0, 30.0, 3)])
     eye = rng.uniform(-3.5, 3.5, 3)
     if np.linalg.norm(eye) < 1.5:
         eye = eye / max(np.linalg.norm(eye), 1e-3) * 2.5
