@@ -88,6 +88,10 @@ def lib(native=False):
         l.orc_bvh_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.orc_intersect.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 8 + [C.c_int]
         l.orc_occluded.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int]
+        l.orc_tri_accepts.restype = None
+        l.orc_tri_accepts.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 6
+        l.orc_quad_path_check.restype = None
+        l.orc_quad_path_check.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64] + [C.c_void_p] * 5
         l.orc_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         l.orc_pixel_samples.argtypes = [C.c_void_p, C.POINTER(RenderDesc), C.c_int, C.c_int, C.c_void_p]
         l.orc_render.restype = C.c_int
@@ -267,6 +271,17 @@ def debug_own_box_rule(on):
     lib().orc_debug_own_box_rule(1 if on else 0)
 
 
+def quad_path_check(quads, root_box, order, o, d, tri, th):
+    """fails[i] = node tests on the way from the root of a product tree to triangle tri[i]'s leaf slot that do not pass for ray i with
+    tfar = th[i] (the production step's arithmetic): 0 = every walk reaches the triangle while its best hit is still >= th[i]"""
+    quads = np.ascontiguousarray(quads, np.uint32).reshape(-1, 16); order = np.ascontiguousarray(order, np.uint32)
+    o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+    tri = np.ascontiguousarray(tri, np.uint32); th = np.ascontiguousarray(th, np.float32); box = np.ascontiguousarray(root_box, np.float32)
+    fails = np.zeros(len(o), np.uint32)
+    lib().orc_quad_path_check(_p(quads), len(quads), _p(box), _p(order), len(order), len(o), _p(o), _p(d), _p(tri), _p(th), _p(fails))
+    return fails
+
+
 def quad_walk_count_visits(per_node):
     """per_node: a uint64 array with one word per quad node that the following quad_walk calls add their node steps to, or None"""
     lib().orc_quad_walk_count_visits.argtypes = [C.c_void_p]
@@ -319,6 +334,14 @@ class OracleScene:
         nodes = np.zeros((max(n, 1), 8), np.uint32); order = np.zeros(max(n_prims, 1), np.uint32)
         self.l.orc_bvh_export(self.h, _p(nodes), _p(order))
         return nodes[:n], order[:n_prims], self.l.orc_bvh_depth(self.h)
+
+    def tri_accepts(self, o, d, tmax, tri):
+        """Triangle::Intersect (Moeller-Trumbore + the own-box rule) of ray i against triangle tri[i] alone -> (ok[n] uint8, t[n])"""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        tmax = np.ascontiguousarray(tmax, np.float32).reshape(-1); tri = np.ascontiguousarray(tri, np.uint32)
+        ok = np.zeros(len(o), np.uint8); t = np.zeros(len(o), np.float32)
+        self.l.orc_tri_accepts(self.h, len(o), _p(o), _p(d), _p(tmax), _p(tri), _p(ok), _p(t))
+        return ok, t
 
     def light_count(self):
         return self.l.orc_light_count(self.h)

@@ -653,6 +653,18 @@ extern "C" {
 
 int orc_sobol_dims(void) { return kSobolDims; }
 void orc_debug_own_box_rule(int on) { Scene::own_box_rule() = on != 0; }
+// Triangle::Intersect (Moeller-Trumbore + the own-box rule) of ray i against triangle tri[i] alone: ok[i], and t[i] where accepted
+void orc_tri_accepts(const orc_scene *s, int64_t n, const float *o, const float *d, const float *tmax, const uint32_t *tri, uint8_t *ok, float *t) {
+  for (int64_t i = 0; i < n; i++) {
+    Ray r;
+    r.o = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+    r.d = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    r.tmax = tmax[i];
+    float tt = 0.f, u, v;
+    ok[i] = tri[i] < s->s.n_tris() && s->s.tri_intersect(tri[i], r, &tt, &u, &v) ? 1 : 0;
+    t[i] = tt;
+  }
+}
 // Halton sampler: u and the integer head of dimension d for indices 0 .. n - 1 under `key` in a frame whose largest sample index is
 // spp_mask (tests of the radical inverse); returns b^D, the head's modulus (0 for base 2)
 uint32_t orc_halton_points(uint32_t d, uint32_t key, uint32_t spp_mask, uint32_t n, float *u, uint32_t *v) {

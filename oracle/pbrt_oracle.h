@@ -170,6 +170,12 @@ void orc_quad_walk_count_visits(uint64_t *per_node);
 /* tests only: 0 switches the own-box rule of Triangle::Intersect off in the oracle's BVH walk and brute force -- the
  * spec as it was until round 5, where the two can disagree --, anything else switches it back on (the default) */
 void orc_debug_own_box_rule(int on);
+/* tests: Triangle::Intersect (Moeller-Trumbore + the own-box rule) of ray i against triangle tri[i] alone -> ok[i], t[i] */
+void orc_tri_accepts(const orc_scene *s, int64_t n, const float *o, const float *d, const float *tmax, const uint32_t *tri, uint8_t *ok, float *t);
+/* tests: what the own-box rule promises, node by node on a product tree -- fails[i] = the node tests on the way from the root to triangle
+ * tri[i]'s leaf slot that do NOT pass for ray i with tfar = th[i] (oracle/quad_walk.cpp) */
+void orc_quad_path_check(const uint32_t *quads, uint32_t n_quads, const float root_box[6], const uint32_t *order, uint32_t n_tris, int64_t n,
+                         const float *o, const float *d, const uint32_t *tri, const float *th, uint32_t *fails);
 
 #ifdef __cplusplus
 }

@@ -249,6 +249,73 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
 
 }  // namespace
 
+// The production node step's test of child k of quad node W against [kRayTMin, tfar] -- the arithmetic of walk() above, for one child
+static bool child_passes(const uint32_t *W, int k, V3 o, V3 inv, bool negx, bool negy, bool negz, float tfar) {
+  const float gx = (o.x - as_f(W[0])) * inv.x, gy = (o.y - as_f(W[1])) * inv.y, gz = (o.z - as_f(W[2])) * inv.z;
+  constexpr float kMargin = 0x1.8p-22f;
+  const float gxn = std::fmaf(std::fabs(gx), kMargin, gx), gxf = std::fmaf(-std::fabs(gx), kMargin, gx);
+  const float gyn = std::fmaf(std::fabs(gy), kMargin, gy), gyf = std::fmaf(-std::fabs(gy), kMargin, gy);
+  const float gzn = std::fmaf(std::fabs(gz), kMargin, gz), gzf = std::fmaf(-std::fabs(gz), kMargin, gz);
+  const float cix = as_f(W[3]) * inv.x, ciy = as_f(W[10]) * inv.y, ciz = as_f(W[11]) * inv.z;
+  const uint32_t bnx = negx ? W[7] : W[4], bfx = negx ? W[4] : W[7];
+  const uint32_t bny = negy ? W[8] : W[5], bfy = negy ? W[5] : W[8];
+  const uint32_t bnz = negz ? W[9] : W[6], bfz = negz ? W[6] : W[9];
+  const float txn = std::fmaf((float)((bnx >> (8 * k)) & 0xffu), cix, -gxn), txf = std::fmaf((float)((bfx >> (8 * k)) & 0xffu), cix, -gxf);
+  const float tyn = std::fmaf((float)((bny >> (8 * k)) & 0xffu), ciy, -gyn), tyf = std::fmaf((float)((bfy >> (8 * k)) & 0xffu), ciy, -gyf);
+  const float tzn = std::fmaf((float)((bnz >> (8 * k)) & 0xffu), ciz, -gzn), tzf = std::fmaf((float)((bfz >> (8 * k)) & 0xffu), ciz, -gzf);
+  const float tn = fmaxn(fmaxn(txn, tyn), fmaxn(tzn, kRayTMin));
+  const float tf = fminn(fminn(txf, tyf), fminn(tzf, tfar));
+  return tn <= tf * kBoxPad;
+}
+
+// What the own-box rule of DESIGN.md 3.5 PROMISES, checked node by node on a product builder's quantised tree: for ray i and a triangle
+// tri[i] whose candidate at t = th[i] the rule accepted, every node test on the way from the root to the triangle's leaf slot passes with
+// tfar = th[i] (so that no walk whose best hit is still >= th[i] can miss the triangle).  fails[i] = the nodes on that path whose test fails
+// (0 = the promise holds); a triangle that is not in the tree counts 1000.
+extern "C" void orc_quad_path_check(const uint32_t *quads, uint32_t n_quads, const float root_box[6], const uint32_t *order, uint32_t n_tris, int64_t n,
+                                    const float *o, const float *d, const uint32_t *tri, const float *th, uint32_t *fails) {
+  struct Up { uint32_t node; int k; };
+  std::vector<Up> node_up(n_quads, Up{kNoPrim, 0}), slot_up(n_tris, Up{kNoPrim, 0});
+  for (uint32_t q = 0; q < n_quads; q++)
+    for (int k = 0; k < 4; k++) {
+      const uint32_t ref = quads[(size_t)q * 16 + 12 + k];
+      if (ref & kLeafRef) {
+        const uint32_t cnt = (ref >> 24) & 0x7fu, first = ref & 0xffffffu;
+        for (uint32_t j = 0; j < cnt && first + j < n_tris; j++) slot_up[first + j] = Up{q, k};
+      } else if (ref / 64u < n_quads && ref != 0u) {
+        node_up[ref / 64u] = Up{q, k};
+      }
+    }
+  std::vector<uint32_t> slot_of(n_tris, kNoPrim);
+  for (uint32_t sl = 0; sl < n_tris; sl++)
+    if (order[sl] < n_tris) slot_of[order[sl]] = sl;
+  for (int64_t i = 0; i < n; i++) {
+    fails[i] = 0;
+    if (tri[i] >= n_tris || slot_of[tri[i]] == kNoPrim || n_quads == 0) { fails[i] = 1000; continue; }
+    const V3 oo = {o[3 * i], o[3 * i + 1], o[3 * i + 2]}, dd = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    const V3 inv1 = {1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z};
+    const bool negx = inv1.x < 0.f, negy = inv1.y < 0.f, negz = inv1.z < 0.f;
+    float big;
+    {
+      const float extent = std::fmax(root_box[3] - root_box[0], std::fmax(root_box[4] - root_box[1], root_box[5] - root_box[2]));
+      int x = 0;
+      if (extent > 0.f && std::isfinite(extent)) (void)std::frexp(2.0f * extent, &x);
+      int e = 123 - x;
+      e = e > 120 ? 120 : (e < -100 ? -100 : e);
+      big = std::ldexp(1.0f, e);
+    }
+    const V3 inv = {dd.x == 0.f ? std::copysign(big, inv1.x) : inv1.x, dd.y == 0.f ? std::copysign(big, inv1.y) : inv1.y, dd.z == 0.f ? std::copysign(big, inv1.z) : inv1.z};
+    const bool inside = oo.x >= root_box[0] && oo.x <= root_box[3] && oo.y >= root_box[1] && oo.y <= root_box[4] && oo.z >= root_box[2] && oo.z <= root_box[5];
+    if (!inside && !box_test(root_box, oo, inv1, th[i])) fails[i]++;
+    Up u = slot_up[slot_of[tri[i]]];
+    for (int guard = 0; u.node != kNoPrim && guard < 4096; guard++) {
+      if (!child_passes(quads + (size_t)u.node * 16, u.k, oo, inv, negx, negy, negz, th[i])) fails[i]++;
+      if (u.node == 0u) break;
+      u = node_up[u.node];
+    }
+  }
+}
+
 // per-node visit counters of the walks that follow (n_quads uint64 words, or null to stop counting)
 extern "C" void orc_quad_walk_count_visits(uint64_t *per_node) { g_visits = per_node; }
 

@@ -99,6 +99,17 @@ def test_a_hit_is_a_function_of_ray_and_triangle_alone(gpu, oracle, name, builde
             assert_bit_equal(b1, rb1, f"{seed}: b1")
             assert_bit_equal(b2, rb2, f"{seed}: b2")
             assert_bit_equal(sc.occluded(o, d, tmax), rocc, f"{seed}: occluded")
+        # ... and the rule's PROMISE node by node on the tree this builder put into HBM (exported as it sits there): every node test on the
+        # way from the root to an accepted triangle's leaf slot passes with tfar = the hit's t, in the production step's arithmetic
+        # (oracle/quad_walk.cpp child_passes; tests/test_oracle_selfcheck.py::test_every_walk_reaches_... does the same for the host's trees)
+        quads, order = sc.export_quads()
+    if len(quads) and sd.spheres.shape[0] == 0:
+        o, d, tmax, tri = adversarial_rays(sd, 40_000, 7, with_targets=True)
+        ok, th = ref.tri_accepts(o, d, tmax, tri)
+        keep = ok != 0
+        V = sd.P[sd.idx.reshape(-1)]
+        fails = oracle.quad_path_check(quads, np.concatenate([V.min(0), V.max(0)]), order, o[keep], d[keep], tri[keep], th[keep])
+        assert keep.sum() > 1000 and not fails.any(), (int(keep.sum()), int((fails != 0).sum()))
 
 
 @pytest.mark.parametrize("builder", [None, "host", "gpu-plain"])

@@ -604,3 +604,46 @@ def test_spheres_are_primitives_of_the_tree(oracle):
     p = o[on_sphere].astype(np.float64) + d[on_sphere].astype(np.float64) * t[on_sphere, None]
     s = sd.spheres[prim[on_sphere] - nt]
     assert np.abs(np.linalg.norm(p - s[:, :3], axis=1) / s[:, 3] - 1).max() < 1e-2
+
+
+@pytest.mark.parametrize("name", ["mesh1k", "mesh20k", "cornell", "ties"])
+def test_every_walk_reaches_what_the_own_box_rule_accepts(oracle, name):
+    """The PROMISE of the own-box rule, checked node by node rather than through its consequence: for every (ray, triangle) pair
+    that Triangle::Intersect accepts at distance t -- the triangle an adversarial ray aims at, and the winner of the brute force --, every
+    node test on the way from the root of a product builder's QUANTISED tree to that triangle's leaf slot passes with tfar = t, in the
+    production step's own arithmetic (fma on 8-bit planes, the 3 eps margins, the stand-in for 1 / 0: oracle/quad_walk.cpp).  So no walk whose
+    best hit is still >= t can be turned away from the triangle, whichever tree it walks: kOwnPad = 1 + 2^-17 sits inside kBoxPad = 1 + 2^-16
+    with room for the quantised walk's roundings.  With the rule off the same check finds the pairs that trees disagreed on."""
+    from pbrt_amd.api import quad_build_host_ex
+    from util import adversarial_rays, random_rays
+    sd = SMALL_SCENES[name]().normalized()
+    sc = oracle.OracleScene(sd)
+    trees = {t: quad_build_host_ex(sd.P, sd.idx, tree=t) for t in ("sah", "reinsert")}
+    pairs = 0
+    big = sd.idx.shape[0] > 5000  # (the brute force over 20 k triangles: one seed, fewer rays)
+    for seed in range(1 if big else 3):
+        o, d, tmax, tri = adversarial_rays(sd, 16_000 if big else 40_000, seed, with_targets=True)
+        o2, d2, tmax2 = random_rays(6_000 if big else 20_000, seed, inside=1.5)
+        cases = [(o, d, tmax, tri)]
+        for oo, dd, tt in ((o, d, tmax), (o2, d2, tmax2)):
+            bt, bprim, *_ = sc.intersect(oo, dd, tt, brute_force=True)
+            hit = bprim < sd.idx.shape[0]
+            cases.append((oo[hit], dd[hit], tt[hit], bprim[hit]))
+        for oo, dd, tt, tr in cases:
+            ok, th = sc.tri_accepts(oo, dd, tt, tr)
+            keep = ok != 0
+            pairs += int(keep.sum())
+            for tname, q in trees.items():
+                fails = oracle.quad_path_check(q["quads"], q["root_box"], q["order"], oo[keep], dd[keep], tr[keep], th[keep])
+                assert not fails.any(), (name, tname, seed, int((fails != 0).sum()), int(fails.max()))
+    assert pairs > 5_000, pairs
+    if name == "cornell":  # the check can see what the rule is for
+        oracle.debug_own_box_rule(False)
+        try:
+            o, d, tmax, tri = adversarial_rays(sd, 40_000, 0, with_targets=True)
+            ok, th = sc.tri_accepts(o, d, tmax, tri)
+            keep = ok != 0
+            q = trees["sah"]
+            assert oracle.quad_path_check(q["quads"], q["root_box"], q["order"], o[keep], d[keep], tri[keep], th[keep]).any()
+        finally:
+            oracle.debug_own_box_rule(True)

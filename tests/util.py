@@ -22,7 +22,7 @@ def random_rays(n, seed, sd=None, inside=2.0):
     return o, d, tmax
 
 
-def adversarial_rays(sd, n, seed, inside=1.8):
+def adversarial_rays(sd, n, seed, inside=1.8, with_targets=False):
     """Rays that aim where fp32 Moeller-Trumbore is ill-conditioned and a triangle's own box is met at a corner or an edge (DESIGN.md
     3.4 / 3.5): from random origins EXACTLY at mesh vertices, at edge midpoints, at points on edges; from origins that are vertices
     themselves; along edges; from points in the PLANE of the triangle that owns the target (edge-on: det ~ 0); with tmax exactly at, a hair before and a hair beyond the target (what a shadow ray towards a light ON the
@@ -56,6 +56,8 @@ def adversarial_rays(sd, n, seed, inside=1.8):
     dist = np.where(kind == 6, np.float32(1), dist)
     scale = rng.choice(np.array([np.inf, 1.0, 1 - 1e-4, 1 + 1e-4, 1 - 6e-8, 1 + 1.2e-7, 0.5, 2.0], np.float32), n)
     tmax = np.where(np.isinf(scale), np.float32(np.inf), dist * scale).astype(np.float32)
+    if with_targets:  # (also the triangle every ray aims at)
+        return np.ascontiguousarray(o), np.ascontiguousarray(d), np.ascontiguousarray(tmax), tri.astype(np.uint32)
     return np.ascontiguousarray(o), np.ascontiguousarray(d), np.ascontiguousarray(tmax)
 
 
