@@ -1689,6 +1689,7 @@ def test_bench_under_torchrun_uses_rccl(gpu):
     out = json.loads(line)
     assert out["n_gpus"] == n and out["value"] > 0 and out["film_check"]["weight_ok"] and out["film_check"]["finite"]
     assert out["roofline"]["bound"] == "valu" and out["roofline"]["hbm"]["achieved_gbps"] > 0
+    assert len(out["per_rank_kernel_ms"]["mean_per_rank"]) == n and "exchange_ms" in out  # (every rank's kernel time: RCCL all_gather)
     if gpu.device_count() >= 2:  # and all GPUs from ONE process through the library's own ncclGather
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--steps", "1", "--warmup", "1",
                             "--workload", "c2", "--spp", "2", "2", "--no-cpu-baseline"], capture_output=True, text=True, cwd=root, timeout=800)
@@ -1746,6 +1747,12 @@ def test_bench_eight_ranks_share_one_gpu_under_gloo(gpu):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["film_check"]["weight_ok"] and out["film_check"]["finite"]
+    # (round 6) the line of an N-rank run carries EVERY rank's kernel time and sample count, and what a step costs beyond
+    # its slowest kernel: an imbalance or a slow gather shows in the first real 8-GPU record
+    pr = out["per_rank_kernel_ms"]
+    assert len(pr["mean_per_rank"]) == len(pr["max_step_per_rank"]) == len(pr["samples_per_rank"]) == 8 and min(pr["mean_per_rank"]) > 0
+    assert sum(pr["samples_per_rank"]) == 1024 * 1024 * 4 and pr["max"] == max(pr["mean_per_rank"]) and pr["imbalance"] >= 1.0
+    assert abs(out["exchange_ms"] - (out["ms_per_step"] - pr["max"])) < 1e-9 and "unmeasured" in out["scaling_note"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--workload", "c2", "--spp", "2", "2",
                           "--no-cpu-baseline", "--no-counters"], capture_output=True, text=True, cwd=root, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
