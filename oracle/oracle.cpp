@@ -652,7 +652,7 @@ struct orc_scene {
 extern "C" {
 
 int orc_sobol_dims(void) { return kSobolDims; }
-void orc_debug_own_box_rule(int on) { Scene::own_box_rule() = on != 0; }
+void orc_debug_own_box_rule(int on) { Scene::own_box_rule_on() = on != 0; }
 // Triangle::Intersect (Moeller-Trumbore + the own-box rule) of ray i against triangle tri[i] alone: ok[i], and t[i] where accepted
 void orc_tri_accepts(const orc_scene *s, int64_t n, const float *o, const float *d, const float *tmax, const uint32_t *tri, uint8_t *ok, float *t) {
   for (int64_t i = 0; i < n; i++) {

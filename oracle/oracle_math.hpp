@@ -39,8 +39,9 @@ static const float kInf = std::numeric_limits<float>::infinity();
 static const float kRayTMin = 1e-4f;      // absolute ray t_min
 static const float kSpawnEps = 1e-4f;     // spawned-ray offset along the facing normal
 static const float kShadowShrink = 0.9999f;  // shadow ray tmax = dist * (1 - 1e-4)
-static const float kBoxPad = 0x1.0001p+0f;   // 1 + 2^-16: the far-side pad of the node test (pbrt-v3 Bounds3::IntersectP pads by 1 + 2 gamma(3); wider since round 6)
-static const float kOwnPad = 0x1.00008p+0f;  // 1 + 2^-17: the pad of the own-box rule of Triangle::Intersect -- STRICTLY inside kBoxPad
+static const float kBoxPad = 0x1.000004p+0f;  // 1 + 2^-19: the far-side pad of the node test (pbrt-v3 Bounds3::IntersectP pads by 1 + 2 gamma(3) = 1 + 6 * 2^-24;
+                                              // 32 * 2^-24 here since round 6: room for the own-box rule's pad INSIDE it)
+static const float kOwnPad = 0x1.000001p+0f;  // 1 + 2^-21: the pad of the own-box rule of Triangle::Intersect -- kOwnPad * (1 + 2^-21) < kBoxPad
 
 // ---------------------------------------------------------------------------------------------
 // PCG32.  Bit-exact restatement of /root/reference/src/core/rng.rs:19-93.

@@ -257,7 +257,7 @@ class Scene {
   }
 
   // (tests only: the rule of in_own_box switched off, to show that the adversarial-ray tests can see what it closes)
-  static bool &own_box_rule() { static bool on = true; return on; }
+  static bool &own_box_rule_on() { static bool on = true; return on; }
 
   // ---- Triangle::Intersect: Moeller-Trumbore in the operation order of SURVEY A5 ----
   bool tri_intersect(uint32_t t, const Ray &r, float *tt, float *uu, float *vv) const {
@@ -275,20 +275,23 @@ class Scene {
     float th = dot(e2, qv) * inv;
     if (!(u >= 0.f) || !(v >= 0.f) || !(u + v <= 1.0f)) return false;
     if (!(th > kRayTMin) || !(th < r.tmax)) return false;
-    if (!in_own_box(p0, p1, p2, r, th)) return false;
+    if (!own_box_rule(p0, p1, p2, r, &th)) return false;
     *tt = th; *uu = u; *vv = v;
     return true;
   }
 
-  // The own-box rule (round 6): what fp32 Moeller-Trumbore accepts counts as a hit only if the node test of 3.4, applied
-  // to the triangle's OWN bounding box with tfar = the hit's t, passes -- the slab distances of the three vertices with the node test's
-  // arithmetic ((p - o) * (1 / d), two roundings), their minimum / maximum per axis (NaN-ignoring), the ray interval [1e-4, t], the pad
-  // kOwnPad < kBoxPad.  Subtraction and multiplication are monotone, so every box that encloses the triangle then passes its own test
-  // whenever the walk's tfar is still >= t: EVERY walk over EVERY tree reaches an accepted hit, and whether a ray hits a triangle is a
-  // function of the ray and the triangle alone.  (Without the rule an ill-conditioned test can "hit" outside the triangle's box, where a
-  // walk over tight boxes culls the triangle and a walk through wider ones does not.)
-  static bool in_own_box(Vec3 p0, Vec3 p1, Vec3 p2, const Ray &r, float th) {
-    if (!own_box_rule()) return true;  // (tests only: orc_debug_own_box_rule(0) shows what the rule is for)
+  // The own-box rule (round 6).  A candidate of fp32 Moeller-Trumbore at distance th counts as a hit only if the RAY MEETS THE
+  // PRIMITIVE'S OWN BOUNDING BOX -- the node test of 3.4 on that box: slab distances of the three vertices with the node test's arithmetic
+  // ((p - o) * (1 / d), two roundings), their minimum / maximum per axis (NaN-ignoring), tn = max(near, 1e-4), tf = min(far), tn <= tf * kOwnPad
+  // with kOwnPad < kBoxPad --, and its distance is AT LEAST THE BOX'S ENTRY: t = max(th, tn), still < tmax.  Subtraction and multiplication
+  // are monotone, so every box that encloses the primitive has tn' <= tn <= t and tf' >= tf: EVERY walk over EVERY tree whose best hit is
+  // still >= t reaches the primitive, and whether and where a ray hits a primitive is a function of the ray and the primitive alone.
+  // (Without the rule an ill-conditioned test "hits" outside the triangle's box, where a walk over tight boxes culls the triangle and a walk
+  // through wider ones does not.  Raising t to the box's entry instead of REJECTING a candidate that lies before it matters for triangles
+  // that lie flat in an axis plane -- every wall of a Cornell box: there entry = exit = the plane's own slab distance, Moeller-Trumbore's t
+  // differs from it by rounding (by far more for a sliver), and a rule that rejected would punch holes into walls.)
+  static bool own_box_rule(Vec3 p0, Vec3 p1, Vec3 p2, const Ray &r, float *th) {
+    if (!own_box_rule_on()) return true;  // (tests only: orc_debug_own_box_rule(0) shows what the rule is for)
     const Vec3 inv = {1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
     const float x0 = (p0.x - r.o.x) * inv.x, x1 = (p1.x - r.o.x) * inv.x, x2 = (p2.x - r.o.x) * inv.x;
     const float y0 = (p0.y - r.o.y) * inv.y, y1 = (p1.y - r.o.y) * inv.y, y2 = (p2.y - r.o.y) * inv.y;
@@ -297,8 +300,12 @@ class Scene {
     const float ny = std::fmin(std::fmin(y0, y1), y2), fy = std::fmax(std::fmax(y0, y1), y2);
     const float nz = std::fmin(std::fmin(z0, z1), z2), fz = std::fmax(std::fmax(z0, z1), z2);
     const float tn = std::fmax(std::fmax(nx, ny), std::fmax(nz, kRayTMin));
-    const float tf = std::fmin(std::fmin(fx, fy), std::fmin(fz, th));
-    return tn <= tf * kOwnPad;
+    const float tf = std::fmin(std::fmin(fx, fy), fz);
+    if (!(tn <= tf * kOwnPad)) return false;
+    const float t = std::fmax(*th, tn);
+    if (!(t < r.tmax)) return false;
+    *th = t;
+    return true;
   }
 
   // ---- Sphere::Intersect, quadratic per lib.rs:181-203 ----
@@ -318,7 +325,7 @@ class Scene {
     // the own-box rule on the sphere's box [c - r, c + r]: the "vertices" lo, hi, lo
     Vec3 lo, hi;
     sphere_box(sp, &lo, &hi);
-    if (!in_own_box(lo, hi, lo, r, th)) return false;
+    if (!own_box_rule(lo, hi, lo, r, &th)) return false;
     *tt = th;
     return true;
   }

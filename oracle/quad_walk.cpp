@@ -6,7 +6,7 @@
 // DESIGN.md 3.4 makes a hit independent of the tree, so any difference is a builder bug (a clipped or quantised box that
 // does not enclose what lies below it) -- and to count node steps / triangle tests per ray of a tree before it is ever
 // uploaded.  The arithmetic of one step follows the kernel instruction for instruction: node-relative planes
-// t = fma(q, cell * inv, -(g +- 3 eps |g|)), the (1 + 2^-16) pad, NaN-ignoring min / max, nearest hit child first,
+// t = fma(q, cell * inv, -(g +- 3 eps |g|)), the (1 + 2^-19) pad, NaN-ignoring min / max, nearest hit child first,
 // the other hit children stacked in slot order.  A lane of the kernel parks at a leaf until its triangles are tested, so
 // the per-ray sequence of steps is the sequential one written here.
 #include <cmath>
@@ -22,8 +22,8 @@ namespace {
 
 constexpr float kInf = __builtin_huge_valf();
 constexpr float kRayTMin = 1e-4f;
-constexpr float kBoxPad = 0x1.0001p+0f;   // 1 + 2^-16
-constexpr float kOwnPad = 0x1.00008p+0f;  // 1 + 2^-17: the own-box rule of DESIGN.md 3.5
+constexpr float kBoxPad = 0x1.000004p+0f;  // 1 + 2^-19
+constexpr float kOwnPad = 0x1.000001p+0f;  // 1 + 2^-21: the own-box rule of DESIGN.md 3.5
 constexpr uint32_t kLeafRef = 0x80000000u, kDone = 0xffffffffu, kNoPrim = 0xffffffffu;
 
 inline float fminn(float a, float b) { return std::fmin(a, b); }  // IEEE minNum / maxNum: a NaN operand is ignored
@@ -236,11 +236,12 @@ void walk(const Tree &T, V3 o, V3 d, float tmax, bool any, Out *out) {
       const float y0 = (-tv.y) * inv1.y, y1 = w1.y * inv1.y, y2 = w2.y * inv1.y;
       const float z0 = (-tv.z) * inv1.z, z1 = w1.z * inv1.z, z2 = w2.z * inv1.z;
       const float otn = fmaxn(fmaxn(fminn(fminn(x0, x1), x2), fminn(fminn(y0, y1), y2)), fmaxn(fminn(fminn(z0, z1), z2), kRayTMin));
-      const float otf = fminn(fminn(fmaxn(fmaxn(x0, x1), x2), fmaxn(fmaxn(y0, y1), y2)), fminn(fmaxn(fmaxn(z0, z1), z2), th));
-      const bool in_own_box = otn <= otf * kOwnPad;
-      const bool valid = in_own_box && !(std::fabs(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < tmax);
+      const float otf = fminn(fminn(fmaxn(fmaxn(x0, x1), x2), fmaxn(fmaxn(y0, y1), y2)), fmaxn(fmaxn(z0, z1), z2));
+      const bool in_own_box = otn <= otf * kOwnPad;   // the ray meets the triangle's own box ...
+      const float ht = fmaxn(th, otn);                  // ... and the hit is not before the box's entry
+      const bool valid = in_own_box && !(std::fabs(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (ht < tmax);
       if (valid && any) { r.occluded = true; stop = true; }
-      if (valid && !any && (th < r.t || (th == r.t && id < r.prim))) { r.t = th; r.prim = id; r.b1 = u; r.b2 = v; }
+      if (valid && !any && (ht < r.t || (ht == r.t && id < r.prim))) { r.t = ht; r.prim = id; r.b1 = u; r.b2 = v; }
     }
     cur = stop ? kDone : pop();
   }

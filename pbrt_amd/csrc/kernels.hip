@@ -38,8 +38,8 @@ constexpr float kInf = __builtin_huge_valf();
 constexpr float kRayTMin = 1e-4f;
 constexpr float kSpawnEps = 1e-4f;
 constexpr float kShadowShrink = 0.9999f;
-constexpr float kBoxPad = 0x1.0001p+0f;   // 1 + 2^-16: the node test's far-side pad (pbrt-v3 pads by 1 + 2 gamma(3))
-constexpr float kOwnPad = 0x1.00008p+0f;  // 1 + 2^-17: the own-box rule's pad (3.5), strictly inside kBoxPad
+constexpr float kBoxPad = 0x1.000004p+0f;  // 1 + 2^-19: the node test's far-side pad (pbrt-v3 pads by 1 + 2 gamma(3) = 1 + 6 * 2^-24)
+constexpr float kOwnPad = 0x1.000001p+0f;  // 1 + 2^-21: the own-box rule's pad (3.5), strictly inside kBoxPad
 constexpr float kInvPi = 0.31830988618379067154f;
 constexpr float kPiOver4 = 0.78539816339744830961f;
 constexpr float kOneMinusEps = 0x1.fffffcp-1f;  // 1 - f32::EPSILON = 1 - 2^-23, core/rng.rs:19 (NOT pbrt-v3's 1 - 2^-24)
@@ -605,23 +605,27 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
           const V3 qv = cross(tv, e1);
           const float v = dot(d, qv) * idet;
           const float th = dot(e2, qv) * idet;
-          // The own-box rule (round 6): the node test of 3.4 on the triangle's OWN box with tfar = this hit's t -- slab
-          // distances of the three vertices with the TRUE 1 / d (two roundings each, as the canonical node test; p0 - o = -tv exactly),
-          // their min / max per axis, the interval [1e-4, t], pad kOwnPad < kBoxPad.  Monotone arithmetic: every enclosing box of every
-          // tree passes whenever this does, so an accepted hit is reached by every walk and a hit is a function of (ray, triangle) alone.
+          // The own-box rule (round 6): the ray must MEET the triangle's own box -- the node test of 3.4 on it: slab distances
+          // of the three vertices with the TRUE 1 / d (two roundings each, as the canonical node test; p0 - o = -tv exactly), their min / max
+          // per axis, pad kOwnPad < kBoxPad -- and the hit's distance is at least the box's entry: t = max(th, entry).  Monotone arithmetic:
+          // every enclosing box of every tree then passes its own test while the walk's best hit is still >= t, so an accepted hit is reached
+          // by every walk and a hit is a function of (ray, triangle) alone.  (Raising t instead of rejecting: a triangle flat in an axis plane
+          // has entry = exit = the plane's slab distance, which Moeller-Trumbore's t misses by rounding.)
 #ifdef PBRT_NO_OWN_BOX_RULE  // A-B switch: the leaf pass as it was until round 5 (what the rule costs; films differ where it rejects)
           const bool in_own_box = true;
+          const float tsnap = th;
 #else
           const V3 w1 = xyz(b) - o, w2 = xyz(c) - o;
           const float x0 = (-tv.x) * inv1.x, x1 = w1.x * inv1.x, x2 = w2.x * inv1.x;
           const float y0 = (-tv.y) * inv1.y, y1 = w1.y * inv1.y, y2 = w2.y * inv1.y;
           const float z0 = (-tv.z) * inv1.z, z1 = w1.z * inv1.z, z2 = w2.z * inv1.z;
           const float otn = fmaxf(fmaxf(fminf(fminf(x0, x1), x2), fminf(fminf(y0, y1), y2)), fmaxf(fminf(fminf(z0, z1), z2), kRayTMin));
-          const float otf = fminf(fminf(fmaxf(fmaxf(x0, x1), x2), fmaxf(fmaxf(y0, y1), y2)), fminf(fmaxf(fmaxf(z0, z1), z2), th));
+          const float otf = fminf(fminf(fmaxf(fmaxf(x0, x1), x2), fmaxf(fmaxf(y0, y1), y2)), fmaxf(fmaxf(z0, z1), z2));
           const bool in_own_box = otn <= otf * kOwnPad;
+          const float tsnap = fmaxf(th, otn);
 #endif
-          bool valid = in_own_box && !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (th < T.tmax);
-          float ht = th, hu = u, hv = v;
+          bool valid = in_own_box && !(fabsf(det) < 1e-8f) && (u >= 0.f) && (v >= 0.f) && (u + v <= 1.0f) && (th > kRayTMin) && (tsnap < T.tmax);
+          float ht = tsnap, hu = u, hv = v;
           if (SPH && __float_as_uint(c.w) != 0u) {
             // a SPHERE's record (round 6: spheres are primitives of the tree): {centre, primitive id}{radius, -, -, material}
             // {-, -, -, 1}.  Sphere::Intersect with the f64 quadratic of lib.rs:181-203, then the own-box rule on [c - r, c + r] (the
@@ -633,9 +637,10 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
             const float sx0 = (lo.x - o.x) * inv1.x, sx1 = (hi.x - o.x) * inv1.x, sy0 = (lo.y - o.y) * inv1.y, sy1 = (hi.y - o.y) * inv1.y;
             const float sz0 = (lo.z - o.z) * inv1.z, sz1 = (hi.z - o.z) * inv1.z;
             const float stn = fmaxf(fmaxf(fminf(fminf(sx0, sx1), sx0), fminf(fminf(sy0, sy1), sy0)), fmaxf(fminf(fminf(sz0, sz1), sz0), kRayTMin));
-            const float stf = fminf(fminf(fmaxf(fmaxf(sx0, sx1), sx0), fmaxf(fmaxf(sy0, sy1), sy0)), fminf(fmaxf(fmaxf(sz0, sz1), sz0), ts));
-            valid = valid && stn <= stf * kOwnPad;
-            ht = ts; hu = 0.f; hv = 0.f;
+            const float stf = fminf(fminf(fmaxf(fmaxf(sx0, sx1), sx0), fmaxf(fmaxf(sy0, sy1), sy0)), fmaxf(fmaxf(sz0, sz1), sz0));
+            ht = fmaxf(ts, stn);
+            valid = valid && stn <= stf * kOwnPad && ht < T.tmax;
+            hu = 0.f; hv = 0.f;
           }
           const uint32_t id = __float_as_uint(a.w);
           const bool occl = valid && T.any != 0u;  // any-hit ray: the walk ends at the first valid hit

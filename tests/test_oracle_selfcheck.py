@@ -647,3 +647,46 @@ def test_every_walk_reaches_what_the_own_box_rule_accepts(oracle, name):
             assert oracle.quad_path_check(q["quads"], q["root_box"], q["order"], o[keep], d[keep], tri[keep], th[keep]).any()
         finally:
             oracle.debug_own_box_rule(True)
+
+
+def test_flat_slivers_have_no_holes(oracle):
+    """DESIGN.md 3.5, why the own-box rule RAISES a candidate's distance to its box's entry instead of rejecting it: a triangle lying flat in
+    an axis plane has a box of zero thickness -- entry = exit = the plane's slab distance --, and fp32 Moeller-Trumbore's t for the same plane
+    differs from it by rounding x the triangle's condition number (a sliver rotated in its plane: hundreds of ulps).  Rays aimed at points
+    well inside nine such slivers (aspect 200 ... 20 000, in all three axis planes) must ALL hit them -- through the BVH, the brute force and
+    the production walk alike --, never before the slab distance fp32 computes for the plane (and within Moeller-Trumbore's own noise above
+    it: 1e-3 of the distance for the thinnest sliver)."""
+    from pbrt_amd.api import quad_build_host_ex
+    from util import flat_sliver_scene
+    sd, n = flat_sliver_scene()
+    sc = oracle.OracleScene(sd)
+    rng = np.random.default_rng(12)
+    m = 60_000
+    tri = rng.integers(0, n, m)
+    b = rng.uniform(0.1, 0.8, (m, 2))
+    b[b.sum(1) > 0.9] *= 0.5                                   # barycentrics well inside: (0.1 ... 0.8, sum <= 0.9)
+    V = sd.P[sd.idx[tri]].astype(np.float64)
+    target = V[:, 0] + (V[:, 1] - V[:, 0]) * b[:, :1] + (V[:, 2] - V[:, 0]) * b[:, 1:]
+    o = rng.uniform(-3, 3, (m, 3))
+    dv = target - o
+    dist = np.linalg.norm(dv, axis=1)
+    o, d = o.astype(np.float32), (dv / dist[:, None]).astype(np.float32)
+    tmax = np.full(m, np.inf, np.float32)
+    ok, th = sc.tri_accepts(o, d, tmax, tri.astype(np.uint32))
+    axis = tri // 3
+    grazing = np.abs(d[np.arange(m), axis]) < 1e-3               # (a ray nearly IN the plane is another matter: |det| < 1e-8, edge-on)
+    assert ok[~grazing].all(), int((ok[~grazing] == 0).sum())    # no holes
+    plane = sd.P[sd.idx[tri, 0], axis].astype(np.float64)
+    t64 = (plane - o[np.arange(m), axis].astype(np.float64)) / d[np.arange(m), axis].astype(np.float64)
+    good = ~grazing & (t64 > 1e-3)
+    assert np.abs(th[good] / t64[good] - 1).max() < 5e-3, np.abs(th[good] / t64[good] - 1).max()
+    slab = ((sd.P[sd.idx[tri, 0], axis] - o[np.arange(m), axis]) * (np.float32(1) / d[np.arange(m), axis])).astype(np.float32)
+    assert (th[good] >= slab[good]).all()                        # never before the box's entry
+    # the walks agree with each other (BVH, brute force, the production walk over both product trees)
+    t, prim, *_ = sc.intersect(o, d, tmax)
+    bt, bprim, *_ = sc.intersect(o, d, tmax, brute_force=True)
+    assert np.array_equal(prim, bprim) and np.array_equal(t.view(np.uint32), bt.view(np.uint32))
+    for tree in ("sah", "reinsert"):
+        q = quad_build_host_ex(sd.P, sd.idx, tree=tree)
+        got = oracle.quad_walk(q["quads"], q["root_box"], sd.P, sd.idx, q["order"], o, d, tmax)
+        assert np.array_equal(got["prim"], prim) and np.array_equal(got["t"].view(np.uint32), t.view(np.uint32)), tree

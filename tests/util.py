@@ -105,6 +105,30 @@ def with_sphere_proxies(sd):
     return Pa, np.concatenate([idx, np.stack([v0, v0 + 1, v0], 1)]).astype(np.uint32)
 
 
+def flat_sliver_scene(xres=48, yres=48):
+    """Slivers lying FLAT in axis planes and rotated in them (aspect 200 ... 20 000): where a triangle's own box has entry = exit = the
+    plane's slab distance and fp32 Moeller-Trumbore's t for the same plane is off by rounding times the sliver's condition number -- the case
+    that decided HOW the own-box rule treats a candidate that lies before its box's entry (its distance is raised to the entry,
+    the candidate is not rejected: a rejecting rule punched holes into 7 % ... 44 % of such hits).  -> (SceneData, number of slivers)"""
+    from pbrt_amd.api import LIGHT_INFINITE, MATTE, SceneData, look_at
+    P, idx = [], []
+    for axis in range(3):
+        for k, eps in enumerate((1e-2, 1e-3, 1e-4)):
+            a, b = (axis + 1) % 3, (axis + 2) % 3
+            base = len(P)
+            for q in ((0.0, 0.0), (2.0, 0.2), (2.0, 0.2 + eps * 2.0)):  # a sliver of two long edges at a small angle, rotated in its plane
+                v = [0.0, 0.0, 0.0]
+                v[axis] = 0.5 * (axis + 1) + 0.125 * k
+                v[a], v[b] = q[0] - 1.0, q[1] - 0.3 * k
+                P.append(v)
+            idx.append([base, base + 1, base + 2])
+    n = len(idx)
+    sd = SceneData(P=np.array(P, np.float32), idx=np.array(idx, np.uint32), mat_id=np.zeros(n, np.uint16),
+                   materials=np.array([[MATTE, .6, .6, .6, 0, 0, 0]], np.float32), lights=np.array([[LIGHT_INFINITE, 0, 0, 0, 1, 1, 1]], np.float32),
+                   cam_to_world=look_at((4, 3, 5), (0, 0, 0), (0, 0, 1))[1], fov=40.0, xres=xres, yres=yres).normalized()
+    return sd, n
+
+
 def sphere_cloud_scene(n_spheres=2000, xres=64, yres=64, n_tris=64, seed=9, radius_scale=0.6):
     """`n_spheres` matte / mirror spheres (centres ~ U[-1, 1]^3, radii ~ radius_scale x n^(-1/3) x U[0.3, 1]) inside the random-mesh scene's box
     with its ceiling light and `n_tris` of its random triangles: spheres as primitives of the tree (round 6) -- overlapping ones, tiny

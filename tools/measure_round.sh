@@ -14,7 +14,7 @@ O=$R/gpurun_out
 cd $R
 export PBRT_HIP_DEBUG_KNOBS=1
 export PROBE_BUILDER=gpu   # the probes use the builder bench.py's default does (the device builder)
-timeout 1800 python3 -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -4 > $O/${TAG}_pytest_gpu.log
+timeout 2400 python3 -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -40 > $O/${TAG}_pytest_gpu.log
 python3 -c "from oracle import binding as ob; ob.build(native=True)"   # (the CPU leg's oracle is built before any profiler runs)
 # FETCH_SIZE against known bytes in the kernel's access shape (round 6): the factor summarize_profile.py stores in pmc_<wl>.json
 bash tools/fetch_size_calibration.sh fetch_cal_${TAG} > $O/fetch_cal_${TAG}.log 2>&1
