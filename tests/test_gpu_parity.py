@@ -109,7 +109,7 @@ def test_a_hit_is_a_function_of_ray_and_triangle_alone(gpu, oracle, name, builde
         keep = ok != 0
         V = sd.P[sd.idx.reshape(-1)]
         fails = oracle.quad_path_check(quads, np.concatenate([V.min(0), V.max(0)]), order, o[keep], d[keep], tri[keep], th[keep])
-        assert keep.sum() > 1000 and not fails.any(), (int(keep.sum()), int((fails != 0).sum()))
+        assert keep.sum() > (100 if name == "deep" else 1000) and not fails.any(), (int(keep.sum()), int((fails != 0).sum()))  # (the deep scene's triangles are specks)
 
 
 @pytest.mark.parametrize("builder", [None, "host", "gpu-plain"])
