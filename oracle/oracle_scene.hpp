@@ -340,7 +340,7 @@ class Scene {
   // Bounds3::IntersectP: slab test against [kRayTMin, tfar].  Near / far plane per axis chosen by
   // the sign of the inverse direction (pbrt-v3 dirIsNeg); a 0 * inf = NaN (ray parallel to a slab
   // and starting exactly on its plane) is ignored by fmin / fmax, which keeps the test
-  // conservative; far side padded by 1 + 2*gamma(3).
+  // conservative; far side padded by kBoxPad (1 + 2^-19 since round 6; pbrt-v3: 1 + 2*gamma(3)).
   static bool box_hit(const LinearBVHNode &n, const Ray &r, Vec3 inv, const int neg[3], float tfar) {
     float nx = ((neg[0] ? n.bmax[0] : n.bmin[0]) - r.o.x) * inv.x, fx = ((neg[0] ? n.bmin[0] : n.bmax[0]) - r.o.x) * inv.x;
     float ny = ((neg[1] ? n.bmax[1] : n.bmin[1]) - r.o.y) * inv.y, fy = ((neg[1] ? n.bmin[1] : n.bmax[1]) - r.o.y) * inv.y;

@@ -468,7 +468,7 @@ __device__ __forceinline__ void trav_run(const DevScene &S, Trav &T, uint32_t *s
       // roundings inside gi = fl(fl(o - origin) * inv) are absolute errors <= 2 eps |gi| in t, covered by
       // the margin m = 3 eps |gi|: near planes subtract gi + m, far planes gi - m, so every computed
       // t_near / t_far lies outside the true one and the walk stays a superset of the exact walk; the
-      // fma's own relative rounding is what the (1 + 2 gamma_3) pad of DESIGN.md 3.4 is for.  A ray
+      // fma's own relative rounding is what kBoxPad of DESIGN.md 3.4 is for (1 + 2^-19 since round 6).  A ray
       // parallel to the slab (d = 0) has the scene's finite stand-in for 1 / 0 in inv (above): t is then
       // negative huge or positive huge by the side of the plane the origin is on; an inv that is infinite
       // because d is a denormal yields NaN or +-inf, which fmin / fmax ignore or keep conservative.
