@@ -263,7 +263,10 @@ int pbrt_hip_render_multi(const pbrt_hip_scene_desc *desc, const pbrt_hip_render
 
 /* Ray-batch entry points: the traversal kernels on their own (parity + roofline of the
  * dominant loop).  Host SoA-of-xyz arrays, n rays.  prim = 0xffffffff on a miss.  A ray whose origin or direction has a component
- * that is not finite, or whose tmax is NaN, is a miss (and is not walked); direction components that are exactly 0 are fine. */
+ * that is not finite, or whose tmax is NaN, is a miss (and is not walked); direction components that are exactly 0 are fine.
+ * What counts as a hit (the own-box rule): the triangle / sphere test's candidate, provided the ray meets the primitive's own
+ * bounding box; t is at least the distance at which it enters that box.  Whether and where a ray hits a primitive depends on the ray and the
+ * primitive alone -- never on the tree, the builder or the walk -- and ties on t go to the lower primitive number (spheres: n_tris + index). */
 int pbrt_hip_intersect(pbrt_hip_scene *scene, int64_t n, const float *o, const float *d, const float *tmax, float *t,
                        uint32_t *prim, float *b1, float *b2, uint64_t *counters /* 2, may be NULL */);
 int pbrt_hip_occluded(pbrt_hip_scene *scene, int64_t n, const float *o, const float *d, const float *tmax,
