@@ -220,8 +220,6 @@ struct QuadChild {
   uint32_t leaf_node;  // binary leaf to expand into its own quad node, or 0xffffffff
 };
 enum Collapse { kCollapsePlain = 0, kCollapseGreedy = 1, kCollapseDp = 2 };
-// EXPERIMENT (round 6, PBRT_HIP_REINSERT_QUADW; build_production_quads): when set, the collapse marks the binary nodes it keeps as quad nodes
-static std::vector<uint8_t> *g_collapse_marks = nullptr;
 // `b`: the binary tree over triangle references (the canonical tree through refs_of_bvh, or the optimised single-triangle tree of
 // single_ref_tree + reinsert_optimize_batch); slot_of_ref[r] = slot of reference r's triangle in the leaf-ordered triangle records (null: r itself).
 void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split_leaves, Collapse how, QuadNodes *out) {
@@ -326,7 +324,6 @@ void make_quad_nodes_as(const RefBvh &b, const uint32_t *slot_of_ref, bool split
     const Item it = todo.back();
     todo.pop_back();
     const BvhNode &me = b.nodes[it.node];
-    if (g_collapse_marks && !it.is_leaf) (*g_collapse_marks)[it.node] = 1;
     QuadChild kids[4];
     int nk = 0;
     auto add_node = [&](uint32_t c) {
@@ -581,38 +578,6 @@ void build_production_quads(const Bvh &canon, const float *P, const uint32_t *id
     single_ref_tree(canon, P, idx, &rb);
     const ReinsertBatchParams rp = reinsert_batch_params();
     if (n_tris >= rp.stop.min_tris) reinsert_optimize_batch(&rb, rp);  // (smaller trees stay as built, as on the device)
-    // EXPERIMENT (round 6, simulator only: tools/walk_sim.py): re-insertion scored by the 4-WIDE tree.  The binary pass
-    // minimises the summed area of ALL interior nodes; the walk pays only for the ones the collapse keeps as quad nodes.  Rounds of
-    // {collapse -> weight 1 for the kept nodes, w_low for the absorbed ones -> a few weighted passes}.  PBRT_HIP_REINSERT_QUADW=w_low:rounds:passes
-    if (const char *qw = debug_knob("PBRT_HIP_REINSERT_QUADW")) {
-      float w_low = 0.5f;
-      int rounds = 2, passes = 3;
-      std::sscanf(qw, "%f:%d:%d", &w_low, &rounds, &passes);
-      for (int r = 0; r < rounds && n_tris >= rp.stop.min_tris; r++) {
-        std::vector<uint8_t> marks(rb.nodes.size(), 0);
-        QuadNodes tmp;
-        g_collapse_marks = &marks;
-        make_quad_nodes_as(rb, nullptr, true, kCollapseDp, &tmp);
-        g_collapse_marks = nullptr;
-        LinkTree lt;
-        link_tree_of(rb, &lt);
-        std::vector<float> w(2 * (size_t)lt.n_int + 1, 1.0f);
-        uint32_t next = 0;  // (link_tree_of numbers the interior nodes in depth-first order)
-        size_t kept = 0;
-        for (size_t i = 0; i < rb.nodes.size(); i++)
-          if ((rb.nodes[i].count_axis & 0xffffu) == 0) { w[next++] = marks[i] ? 1.0f : w_low; kept += marks[i]; }
-        ReinsertBatchParams wp = rp;
-        wp.passes = passes;
-        wp.search.w = w.data();
-        ReinsertBatchStats st;
-        reinsert_batch_links(&lt, wp, &st);
-        RefBvh o;
-        ref_bvh_of(lt, rb, &o);
-        rb = std::move(o);
-        if (std::getenv("PBRT_HIP_REINSERT_VERBOSE"))
-          std::fprintf(stderr, "quad-weighted round %d: %zu of %u interior nodes kept by the collapse, %llu moves applied\n", r, kept, lt.n_int, (unsigned long long)st.applied);
-      }
-    }
     if (std::getenv("PBRT_HIP_REINSERT_VERBOSE")) {
       LinkTree lt;
       link_tree_of(rb, &lt);

@@ -250,7 +250,7 @@ void reinsert_batch_links(LinkTree *lt, const ReinsertBatchParams &prm, Reinsert
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     const float to_fix = ldexpf(1.0f, se);
     unsigned long long sum = 0;
-    for (uint32_t i = 0; i < n_int; i++) sum += (unsigned long long)((prm.search.w ? prm.search.w[i] : 1.0f) * reins::area(reins::load_box(t, i)) * to_fix);
+    for (uint32_t i = 0; i < n_int; i++) sum += (unsigned long long)(reins::area(reins::load_box(t, i)) * to_fix);
     return sum;
   };
   unsigned long long cost = fixed_cost();
@@ -263,7 +263,7 @@ void reinsert_batch_links(LinkTree *lt, const ReinsertBatchParams &prm, Reinsert
     uint64_t visits = 0, found = 0, max_v = 0;
     for (uint32_t x = 0; x < n_nodes; x++) {
       if ((x + (uint32_t)pass) % mu != 0u) { mv[x].y = kNone; continue; }
-      mv[x] = prm.search.w ? reins::find_move<true>(t, x, prm.search) : reins::find_move(t, x, prm.search);
+      mv[x] = reins::find_move(t, x, prm.search);
       visits += mv[x].visits;
       max_v = std::max<uint64_t>(max_v, mv[x].visits);
       found += mv[x].y != kNone;

@@ -129,10 +129,6 @@ struct Search {
   // triangles smaller than a top-level cell (1M triangles: 0.010 against 0.016) hangs triangles that straddle a split high
   // in the tree: 11 % MORE triangle tests per ray than the unoptimised tree instead of 3 % fewer (tools/experiments/README.md).
   float qk = 2.0f / 255.0f, qw = 2.0f;
-  // EXPERIMENT (round 6, host run only; find_move<true>): a weight per node on its area in the objective -- 1 for the binary nodes the
-  // 4-wide collapse keeps as quad nodes, less for the ones it absorbs (tools/experiments/README.md "re-insertion scored by the 4-wide
-  // tree").  The product (device and host) runs find_move<false>, which never reads it.
-  const float *w = nullptr;
 };
 
 // the surface area of box b as a grid of cell size k x extent(q) per axis holds it
@@ -140,9 +136,7 @@ RI_HD float area_on(const Box &b, const Box &q, float k) {
   const float dx = (b.hi[0] - b.lo[0]) + k * (q.hi[0] - q.lo[0]), dy = (b.hi[1] - b.lo[1]) + k * (q.hi[1] - q.lo[1]), dz = (b.hi[2] - b.lo[2]) + k * (q.hi[2] - q.lo[2]);
   return (dx * dy + dx * dz) + dy * dz;
 }
-template <bool WEIGHTED = false>
 RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
-  auto wt = [&](uint32_t i) { return WEIGHTED ? sp.w[i] : 1.0f; };
   const uint32_t max_visits = sp.max_visits;
   const float min_rel = sp.min_rel, qk = sp.qk, qw = sp.qw;
   Move m;
@@ -163,9 +157,8 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
   se = se > 100 ? 100 : (se < -100 ? -100 : se);
   const float to_fix = ldexpf(1.0f, se), from_fix = ldexpf(1.0f, -se);
   const Box bp0 = load_box(t, p);
-  const float wp = wt(p);   // (the re-used node p keeps its weight where it lands)
-  float saved = wp * area(bp0);  // taking x out: p disappears (below: + what the ancestors under the pivot shrink by)
-  float best = min_rel * area(bp0);
+  float saved = area(bp0);  // taking x out: p disappears (below: + what the ancestors under the pivot shrink by)
+  float best = min_rel * saved;
   const float wx = x < t.n_int ? 1.f : qw;
   const float q_old = qk > 0.f ? wx * area_on(bxx, bp0, qk) : 0.f, q_min = qk > 0.f ? wx * area_on(bxx, bxx, qk) : 0.f;
   uint32_t pivot = p, other = sibling(t, p, x), visits = 0;
@@ -184,16 +177,16 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
           const Box bo = out == other ? top : load_box(t, out);
           visits++;
           const Box un = unite(bo, bxx);
-          const float direct = wp * area(un);
+          const float direct = area(un);
           const float c = (float)ci * from_fix;
           if (!(first && out == other)) {  // (x's own sibling: putting x back where it was)
             float g = (saved - c) - direct;
             if (qk > 0.f) g -= wx * area_on(bxx, un, qk) - q_old;
             if (g > best) { best = g; m.y = out; m.lca = pivot; }
           }
-          const long long di = (long long)((wt(out) * (area(un) - area(bo))) * to_fix);
+          const long long di = (long long)((direct - area(bo)) * to_fix);
           const float cn = (float)(ci + di) * from_fix;
-          if (out < t.n_int && ((saved - cn) - wp * ax) - (q_min - q_old) > best && visits < max_visits) {
+          if (out < t.n_int && ((saved - cn) - ax) - (q_min - q_old) > best && visits < max_visits) {
             ci += di;
             out = t.kid[2 * (size_t)out];
             continue;
@@ -207,7 +200,7 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
           down = true;
         } else {
           const Box bq = load_box(t, q);
-          ci -= (long long)((wt(q) * (area(unite(bq, bxx)) - area(bq))) * to_fix);  // the term q added on the way down, bit for bit
+          ci -= (long long)((area(unite(bq, bxx)) - area(bq)) * to_fix);  // the term q added on the way down, bit for bit
           out = q;
         }
       }
@@ -218,11 +211,11 @@ RI_HD Move find_move(const Tree &t, uint32_t x, const Search &sp) {
     if (up == kNone) break;
     if (!first) {
       // x as the sibling of the pivot itself: the pivot shrinks to nb, the freed node above it gets the pivot's old box
-      const float an = area(nb), apv = area(load_box(t, pivot));
-      float g = WEIGHTED ? saved - ((wp * apv + wt(pivot) * an) - wt(pivot) * apv) : saved - an;
+      const float an = area(nb);
+      float g = saved - an;
       if (qk > 0.f) g -= wx * area_on(bxx, load_box(t, pivot), qk) - q_old;
       if (g > best) { best = g; m.y = pivot; m.lca = up; }
-      saved += wt(pivot) * (apv - an);
+      saved += area(load_box(t, pivot)) - an;
     }
     other = sibling(t, up, pivot);
     pivot = up;
