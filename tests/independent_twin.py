@@ -1,0 +1,294 @@
+"""A SECOND implementation of the path of DESIGN.md section 3, in float64 numpy, that shares the RANDOM NUMBERS with the oracle and the
+library and nothing else: test infrastructure, like oracle/, written from the spec's text (3.1 sampler and chunks, 3.2 camera, 3.5
+Moeller-Trumbore -- the textbook's, every ray against every triangle, no BVH, no own-box rule --, 3.7 surface and BSDFs, 3.8 one-light direct
+estimate, 3.9 path loop, roulette and film), with numpy's own sin / cos / sqrt where the spec fixes polynomials.
+
+What it is for: north_star's "PSNR >= 50 dB vs the reference image".  The oracle and the HIP path agree bit for bit, which proves that two
+restatements of ONE spec by one author agree; tests/independent_mc.py agrees with them statistically.  This file sits between the two: because
+sample s of pixel (x, y) draws the same numbers here, its path is the same path up to rounding, and the IMAGES can be compared directly --
+a wrong term (a pdf, a cosine, the n_lights factor, the order of the draws, the depth rule, the roulette weight) would show in every pixel.
+What differs legitimately: float64 against fp32 arithmetic (1e-6 relative), and a handful of paths per image whose discrete decisions (which
+triangle at an edge, roulette at the threshold, the picked light) fall the other way.
+
+Supported: triangles (matte / mirror, emissive = area lights), point / distant / constant-infinite lights, integrators 0 (path) and 1
+(direct), the stratified sampler, the default box filter.  No spheres, textures, MIS or table samplers."""
+import numpy as np
+
+_M = np.uint64(0x5851F42D4C957F2D)
+_EPS1 = np.float32(1.0) - np.float32(2.0 ** -23)  # 1 - f32::EPSILON (core/rng.rs:19)
+
+
+class _Pcg:
+    """n PCG32 streams (core/rng.rs:46-93: set_sequence, uniform_u32, uniform_float), advanced only where `mask` says so"""
+
+    def __init__(self, seq):
+        seq = np.asarray(seq, np.uint64)
+        self.inc = (seq << np.uint64(1)) | np.uint64(1)
+        self.state = np.zeros_like(seq)
+        self._u32(np.ones(len(seq), bool))
+        with np.errstate(over="ignore"):
+            self.state = self.state + np.uint64(0x853C49E6748FEA9B)
+        self._u32(np.ones(len(seq), bool))
+
+    def _u32(self, mask):
+        old = self.state
+        with np.errstate(over="ignore"):
+            self.state = np.where(mask, old * _M + self.inc, old)
+        xs = (((old >> np.uint64(18)) ^ old) >> np.uint64(27)).astype(np.uint32)
+        rot = (old >> np.uint64(59)).astype(np.uint32)
+        return (xs >> rot) | (xs << ((~rot + np.uint32(1)) & np.uint32(31)))
+
+    def uniform(self, mask):
+        """one uniform_float per stream of `mask` (fp32, as the spec's arithmetic has it); the others keep their state"""
+        u = self._u32(mask).astype(np.float32) * np.float32(2.3283064365386963e-10)
+        return np.minimum(u, _EPS1)
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def _closest(o, d, tmax, p0, e1, e2, any_hit=False):
+    """every ray against every triangle, float64: (t, triangle, u, v) of the closest hit in (1e-4, tmax), triangle -1 for a miss;
+    ties to the lower triangle number"""
+    n = len(o)
+    t_best, tri, ub, vb = np.full(n, np.inf), np.full(n, -1, np.int64), np.zeros(n), np.zeros(n)
+    step = max(64, 400_000 // max(1, len(p0)))
+    for a in range(0, n, step):
+        sl = slice(a, min(n, a + step))
+        with np.errstate(all="ignore"):
+            oo, dd = o[sl, None, :], d[sl, None, :]
+            pv = np.cross(dd, e2[None])
+            det = (e1[None] * pv).sum(-1)
+            inv = 1.0 / det
+            tv = oo - p0[None]
+            u = (tv * pv).sum(-1) * inv
+            qv = np.cross(tv, e1[None])
+            v = (dd * qv).sum(-1) * inv
+            t = (e2[None] * qv).sum(-1) * inv
+            ok = (np.abs(det) >= 1e-8) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 1e-4) & (t < tmax[sl, None])
+        tt = np.where(ok, t, np.inf)
+        k = tt.argmin(1)  # (argmin returns the first minimum: the lower triangle number at equal t)
+        r = np.arange(tt.shape[0])
+        hit = np.isfinite(tt[r, k])
+        t_best[sl], tri[sl] = tt[r, k], np.where(hit, k, -1)
+        ub[sl], vb[sl] = u[r, k], v[r, k]
+    return t_best, tri, ub, vb
+
+
+def _cosine_about(n, u1, u2):
+    """pbrt-v3 CosineSampleHemisphere through ConcentricSampleDisk, in the frame CoordinateSystem(n) gives; -> (wi, z)"""
+    ox, oy = 2.0 * u1 - 1.0, 2.0 * u2 - 1.0
+    with np.errstate(all="ignore"):
+        wide = np.abs(ox) > np.abs(oy)
+        r = np.where(wide, ox, oy)
+        phi = np.where(wide, (np.pi / 4) * (oy / ox), np.pi / 2 - (np.pi / 4) * (ox / oy))
+    zero = (ox == 0) & (oy == 0)
+    dx, dy = np.where(zero, 0.0, r * np.cos(phi)), np.where(zero, 0.0, r * np.sin(phi))
+    z = np.sqrt(np.maximum(0.0, 1.0 - dx * dx - dy * dy))
+    big_x = np.abs(n[:, 0]) > np.abs(n[:, 1])
+    with np.errstate(all="ignore"):
+        v2a = np.stack([-n[:, 2], np.zeros(len(n)), n[:, 0]], 1) / np.sqrt(n[:, 0] ** 2 + n[:, 2] ** 2)[:, None]
+        v2b = np.stack([np.zeros(len(n)), n[:, 2], -n[:, 1]], 1) / np.sqrt(n[:, 1] ** 2 + n[:, 2] ** 2)[:, None]
+    v2 = np.where(big_x[:, None], v2a, v2b)
+    v3 = np.cross(n, v2)
+    return v2 * dx[:, None] + v3 * dy[:, None] + n * z[:, None], z
+
+
+def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
+    """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image, no crop window)"""
+    sd = sd.normalized()
+    assert sd.spheres.shape[0] == 0 and tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0)
+    W, H = int(sd.xres), int(sd.yres)
+    nx, ny = spp
+    n_spp = nx * ny
+    K = 1
+    while 2 * K <= 16 and 2 * K * 32 <= n_spp:
+        K *= 2
+    P = sd.P.astype(np.float64)[sd.idx.astype(np.int64)]
+    p0, p1, p2 = P[:, 0], P[:, 1], P[:, 2]
+    e1, e2 = p1 - p0, p2 - p0
+    mats = sd.materials.astype(np.float64)
+    mat_of = sd.mat_id.astype(np.int64)
+    is_mirror = mats[:, 0] == 1
+    kcol, le = mats[:, 1:4], mats[:, 4:7]
+    # the light list (3.8): explicit lights in order, then every emissive triangle in index order
+    L = []
+    for row in sd.lights.astype(np.float64):
+        L.append(dict(type=int(row[0]), p=row[1:4], c=row[4:7]))
+    le_inf = sum((l["c"] for l in L if l["type"] == 2), np.zeros(3))
+    has_inf = any(l["type"] == 2 for l in L)
+    for t in range(len(P)):
+        if (le[mat_of[t]] > 0).any():
+            cr = np.cross(e1[t], e2[t])
+            L.append(dict(type=3, p=p0[t], p1=p1[t], p2=p2[t], c=le[mat_of[t]], n=cr / np.linalg.norm(cr), area=0.5 * np.linalg.norm(cr)))
+    nL = len(L)
+    nLf = np.float32(nL)
+    ltype = np.array([l["type"] for l in L], np.int64) if nL else np.zeros(0, np.int64)
+    lp = np.array([l["p"] for l in L]).reshape(-1, 3)
+    lc = np.array([l["c"] for l in L]).reshape(-1, 3)
+    lp1 = np.array([l.get("p1", np.zeros(3)) for l in L]).reshape(-1, 3)
+    lp2 = np.array([l.get("p2", np.zeros(3)) for l in L]).reshape(-1, 3)
+    ln = np.array([l.get("n", np.zeros(3)) for l in L]).reshape(-1, 3)
+    larea = np.array([l.get("area", 0.0) for l in L])
+    # the camera (3.2)
+    c2w = sd.cam_to_world.astype(np.float64)
+    aspect = W / H
+    x0, x1, y0, y1 = (-aspect, aspect, -1.0, 1.0) if aspect >= 1 else (-1.0, 1.0, -1.0 / aspect, 1.0 / aspect)
+    th = float(np.float32(np.tan(float(sd.fov) * np.pi / 360.0)))
+    ax, bx, ay, by = (x1 - x0) / W * th, x0 * th, -(y1 - y0) / H * th, y1 * th
+    # one stream per (pixel, chunk); the samples of a chunk run in order on their stream
+    py, px = np.mgrid[0:H, 0:W]
+    px, py = px.ravel(), py.ravel()
+    n_px = W * H
+    film = np.zeros((n_px, 3))
+    for c in range(K):
+        s_lo, s_hi = (c * n_spp) // K, ((c + 1) * n_spp) // K
+        rng = _Pcg((np.uint64(seed) * np.uint64(W) * np.uint64(H) + py.astype(np.uint64) * np.uint64(W) + px.astype(np.uint64)) * np.uint64(K) + np.uint64(c))
+        part = np.zeros((n_px, 3))
+        everyone = np.ones(n_px, bool)
+        for s in range(s_lo, s_hi):
+            sx, sy = s % nx, s // nx
+            u1, u2 = rng.uniform(everyone), rng.uniform(everyone)
+            jx = np.minimum((np.float32(sx) + u1) * (np.float32(1) / np.float32(nx)), _EPS1)
+            jy = np.minimum((np.float32(sy) + u2) * (np.float32(1) / np.float32(ny)), _EPS1)
+            fx = (px.astype(np.float32) + jx).astype(np.float64)
+            fy = (py.astype(np.float32) + jy).astype(np.float64)
+            dc = _unit(np.stack([fx * ax + bx, fy * ay + by, np.ones(n_px)], 1))
+            d = dc @ c2w[:3, :3].T
+            o = np.tile(c2w[:3, 3], (n_px, 1))
+            Lsum, beta = np.zeros((n_px, 3)), np.ones((n_px, 3))
+            alive = np.ones(n_px, bool)
+            specular = np.zeros(n_px, bool)
+            bounces = 0
+            while alive.any():
+                a = np.flatnonzero(alive)
+                t, tri, ub, vb = _closest(o[a], d[a], np.full(len(a), np.inf), p0, e1, e2)
+                hit = tri >= 0
+                wo = -d[a]
+                m = mat_of[np.maximum(tri, 0)]
+                ng = _unit(np.cross(e1[np.maximum(tri, 0)], e2[np.maximum(tri, 0)]))
+                collect = (bounces == 0) | specular[a]
+                front = (ng * wo).sum(1) > 0
+                Lsum[a] += np.where((hit & collect & front & (le[m] > 0).any(1))[:, None], beta[a] * le[m], 0.0)
+                if has_inf:
+                    Lsum[a] += np.where((~hit & collect)[:, None], beta[a] * le_inf, 0.0)
+                alive[a[~hit]] = False
+                if bounces >= max_depth:  # (such a ray was traced for its emission alone)
+                    alive[a] = False
+                    break
+                a, tri, ub, vb, m, ng, wo = a[hit], tri[hit], ub[hit], vb[hit], m[hit], ng[hit], wo[hit]
+                if len(a) == 0:
+                    break
+                w = (1.0 - ub) - vb
+                p = p0[tri] * w[:, None] + p1[tri] * ub[:, None] + p2[tri] * vb[:, None]
+                nf = np.where(((ng * wo).sum(1) < 0)[:, None], -ng, ng)
+                po = p + nf * 1e-4
+                matte = ~is_mirror[m]
+                k = kcol[m]
+                full = np.zeros(n_px, bool)
+                # --- the direct-light estimate at a matte vertex: pick, then the pair, whatever the light's kind (3.1) ---
+                lpend = np.zeros((len(a), 3))
+                need_shadow = np.zeros(len(a), bool)
+                sh_d, sh_t = np.zeros((len(a), 3)), np.full(len(a), np.inf)
+                if nL > 0:
+                    full[:] = False
+                    full[a[matte]] = True
+                    xi, l1, l2 = rng.uniform(full)[a], rng.uniform(full)[a], rng.uniform(full)[a]
+                    li = np.minimum((xi * nLf).astype(np.int64), nL - 1)  # (fp32 product, truncated: the spec's pick)
+                    f = k / np.pi
+                    ty = ltype[li]
+                    # point
+                    dv = lp[li] - po
+                    d2 = (dv * dv).sum(1)
+                    with np.errstate(all="ignore"):
+                        dist = np.sqrt(d2)
+                        wi_p = dv / dist[:, None]
+                        cs_p = (wi_p * nf).sum(1)
+                        ld_p = f * lc[li] * ((cs_p / d2) * nL)[:, None]
+                    ok_p = (ty == 0) & (d2 > 0) & (cs_p > 0)
+                    # distant
+                    cs_d = (lp[li] * nf).sum(1)
+                    ok_d = (ty == 1) & (cs_d > 0)
+                    ld_d = f * lc[li] * (cs_d * nL)[:, None]
+                    # constant infinite: a cosine-sampled direction
+                    wi_i, z_i = _cosine_about(nf, l1.astype(np.float64), l2.astype(np.float64))
+                    ok_i = (ty == 2) & (z_i != 0)
+                    ld_i = k * lc[li] * nL
+                    # an emissive triangle: a uniform point (the sqrt form), one-sided
+                    su0 = np.sqrt(l1.astype(np.float64))
+                    b0 = 1.0 - su0
+                    b1 = l2.astype(np.float64) * su0
+                    b2 = (1.0 - b0) - b1
+                    pl = lp[li] * b0[:, None] + lp1[li] * b1[:, None] + lp2[li] * b2[:, None]
+                    dv = pl - po
+                    d2t = (dv * dv).sum(1)
+                    with np.errstate(all="ignore"):
+                        dist_t = np.sqrt(d2t)
+                        wi_t = dv / dist_t[:, None]
+                        cs_t = (wi_t * nf).sum(1)
+                        cl_t = -(wi_t * ln[li]).sum(1)
+                        ld_t = f * lc[li] * ((((cs_t * cl_t) * larea[li]) / d2t) * nL)[:, None]
+                    ok_t = (ty == 3) & (d2t > 0) & (cs_t > 0) & (cl_t > 0)
+                    need_shadow = matte & (ok_p | ok_d | ok_i | ok_t)
+                    with np.errstate(all="ignore"):
+                        ld = np.where(ok_p[:, None], ld_p, np.where(ok_d[:, None], ld_d, np.where(ok_i[:, None], ld_i, ld_t)))
+                        sh_d = np.where(ok_p[:, None], wi_p, np.where(ok_d[:, None], lp[li], np.where(ok_i[:, None], wi_i, wi_t)))
+                        sh_t = np.where(ok_p, dist * 0.9999, np.where(ok_t, dist_t * 0.9999, np.inf))
+                    lpend = np.where(need_shadow[:, None], beta[a] * ld, 0.0)
+                # --- the BSDF sample: matte = cosine hemisphere (two draws, path integrator only), mirror = reflection (none) ---
+                go = np.ones(len(a), bool)
+                wi_next = -wo + nf * (2.0 * (wo * nf).sum(1))[:, None]
+                if integrator == 1:
+                    go &= ~matte  # direct lighting ends at the first matte vertex
+                else:
+                    full[:] = False
+                    full[a[matte]] = True
+                    c1, c2 = rng.uniform(full)[a], rng.uniform(full)[a]
+                    wi_c, z_c = _cosine_about(nf, c1.astype(np.float64), c2.astype(np.float64))
+                    wi_next = np.where(matte[:, None], wi_c, wi_next)
+                    go &= ~(matte & (z_c == 0))
+                new_beta = np.where(go[:, None], beta[a] * k, beta[a])
+                spec_next = ~matte
+                go &= ~(new_beta == 0).all(1)
+                if bounces > 3:  # Russian roulette (3.9)
+                    full[:] = False
+                    full[a[go]] = True
+                    xr = rng.uniform(full)[a]
+                    q = np.maximum(0.05, 1.0 - new_beta.max(1))
+                    die = go & (xr < q)
+                    with np.errstate(all="ignore"):
+                        new_beta = np.where((go & ~die)[:, None], new_beta / (1.0 - q)[:, None], new_beta)
+                    go &= ~die
+                # --- the shadow ray ---
+                if need_shadow.any():
+                    sidx = np.flatnonzero(need_shadow)
+                    _, blocker, _, _ = _closest(po[sidx], sh_d[sidx], sh_t[sidx], p0, e1, e2)
+                    lit = np.zeros(len(a), bool)
+                    lit[sidx] = blocker < 0
+                    Lsum[a] += np.where(lit[:, None], lpend, 0.0)
+                beta[a] = new_beta
+                specular[a] = spec_next
+                # a ray at the depth limit is traced only after a specular bounce, for its emission
+                go &= ~((bounces + 1 >= max_depth) & ~spec_next)
+                alive[a] = go
+                o[a], d[a] = po, wi_next
+                bounces += 1
+            y = 0.212671 * Lsum[:, 0] + 0.715160 * Lsum[:, 1] + 0.072169 * Lsum[:, 2]
+            bad = np.isnan(Lsum).any(1) | (y < -1e-5) | np.isinf(y)
+            part += np.where(bad[:, None], 0.0, Lsum)
+        film += part
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    out = np.concatenate([film @ M.T, np.full((n_px, 1), float(n_spp))], 1)
+    return out.reshape(H, W, 4)
+
+
+def psnr_db(film_a, film_b):
+    """PSNR of two {X, Y, Z, weight} films as north_star states it: linear RGB (XYZ / weight through the inverse matrix) clamped to [0, 1], peak 1"""
+    Minv = np.linalg.inv(np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]]))
+
+    def rgb(f):
+        f = np.asarray(f, np.float64)
+        return np.clip((f[..., :3] / np.maximum(f[..., 3:4], 1e-30)) @ Minv.T, 0.0, 1.0)
+    mse = float(((rgb(film_a) - rgb(film_b)) ** 2).mean())
+    return np.inf if mse == 0 else 10.0 * np.log10(1.0 / mse)
