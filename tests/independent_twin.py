@@ -10,8 +10,8 @@ a wrong term (a pdf, a cosine, the n_lights factor, the order of the draws, the 
 What differs legitimately: float64 against fp32 arithmetic (1e-6 relative), and a handful of paths per image whose discrete decisions (which
 triangle at an edge, roulette at the threshold, the picked light) fall the other way.
 
-Supported: triangles (matte / mirror, emissive = area lights), point / distant / constant-infinite lights, integrators 0 (path) and 1
-(direct), the stratified sampler, the default box filter.  No spheres, textures, MIS or table samplers."""
+Supported: triangles and spheres (matte / mirror; emissive triangles = area lights), point / distant / constant-infinite lights, integrators 0
+(path), 1 (direct) and 2 (path with the one-sample MIS of 3.14), the stratified sampler, the default box filter.  No textures, no table samplers."""
 import numpy as np
 
 _M = np.uint64(0x5851F42D4C957F2D)
@@ -76,6 +76,33 @@ def _closest(o, d, tmax, p0, e1, e2, any_hit=False):
     return t_best, tri, ub, vb
 
 
+def _closest_prims(o, d, tmax, p0, e1, e2, sph):
+    """triangles (numbers 0 .. T - 1) and spheres (T + s; `sph` rows: centre, radius): the closest hit, ties to the lower primitive number"""
+    T = len(p0)
+    if T:
+        t, prim, ub, vb = _closest(o, d, tmax, p0, e1, e2)
+    else:
+        t, prim, ub, vb = np.full(len(o), np.inf), np.full(len(o), -1, np.int64), np.zeros(len(o)), np.zeros(len(o))
+    for k, row in enumerate(sph):
+        c, r = row[:3], row[3]
+        oc = o - c
+        a = (d * d).sum(1)
+        b = 2.0 * (d * oc).sum(1)
+        cc = (oc * oc).sum(1) - r * r
+        with np.errstate(all="ignore"):
+            disc = b * b - 4.0 * a * cc
+            rd = np.sqrt(np.maximum(disc, 0.0))
+            q = np.where(b < 0, -0.5 * (b - rd), -0.5 * (b + rd))
+            r0, r1 = q / a, cc / q
+        t0, t1 = np.minimum(r0, r1), np.maximum(r0, r1)
+        ok0 = (disc >= 0) & (t0 > 1e-4) & (t0 < tmax)
+        ok1 = (disc >= 0) & (t1 > 1e-4) & (t1 < tmax)
+        ts = np.where(ok0, t0, np.where(ok1, t1, np.inf))
+        closer = ts < t  # (a sphere's number is above every triangle's: at equal t the triangle keeps the hit)
+        t, prim = np.where(closer, ts, t), np.where(closer, T + k, prim)
+    return t, prim, ub, vb
+
+
 def _cosine_about(n, u1, u2):
     """pbrt-v3 CosineSampleHemisphere through ConcentricSampleDisk, in the frame CoordinateSystem(n) gives; -> (wi, z)"""
     ox, oy = 2.0 * u1 - 1.0, 2.0 * u2 - 1.0
@@ -98,18 +125,22 @@ def _cosine_about(n, u1, u2):
 def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
     """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image, no crop window)"""
     sd = sd.normalized()
-    assert sd.spheres.shape[0] == 0 and tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0)
+    assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2)
+    mis = integrator == 2
+    sph = sd.spheres.astype(np.float64)
+    T = sd.idx.shape[0]
     W, H = int(sd.xres), int(sd.yres)
     nx, ny = spp
     n_spp = nx * ny
     K = 1
     while 2 * K <= 16 and 2 * K * 32 <= n_spp:
         K *= 2
-    P = sd.P.astype(np.float64)[sd.idx.astype(np.int64)]
+    P = sd.P.astype(np.float64)[sd.idx.astype(np.int64)] if T else np.zeros((0, 3, 3))
     p0, p1, p2 = P[:, 0], P[:, 1], P[:, 2]
     e1, e2 = p1 - p0, p2 - p0
     mats = sd.materials.astype(np.float64)
-    mat_of = sd.mat_id.astype(np.int64)
+    mat_of = np.concatenate([sd.mat_id.astype(np.int64), sph[:, 4].astype(np.int64)])  # by primitive number: triangles, then spheres
+    tri_area_all = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1) if T else np.zeros(0)
     is_mirror = mats[:, 0] == 1
     kcol, le = mats[:, 1:4], mats[:, 4:7]
     # the light list (3.8): explicit lights in order, then every emissive triangle in index order
@@ -160,28 +191,48 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
             Lsum, beta = np.zeros((n_px, 3)), np.ones((n_px, 3))
             alive = np.ones(n_px, bool)
             specular = np.zeros(n_px, bool)
+            pb_prev = np.zeros(n_px)  # MIS: the density the ray in flight was drawn with (cos / pi of its cosine sample)
             bounces = 0
             while alive.any():
                 a = np.flatnonzero(alive)
-                t, tri, ub, vb = _closest(o[a], d[a], np.full(len(a), np.inf), p0, e1, e2)
+                t, tri, ub, vb = _closest_prims(o[a], d[a], np.full(len(a), np.inf), p0, e1, e2, sph)
                 hit = tri >= 0
+                on_tri = hit & (tri < T)
                 wo = -d[a]
                 m = mat_of[np.maximum(tri, 0)]
-                ng = _unit(np.cross(e1[np.maximum(tri, 0)], e2[np.maximum(tri, 0)]))
+                ti = np.where(on_tri, tri, 0)
+                ng = _unit(np.cross(e1[ti], e2[ti])) if T else np.zeros((len(a), 3))
+                if len(sph):
+                    si = np.clip(tri - T, 0, len(sph) - 1)
+                    ph = (o[a] - sph[si, :3]) + d[a] * np.where(hit, t, 0.0)[:, None]
+                    ng = np.where(on_tri[:, None], ng, ph / sph[si, 3:4])
                 collect = (bounces == 0) | specular[a]
                 front = (ng * wo).sum(1) > 0
-                Lsum[a] += np.where((hit & collect & front & (le[m] > 0).any(1))[:, None], beta[a] * le[m], 0.0)
+                emits = hit & front & (le[m] > 0).any(1)
+                Lsum[a] += np.where((emits & collect)[:, None], beta[a] * le[m], 0.0)
                 if has_inf:
                     Lsum[a] += np.where((~hit & collect)[:, None], beta[a] * le_inf, 0.0)
+                if mis:  # 3.14: the BSDF-sampled half of the previous vertex's estimate, where the bounce ray lands on a light
+                    with np.errstate(all="ignore"):
+                        cl = (ng * wo).sum(1)
+                        pl = ((t * t) / (cl * tri_area_all[ti])) / nL if T else np.zeros(len(a))
+                        wb = pb_prev[a] ** 2 / (pb_prev[a] ** 2 + pl ** 2)
+                    Lsum[a] += np.where((emits & on_tri & ~collect)[:, None], beta[a] * le[m] * wb[:, None], 0.0)
+                    if has_inf:
+                        Lsum[a] += np.where((~hit & ~collect)[:, None], beta[a] * le_inf * (nL * nL / (nL * nL + 1.0)), 0.0)
                 alive[a[~hit]] = False
                 if bounces >= max_depth:  # (such a ray was traced for its emission alone)
                     alive[a] = False
                     break
-                a, tri, ub, vb, m, ng, wo = a[hit], tri[hit], ub[hit], vb[hit], m[hit], ng[hit], wo[hit]
+                a, tri, ub, vb, m, ng, wo, on_tri, t = a[hit], tri[hit], ub[hit], vb[hit], m[hit], ng[hit], wo[hit], on_tri[hit], t[hit]
                 if len(a) == 0:
                     break
                 w = (1.0 - ub) - vb
-                p = p0[tri] * w[:, None] + p1[tri] * ub[:, None] + p2[tri] * vb[:, None]
+                ti = np.where(on_tri, tri, 0)
+                p = p0[ti] * w[:, None] + p1[ti] * ub[:, None] + p2[ti] * vb[:, None] if T else np.zeros((len(a), 3))
+                if len(sph):
+                    si = np.clip(tri - T, 0, len(sph) - 1)
+                    p = np.where(on_tri[:, None], p, sph[si, :3] + ((o[a] - sph[si, :3]) + d[a] * t[:, None]))
                 nf = np.where(((ng * wo).sum(1) < 0)[:, None], -ng, ng)
                 po = p + nf * 1e-4
                 matte = ~is_mirror[m]
@@ -229,6 +280,11 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
                         cs_t = (wi_t * nf).sum(1)
                         cl_t = -(wi_t * ln[li]).sum(1)
                         ld_t = f * lc[li] * ((((cs_t * cl_t) * larea[li]) / d2t) * nL)[:, None]
+                        if mis:  # power heuristic: this strategy's density against the BSDF's for the same direction
+                            pl_t, pb_t = (d2t / (cl_t * larea[li])) / nL, cs_t / np.pi
+                            ld_t = ld_t * (pl_t ** 2 / (pl_t ** 2 + pb_t ** 2))[:, None]
+                    if mis:
+                        ld_i = ld_i * (1.0 / (1.0 + nL * nL))
                     ok_t = (ty == 3) & (d2t > 0) & (cs_t > 0) & (cl_t > 0)
                     need_shadow = matte & (ok_p | ok_d | ok_i | ok_t)
                     with np.errstate(all="ignore"):
@@ -248,6 +304,7 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
                     wi_c, z_c = _cosine_about(nf, c1.astype(np.float64), c2.astype(np.float64))
                     wi_next = np.where(matte[:, None], wi_c, wi_next)
                     go &= ~(matte & (z_c == 0))
+                    pb_prev[a] = z_c / np.pi
                 new_beta = np.where(go[:, None], beta[a] * k, beta[a])
                 spec_next = ~matte
                 go &= ~(new_beta == 0).all(1)
@@ -263,14 +320,15 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
                 # --- the shadow ray ---
                 if need_shadow.any():
                     sidx = np.flatnonzero(need_shadow)
-                    _, blocker, _, _ = _closest(po[sidx], sh_d[sidx], sh_t[sidx], p0, e1, e2)
+                    _, blocker, _, _ = _closest_prims(po[sidx], sh_d[sidx], sh_t[sidx], p0, e1, e2, sph)
                     lit = np.zeros(len(a), bool)
                     lit[sidx] = blocker < 0
                     Lsum[a] += np.where(lit[:, None], lpend, 0.0)
                 beta[a] = new_beta
                 specular[a] = spec_next
                 # a ray at the depth limit is traced only after a specular bounce, for its emission
-                go &= ~((bounces + 1 >= max_depth) & ~spec_next)
+                if not mis:  # (with MIS the ray at the limit IS traced: the BSDF half of the last vertex's estimate)
+                    go &= ~((bounces + 1 >= max_depth) & ~spec_next)
                 alive[a] = go
                 o[a], d[a] = po, wi_next
                 bounces += 1
