@@ -11,7 +11,8 @@ What differs legitimately: float64 against fp32 arithmetic (1e-6 relative), and 
 triangle at an edge, roulette at the threshold, the picked light) fall the other way.
 
 Supported: triangles and spheres (matte / mirror; emissive triangles = area lights), point / distant / constant-infinite lights, integrators 0
-(path), 1 (direct) and 2 (path with the one-sample MIS of 3.14), the stratified sampler, the default box filter.  No textures, no table samplers."""
+(path), 1 (direct) and 2 (path with the one-sample MIS of 3.14), the stratified sampler, the padded (0,2)-sequence of 3.10 ("sobol") and the
+Halton sampler of 3.13 ("halton"), the default box filter.  No textures, no Sobol' sampler proper (its generator matrices are a table)."""
 import numpy as np
 
 _M = np.uint64(0x5851F42D4C957F2D)
@@ -42,6 +43,120 @@ class _Pcg:
         """one uniform_float per stream of `mask` (fp32, as the spec's arithmetic has it); the others keep their state"""
         u = self._u32(mask).astype(np.float32) * np.float32(2.3283064365386963e-10)
         return np.minimum(u, _EPS1)
+
+
+    def get1(self, mask):
+        return self.uniform(mask)
+
+    def get2(self, mask):
+        return self.uniform(mask), self.uniform(mask)
+
+    def start_sample(self, s):
+        pass
+
+
+def _mix32(v):
+    v = np.asarray(v, np.uint32).copy()
+    with np.errstate(over="ignore"):
+        v ^= v >> np.uint32(16); v *= np.uint32(0x7FEB352D); v ^= v >> np.uint32(15); v *= np.uint32(0x846CA68B); v ^= v >> np.uint32(16)
+    return v
+
+
+def _bitrev32(v):
+    v = np.asarray(v, np.uint32)
+    v = ((v >> np.uint32(1)) & np.uint32(0x55555555)) | ((v & np.uint32(0x55555555)) << np.uint32(1))
+    v = ((v >> np.uint32(2)) & np.uint32(0x33333333)) | ((v & np.uint32(0x33333333)) << np.uint32(2))
+    v = ((v >> np.uint32(4)) & np.uint32(0x0F0F0F0F)) | ((v & np.uint32(0x0F0F0F0F)) << np.uint32(4))
+    v = ((v >> np.uint32(8)) & np.uint32(0x00FF00FF)) | ((v & np.uint32(0x00FF00FF)) << np.uint32(8))
+    return (v >> np.uint32(16)) | (v << np.uint32(16))
+
+
+def _primes(n):
+    out, k = [], 2
+    while len(out) < n:
+        if all(k % q for q in out if q * q <= k):
+            out.append(k)
+        k += 1
+    return out
+
+
+class _Lds:
+    """The low-discrepancy samplers as DESIGN.md writes them: "02" = the padded (0,2)-sequence of 3.10, "halton" = 3.13 -- integer arithmetic
+    keyed by (pixel, sample number, request number); nothing but the request counter is state."""
+    G = np.uint32(0x9E3779B9)
+
+    def __init__(self, kind, q, spp):
+        q = np.asarray(q, np.uint64)
+        with np.errstate(over="ignore"):
+            self.key = _mix32((q & np.uint64(0xFFFFFFFF)).astype(np.uint32) ^ _mix32((q >> np.uint64(32)).astype(np.uint32) + self.G))
+        self.kind, self.n = kind, len(q)
+        self.mask = np.uint32((1 << int(np.ceil(np.log2(max(spp, 1))))) - 1) if spp > 1 else np.uint32(0)
+        self.primes = _primes(128)
+        self.j = np.zeros(self.n, np.uint32)
+        self.s = 0
+
+    def start_sample(self, s):
+        self.s, self.j = s, np.zeros(self.n, np.uint32)
+
+    @staticmethod
+    def _u(bits):
+        return np.minimum(bits.astype(np.float32) * np.float32(2.3283064365386963e-10), _EPS1)
+
+    def _padded(self, j):
+        with np.errstate(over="ignore"):
+            a = _mix32(self.key + j * self.G)
+        i = np.uint32(self.s) ^ (a & self.mask)
+        x = _bitrev32(i)
+        y, k, v = np.zeros(self.n, np.uint32), i.copy(), np.full(self.n, 0x80000000, np.uint32)
+        while k.any():
+            y ^= np.where((k & np.uint32(1)) != 0, v, np.uint32(0))
+            k >>= np.uint32(1)
+            v ^= v >> np.uint32(1)
+        return self._u(x ^ _mix32(a ^ np.uint32(0x68E31DA4))), self._u(y ^ _mix32(a ^ np.uint32(0xB5297A4D)))
+
+    def _halton_dim(self, d):
+        """dimension d (an array) of sample self.s under the pixel keys"""
+        out = np.zeros(self.n, np.float32)
+        i = np.uint32(self.s)
+        for dd in np.unique(d):
+            sel = d == dd
+            b = self.primes[int(dd)]
+            with np.errstate(over="ignore"):
+                h = _mix32(self.key[sel] + np.uint32(int(dd) + 1) * self.G)
+            if b == 2:
+                out[sel] = self._u(_bitrev32(np.full(sel.sum(), i, np.uint32)) ^ h)
+                continue
+            v, nrem, pw = np.zeros(sel.sum(), np.uint32), int(i), 1
+            while True:
+                pw *= b
+                a_k = nrem % b
+                nrem //= b
+                with np.errstate(over="ignore"):
+                    h = h * np.uint32(0x9E3779B1) + np.uint32(0x7F4A7C15)
+                w = np.uint32(a_k) * (np.uint32(1) + (((h >> np.uint32(16)) * np.uint32(b - 1)) >> np.uint32(16))) + (((h & np.uint32(0xFFFF)) * np.uint32(b)) >> np.uint32(16))
+                v = v * np.uint32(b) + w % np.uint32(b)
+                if pw > int(self.mask):
+                    break
+            with np.errstate(over="ignore"):
+                h = h * np.uint32(0x9E3779B1) + np.uint32(0x7F4A7C15)
+            u = (v.astype(np.float32) + h.astype(np.float32) * np.float32(2.3283064365386963e-10)) * (np.float32(1.0) / np.float32(pw))
+            out[sel] = np.minimum(u, _EPS1)
+        return out
+
+    def get2(self, mask):
+        j = self.j.copy()
+        assert int(j[mask].max(initial=0)) < 64 or self.kind in ("02", "sobol")  # (requests beyond the 64th fall back to the padded ones: not walked here)
+        self.j = np.where(mask, self.j + np.uint32(1), self.j)
+        if self.kind in ("02", "sobol"):
+            return self._padded(j)
+        return self._halton_dim(2 * j.astype(np.int64)), self._halton_dim(2 * j.astype(np.int64) + 1)
+
+    def get1(self, mask):  # a 1-D request takes the first coordinate of its pair
+        j = self.j.copy()
+        self.j = np.where(mask, self.j + np.uint32(1), self.j)
+        if self.kind in ("02", "sobol"):
+            return self._padded(j)[0]
+        return self._halton_dim(2 * j.astype(np.int64))
 
 
 def _unit(v):
@@ -122,7 +237,7 @@ def _cosine_about(n, u1, u2):
     return v2 * dx[:, None] + v3 * dy[:, None] + n * z[:, None], z
 
 
-def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
+def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratified"):
     """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image, no crop window)"""
     sd = sd.normalized()
     assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2)
@@ -175,14 +290,20 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
     film = np.zeros((n_px, 3))
     for c in range(K):
         s_lo, s_hi = (c * n_spp) // K, ((c + 1) * n_spp) // K
-        rng = _Pcg((np.uint64(seed) * np.uint64(W) * np.uint64(H) + py.astype(np.uint64) * np.uint64(W) + px.astype(np.uint64)) * np.uint64(K) + np.uint64(c))
+        with np.errstate(over="ignore"):
+            qpix = np.uint64(seed) * np.uint64(W) * np.uint64(H) + py.astype(np.uint64) * np.uint64(W) + px.astype(np.uint64)
+            rng = _Pcg(qpix * np.uint64(K) + np.uint64(c)) if sampler == "stratified" else _Lds(sampler, qpix, n_spp)
         part = np.zeros((n_px, 3))
         everyone = np.ones(n_px, bool)
         for s in range(s_lo, s_hi):
             sx, sy = s % nx, s // nx
-            u1, u2 = rng.uniform(everyone), rng.uniform(everyone)
-            jx = np.minimum((np.float32(sx) + u1) * (np.float32(1) / np.float32(nx)), _EPS1)
-            jy = np.minimum((np.float32(sy) + u2) * (np.float32(1) / np.float32(ny)), _EPS1)
+            rng.start_sample(s)
+            u1, u2 = rng.get2(everyone)
+            if sampler == "stratified":
+                jx = np.minimum((np.float32(sx) + u1) * (np.float32(1) / np.float32(nx)), _EPS1)
+                jy = np.minimum((np.float32(sy) + u2) * (np.float32(1) / np.float32(ny)), _EPS1)
+            else:  # (3.10: the net's point is the film offset itself)
+                jx, jy = u1, u2
             fx = (px.astype(np.float32) + jx).astype(np.float64)
             fy = (py.astype(np.float32) + jy).astype(np.float64)
             dc = _unit(np.stack([fx * ax + bx, fy * ay + by, np.ones(n_px)], 1))
@@ -245,7 +366,8 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
                 if nL > 0:
                     full[:] = False
                     full[a[matte]] = True
-                    xi, l1, l2 = rng.uniform(full)[a], rng.uniform(full)[a], rng.uniform(full)[a]
+                    xi = rng.get1(full)[a]
+                    l1, l2 = (v[a] for v in rng.get2(full))
                     li = np.minimum((xi * nLf).astype(np.int64), nL - 1)  # (fp32 product, truncated: the spec's pick)
                     f = k / np.pi
                     ty = ltype[li]
@@ -300,7 +422,7 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
                 else:
                     full[:] = False
                     full[a[matte]] = True
-                    c1, c2 = rng.uniform(full)[a], rng.uniform(full)[a]
+                    c1, c2 = (v[a] for v in rng.get2(full))
                     wi_c, z_c = _cosine_about(nf, c1.astype(np.float64), c2.astype(np.float64))
                     wi_next = np.where(matte[:, None], wi_c, wi_next)
                     go &= ~(matte & (z_c == 0))
@@ -311,7 +433,7 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0):
                 if bounces > 3:  # Russian roulette (3.9)
                     full[:] = False
                     full[a[go]] = True
-                    xr = rng.uniform(full)[a]
+                    xr = rng.get1(full)[a]
                     q = np.maximum(0.05, 1.0 - new_beta.max(1))
                     die = go & (xr < q)
                     with np.errstate(all="ignore"):
