@@ -12,7 +12,8 @@ triangle at an edge, roulette at the threshold, the picked light) fall the other
 
 Supported: triangles and spheres (matte / mirror; emissive triangles = area lights), point / distant / constant-infinite lights, integrators 0
 (path), 1 (direct) and 2 (path with the one-sample MIS of 3.14), the stratified sampler, the padded (0,2)-sequence of 3.10 ("sobol") and the
-Halton sampler of 3.13 ("halton"), the default box filter.  No textures, no Sobol' sampler proper (its generator matrices are a table)."""
+Halton sampler of 3.13 ("halton"), checkerboard textures (3.15; numpy's arctan2 / arccos for a sphere's (u, v)), the default box filter.  No
+Sobol' sampler proper (its generator matrices are a table), no wide filter."""
 import numpy as np
 
 _M = np.uint64(0x5851F42D4C957F2D)
@@ -240,7 +241,8 @@ def _cosine_about(n, u1, u2):
 def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratified"):
     """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image, no crop window)"""
     sd = sd.normalized()
-    assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2)
+    sampler = {0: "stratified", 1: "sobol", 3: "halton"}.get(sampler, sampler)  # (the C ABI's numbers: what a loaded scene file carries)
+    assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2) and sampler in ("stratified", "sobol", "halton")
     mis = integrator == 2
     sph = sd.spheres.astype(np.float64)
     T = sd.idx.shape[0]
@@ -256,6 +258,11 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
     mats = sd.materials.astype(np.float64)
     mat_of = np.concatenate([sd.mat_id.astype(np.int64), sph[:, 4].astype(np.int64)])  # by primitive number: triangles, then spheres
     tri_area_all = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1) if T else np.zeros(0)
+    textures = sd.textures.astype(np.float64)
+    n_tex = len(textures)
+    mat_tex = sd.mat_tex.astype(np.int64)
+    have_uv = sd.tri_uv.shape[0] == T and T > 0
+    tri_uv = sd.tri_uv.astype(np.float64) if have_uv else np.zeros((max(T, 1), 6))
     is_mirror = mats[:, 0] == 1
     kcol, le = mats[:, 1:4], mats[:, 4:7]
     # the light list (3.8): explicit lights in order, then every emissive triangle in index order
@@ -358,6 +365,24 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
                 po = p + nf * 1e-4
                 matte = ~is_mirror[m]
                 k = kcol[m]
+                if n_tex and (mat_tex[m] > 0).any():
+                    # 3.15: a matte Kd from a checkerboard over the primitive's (u, v), point-sampled
+                    if T and have_uv:
+                        uvc = tri_uv[ti]
+                        tu = (uvc[:, 0] * w + uvc[:, 2] * ub) + uvc[:, 4] * vb
+                        tv_ = (uvc[:, 1] * w + uvc[:, 3] * ub) + uvc[:, 5] * vb
+                    else:
+                        tu, tv_ = np.zeros(len(a)), np.zeros(len(a))
+                    if len(sph):
+                        phi = np.arctan2(ng[:, 1], ng[:, 0])
+                        phi = np.where(phi < 0, phi + 2 * np.pi, phi)
+                        theta = np.arccos(np.clip(ng[:, 2], -1.0, 1.0))
+                        tu = np.where(on_tri, tu, phi / (2 * np.pi))
+                        tv_ = np.where(on_tri, tv_, (theta - np.pi) / (0.0 - np.pi))
+                    tx = textures[np.maximum(mat_tex[m], 1) - 1]
+                    cell = np.floor(tx[:, 7] * tu + tx[:, 9]) + np.floor(tx[:, 8] * tv_ + tx[:, 10])
+                    kt = np.where((np.mod(cell, 2) == 0)[:, None], tx[:, 1:4], tx[:, 4:7])
+                    k = np.where(((mat_tex[m] > 0) & matte)[:, None], kt, k)
                 full = np.zeros(n_px, bool)
                 # --- the direct-light estimate at a matte vertex: pick, then the pair, whatever the light's kind (3.1) ---
                 lpend = np.zeros((len(a), 3))

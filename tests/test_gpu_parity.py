@@ -198,6 +198,15 @@ def test_hip_image_equals_an_independent_float64_implementation_of_the_spec(gpu)
         rel = np.abs(twin[..., :3] - film[..., :3]) / np.maximum(np.abs(film[..., :3]), 1e-3 * film[..., :3].max())
         assert tw.psnr_db(twin, film) >= 90.0 and (rel.max(-1) < 1e-4).mean() >= 0.99, (name, tw.psnr_db(twin, film), (rel.max(-1) < 1e-4).mean())
         assert np.array_equal(twin[..., 3], film[..., 3])
+    # ... and BASELINE C0 exactly as it is stated (256 x 256, 4 spp, the scene file through the parser, its checkerboard, its Halton sampler)
+    from test_oracle_selfcheck import _c0_against_the_twin
+
+    def hip(sd, kw):
+        with gpu.Scene(sd) as sc:
+            return sc.render(seed=0, **kw)[0]
+    for sampler, twin, film in _c0_against_the_twin(hip):
+        rel = np.abs(twin[..., :3] - film[..., :3]) / np.maximum(np.abs(film[..., :3]), 1e-3 * film[..., :3].max())
+        assert tw.psnr_db(twin, film) >= 60.0 and (rel.max(-1) < 1e-4).mean() >= 0.9999, (sampler, tw.psnr_db(twin, film), (rel.max(-1) < 1e-4).mean())
 
 
 def test_intersect_edge_cases(gpu, oracle):

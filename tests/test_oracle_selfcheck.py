@@ -1,6 +1,8 @@
 """The oracle checked against itself and against closed-form answers (CPU only): the rendered
 pixels are "parity unpinned" against the reference (it has no renderer), so these
 are the independent anchors the oracle does have."""
+import os
+
 import numpy as np
 import pytest
 
@@ -712,6 +714,23 @@ def _twin_cases():
             ("the same, direct lighting", mesh, dict(integrator=INTEGRATOR_DIRECT, max_depth=5, spp=(2, 2), seed=2))]
 
 
+def _c0_against_the_twin(render):
+    """BASELINE config C0 AS IT IS STATED -- scenes/c0_check_sphere.pbrt (= the reference's check-sphere.pbrt) at 256 x 256, 4 spp, through the
+    parser: its mirror sphere, its checkerboard ground (3.15), its sky and sun, `Integrator "path"` as pbrt-v3 means it (MIS), under its own
+    `Sampler "halton"` and under a stratified one -- against the independent float64 implementation: yields (sampler, twin film, film of
+    render(scene, render arguments)).  A sample that lands on the border of two checker cells takes the other colour in one program or the
+    other (0.1 against 0.8): one or two pixels of 65 536, which is what holds the PSNR at 67 dB."""
+    import independent_twin as tw
+    from pbrt_amd import loader
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "c0_check_sphere.pbrt")).read().replace("[400]", "[256]")
+    for sampler, line in (("halton", 'Sampler "halton" "integer pixelsamples" 4'), ("stratified", 'Sampler "stratified" "integer xsamples" 2 "integer ysamples" 2')):
+        ls = loader.load_string(text.replace('Sampler "halton" "integer pixelsamples" 128', line))
+        kw = ls.render_kwargs()
+        assert (ls.scene.xres, ls.scene.yres, ls.spp, ls.integrator) == (256, 256, (2, 2), 2)
+        twin = tw.render(ls.scene, seed=0, **{k: v for k, v in kw.items() if k in ("integrator", "max_depth", "spp", "sampler")})
+        yield sampler, twin, render(ls.scene, kw)
+
+
 def test_oracle_image_equals_an_independent_float64_implementation_of_the_spec(oracle):
     """north_star's "PSNR >= 50 dB vs the reference image", against a reference that is not the twin: tests/independent_twin.py is a SECOND
     implementation of DESIGN.md section 3 -- float64 numpy written from the spec's text, every ray against every triangle, the textbook's
@@ -719,7 +738,8 @@ def test_oracle_image_equals_an_independent_float64_implementation_of_the_spec(o
     spec's order; the integer arithmetic of the padded (0,2)-sequence of 3.10 and of the Halton sampler of 3.13, restated) and no code.  Sample s of
     pixel (x, y) then walks the same path up to rounding, so the images compare directly: PSNR >= 90 dB (measured 105 ... 148) and 99 % of the pixels (measured: 99.5 ... 100 %) equal to 1e-4 in every channel, for integrators 0, 1 and 2
     (MIS), triangles and spheres -- where a wrong pdf, cosine, n_lights factor, draw
-    order, depth rule or roulette weight would move every pixel (one bounce more or fewer: < 40 dB at depth 3, 62 dB even at depth 16).  The HIP path against the same images:
+    order, depth rule or roulette weight would move every pixel; and BASELINE C0 exactly as it is stated (the scene file through the parser: checkerboard,
+    mirror sphere, Halton, MIS): PSNR >= 60 dB (67.0), 99.99 % of the pixels -- (one bounce more or fewer: < 40 dB at depth 3, 62 dB even at depth 16).  The HIP path against the same images:
     tests/test_gpu_parity.py."""
     import independent_twin as tw
     for name, sd, kw in _twin_cases():
@@ -728,6 +748,9 @@ def test_oracle_image_equals_an_independent_float64_implementation_of_the_spec(o
         rel = np.abs(twin[..., :3] - film[..., :3]) / np.maximum(np.abs(film[..., :3]), 1e-3 * film[..., :3].max())
         assert tw.psnr_db(twin, film) >= 90.0 and (rel.max(-1) < 1e-4).mean() >= 0.99, (name, tw.psnr_db(twin, film), (rel.max(-1) < 1e-4).mean())
         assert np.array_equal(twin[..., 3], film[..., 3])
+    for sampler, twin, film in _c0_against_the_twin(lambda sd, kw: oracle.OracleScene(sd).render(seed=0, **kw)[0]):
+        rel = np.abs(twin[..., :3] - film[..., :3]) / np.maximum(np.abs(film[..., :3]), 1e-3 * film[..., :3].max())
+        assert tw.psnr_db(twin, film) >= 60.0 and (rel.max(-1) < 1e-4).mean() >= 0.9999, (sampler, tw.psnr_db(twin, film), (rel.max(-1) < 1e-4).mean())
     # the comparison can see one bounce
     name, sd, kw = _twin_cases()[0]
     film, _ = oracle.OracleScene(sd).render(**dict(kw, max_depth=15))
