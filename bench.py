@@ -460,7 +460,7 @@ def main():
             # ray on its tree, and a live walk that differs by more than 0.5 % is another tree
             live = (wst["nodes_visited"] / rays, wst["tris_tested"] / rays)
             rel = 0.0
-            if tree.get("spp") in (None, spp[0] * spp[1]):  # (per-ray work is compared on the same frame: other sample counts trace other rays)
+            if tree.get("spp") in (None, spp[0] * spp[1]) and world == 1:  # (per-ray work is compared on the same frame: other sample counts, or one rank's share of the frame, trace other rays)
                 rel = max(abs(live[0] / tree["kernel_fetches_per_ray"] - 1.0), abs(live[1] / tree["kernel_tris_per_ray"] - 1.0) if tree.get("kernel_tris_per_ray") else 0.0)
             if tree.get("quad_nodes") not in (None, info["quad_nodes"]):  # (the builders are deterministic: another node count IS another tree)
                 rel = max(rel, 1.0)
