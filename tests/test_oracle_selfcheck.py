@@ -707,6 +707,7 @@ def _twin_cases():
             ("C0's geometry through its own sampler and integrator: Halton (3.13) + MIS", scenes.check_sphere_scene(40, 32), dict(integrator=2, max_depth=5, spp=(3, 2), seed=1, sampler="halton")),
             ("C4's scene, the padded (0,2)-sequence (3.10), depth 16, 6 spp", scenes.cornell_scene(32, 32), dict(integrator=INTEGRATOR_PATH, max_depth=16, spp=(3, 2), seed=1, sampler="sobol")),
             ("C4's scene, Halton, 64 spp", scenes.cornell_scene(16, 16), dict(integrator=INTEGRATOR_PATH, max_depth=4, spp=(8, 8), seed=2, sampler="halton")),
+            ("slivers lying flat in axis planes under a sky (the own-box rule's hardest case: no holes)", __import__("util").flat_sliver_scene(96, 96)[0], dict(integrator=INTEGRATOR_PATH, max_depth=3, spp=(4, 4), seed=2)),
             ("C1's scene: a sphere under a point light, direct lighting", scenes.sphere_scene(48, 48), dict(integrator=INTEGRATOR_DIRECT, max_depth=5, spp=(4, 4), seed=0)),
             ("300 triangles + two spheres, all four kinds of light, MIS", both, dict(integrator=2, max_depth=8, spp=(3, 2), seed=5)),
             ("C4's scene, 64 spp in two chunks", scenes.cornell_scene(24, 24), dict(integrator=INTEGRATOR_PATH, max_depth=3, spp=(8, 8), seed=1)),
