@@ -12,8 +12,8 @@ triangle at an edge, roulette at the threshold, the picked light) fall the other
 
 Supported: triangles and spheres (matte / mirror; emissive triangles = area lights), point / distant / constant-infinite lights, integrators 0
 (path), 1 (direct) and 2 (path with the one-sample MIS of 3.14), the stratified sampler, the padded (0,2)-sequence of 3.10 ("sobol") and the
-Halton sampler of 3.13 ("halton"), checkerboard textures (3.15; numpy's arctan2 / arccos for a sphere's (u, v)), the default box filter.  No
-Sobol' sampler proper (its generator matrices are a table), no wide filter."""
+Halton sampler of 3.13 ("halton"), the Sobol' sampler of 3.12 ("sobol_nd": the generator matrices are a table, handed in), checkerboard textures
+(3.15; numpy's arctan2 / arccos for a sphere's (u, v)), box filters of any radius (3.11: the fixed-point film) and "maxsampleluminance"."""
 import numpy as np
 
 _M = np.uint64(0x5851F42D4C957F2D)
@@ -86,7 +86,8 @@ class _Lds:
     keyed by (pixel, sample number, request number); nothing but the request counter is state."""
     G = np.uint32(0x9E3779B9)
 
-    def __init__(self, kind, q, spp):
+    def __init__(self, kind, q, spp, matrices=None):
+        self.mat = None if matrices is None else np.asarray(matrices, np.uint32).reshape(128, 32)
         q = np.asarray(q, np.uint64)
         with np.errstate(over="ignore"):
             self.key = _mix32((q & np.uint64(0xFFFFFFFF)).astype(np.uint32) ^ _mix32((q >> np.uint64(32)).astype(np.uint32) + self.G))
@@ -144,12 +145,24 @@ class _Lds:
             out[sel] = np.minimum(u, _EPS1)
         return out
 
+    def _sobol_dim(self, d):
+        """3.12: dimension d (an array) of the Sobol' sequence at index self.s -- XOR of the generator matrix's columns at the set bits --,
+        scrambled per pixel and dimension"""
+        x = np.zeros(self.n, np.uint32)
+        for b in range(32):
+            if (self.s >> b) & 1:
+                x ^= self.mat[d, b]
+        with np.errstate(over="ignore"):
+            return self._u(x ^ _mix32(self.key + (d.astype(np.uint32) + np.uint32(1)) * self.G))
+
     def get2(self, mask):
         j = self.j.copy()
         assert int(j[mask].max(initial=0)) < 64 or self.kind in ("02", "sobol")  # (requests beyond the 64th fall back to the padded ones: not walked here)
         self.j = np.where(mask, self.j + np.uint32(1), self.j)
         if self.kind in ("02", "sobol"):
             return self._padded(j)
+        if self.kind == "sobol_nd":
+            return self._sobol_dim(2 * j.astype(np.int64)), self._sobol_dim(2 * j.astype(np.int64) + 1)
         return self._halton_dim(2 * j.astype(np.int64)), self._halton_dim(2 * j.astype(np.int64) + 1)
 
     def get1(self, mask):  # a 1-D request takes the first coordinate of its pair
@@ -157,6 +170,8 @@ class _Lds:
         self.j = np.where(mask, self.j + np.uint32(1), self.j)
         if self.kind in ("02", "sobol"):
             return self._padded(j)[0]
+        if self.kind == "sobol_nd":
+            return self._sobol_dim(2 * j.astype(np.int64))
         return self._halton_dim(2 * j.astype(np.int64))
 
 
@@ -238,11 +253,15 @@ def _cosine_about(n, u1, u2):
     return v2 * dx[:, None] + v3 * dy[:, None] + n * z[:, None], z
 
 
-def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratified"):
+def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratified", filter_width=None, max_sample_luminance=0.0, sobol_matrices=None):
     """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image, no crop window)"""
     sd = sd.normalized()
-    sampler = {0: "stratified", 1: "sobol", 3: "halton"}.get(sampler, sampler)  # (the C ABI's numbers: what a loaded scene file carries)
-    assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2) and sampler in ("stratified", "sobol", "halton")
+    sampler = {0: "stratified", 1: "sobol", 2: "sobol_nd", 3: "halton"}.get(sampler, sampler)  # (the C ABI's numbers: what a loaded scene file carries)
+    assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2) and sampler in ("stratified", "sobol", "sobol_nd", "halton")
+    assert sampler != "sobol_nd" or sobol_matrices is not None  # (3.12's generator matrices are a table: the caller hands them over)
+    rx, ry = (float(v) if float(v) != 0.0 else 0.5 for v in (filter_width or (0.5, 0.5)))
+    wide = (rx, ry) != (0.5, 0.5)
+    pad_x, pad_y = (int(np.ceil(rx - 0.5)), int(np.ceil(ry - 0.5))) if wide else (0, 0)
     mis = integrator == 2
     sph = sd.spheres.astype(np.float64)
     T = sd.idx.shape[0]
@@ -291,15 +310,19 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
     th = float(np.float32(np.tan(float(sd.fov) * np.pi / 360.0)))
     ax, bx, ay, by = (x1 - x0) / W * th, x0 * th, -(y1 - y0) / H * th, y1 * th
     # one stream per (pixel, chunk); the samples of a chunk run in order on their stream
-    py, px = np.mgrid[0:H, 0:W]
+    # the SAMPLED pixels (3.11): the image plus a halo of pad pixels for a box filter wider than 0.5; their streams are numbered in the
+    # haloed image W' x H'
+    py, px = np.mgrid[-pad_y:H + pad_y, -pad_x:W + pad_x]
     px, py = px.ravel(), py.ravel()
-    n_px = W * H
+    n_px = len(px)
+    Wn, Hn = W + 2 * pad_x, H + 2 * pad_y
     film = np.zeros((n_px, 3))
+    acc = np.zeros((H, W, 4), np.int64)  # the fixed-point film of a wide filter
     for c in range(K):
         s_lo, s_hi = (c * n_spp) // K, ((c + 1) * n_spp) // K
         with np.errstate(over="ignore"):
-            qpix = np.uint64(seed) * np.uint64(W) * np.uint64(H) + py.astype(np.uint64) * np.uint64(W) + px.astype(np.uint64)
-            rng = _Pcg(qpix * np.uint64(K) + np.uint64(c)) if sampler == "stratified" else _Lds(sampler, qpix, n_spp)
+            qpix = np.uint64(seed) * np.uint64(Wn) * np.uint64(Hn) + (py + pad_y).astype(np.uint64) * np.uint64(Wn) + (px + pad_x).astype(np.uint64)
+            rng = _Pcg(qpix * np.uint64(K) + np.uint64(c)) if sampler == "stratified" else _Lds(sampler, qpix, n_spp, sobol_matrices)
         part = np.zeros((n_px, 3))
         everyone = np.ones(n_px, bool)
         for s in range(s_lo, s_hi):
@@ -481,9 +504,26 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
                 bounces += 1
             y = 0.212671 * Lsum[:, 0] + 0.715160 * Lsum[:, 1] + 0.072169 * Lsum[:, 2]
             bad = np.isnan(Lsum).any(1) | (y < -1e-5) | np.isinf(y)
-            part += np.where(bad[:, None], 0.0, Lsum)
+            Ls = np.where(bad[:, None], 0.0, Lsum)
+            if max_sample_luminance > 0:  # Film "maxsampleluminance" (3.9)
+                with np.errstate(all="ignore"):
+                    Ls = np.where((y > max_sample_luminance)[:, None] & ~bad[:, None], Ls * (max_sample_luminance / y)[:, None], Ls)
+            if not wide:
+                part += Ls
+            else:  # 3.11: every pixel within the radius of the film point gets the sample, as 2^-24 fixed point
+                q = (np.minimum(np.maximum(Ls, 0.0), 32768.0).astype(np.float32).astype(np.float64) * 16777216.0).astype(np.int64)
+                dx, dy = fx - 0.5, fy - 0.5
+                x0, x1 = np.maximum(np.ceil(dx - rx).astype(np.int64), 0), np.minimum(np.floor(dx + rx).astype(np.int64), W - 1)
+                y0, y1 = np.maximum(np.ceil(dy - ry).astype(np.int64), 0), np.minimum(np.floor(dy + ry).astype(np.int64), H - 1)
+                for oy in range(2 * pad_y + 2):
+                    for ox in range(2 * pad_x + 2):
+                        xx, yy = x0 + ox, y0 + oy
+                        ok = (xx <= x1) & (yy <= y1)
+                        np.add.at(acc, (yy[ok], xx[ok]), np.concatenate([q[ok], np.ones((int(ok.sum()), 1), np.int64)], 1))
         film += part
     M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    if wide:
+        return np.concatenate([(acc[..., :3].astype(np.float64) / 16777216.0) @ M.T, acc[..., 3:4].astype(np.float64)], -1)
     out = np.concatenate([film @ M.T, np.full((n_px, 1), float(n_spp))], 1)
     return out.reshape(H, W, 4)
 

@@ -191,8 +191,9 @@ def test_hip_image_equals_an_independent_float64_implementation_of_the_spec(gpu)
     import independent_twin as tw
     from test_oracle_selfcheck import _twin_cases
     cases = _twin_cases() + [("C4's scene at 96 x 96, 36 spp, depth 16", scenes.cornell_scene(96, 96), dict(integrator=INTEGRATOR_PATH, max_depth=16, spp=(6, 6), seed=0))]
+    from test_oracle_selfcheck import _twin_kw
     for name, sd, kw in cases:
-        twin = tw.render(sd, **kw)
+        twin = tw.render(sd, **_twin_kw(kw))
         with gpu.Scene(sd) as sc:
             film, _ = sc.render(**kw)
         rel = np.abs(twin[..., :3] - film[..., :3]) / np.maximum(np.abs(film[..., :3]), 1e-3 * film[..., :3].max())

@@ -708,11 +708,24 @@ def _twin_cases():
             ("C4's scene, the padded (0,2)-sequence (3.10), depth 16, 6 spp", scenes.cornell_scene(32, 32), dict(integrator=INTEGRATOR_PATH, max_depth=16, spp=(3, 2), seed=1, sampler="sobol")),
             ("C4's scene, Halton, 64 spp", scenes.cornell_scene(16, 16), dict(integrator=INTEGRATOR_PATH, max_depth=4, spp=(8, 8), seed=2, sampler="halton")),
             ("slivers lying flat in axis planes under a sky (the own-box rule's hardest case: no holes)", __import__("util").flat_sliver_scene(96, 96)[0], dict(integrator=INTEGRATOR_PATH, max_depth=3, spp=(4, 4), seed=2)),
+            ("C4's scene under a 1.5 x 1.0 box filter (3.11: the fixed-point film; integer weights compared exactly)", scenes.cornell_scene(32, 32), dict(integrator=INTEGRATOR_PATH, max_depth=4, spp=(3, 3), seed=3, filter_width=(1.5, 1.0))),
+            ("C4's scene, a 2.5-pixel box filter, Halton, MIS", scenes.cornell_scene(24, 24), dict(integrator=2, max_depth=4, spp=(2, 2), seed=1, filter_width=(2.5, 2.5), sampler="halton")),
+            ("C4's scene, maxsampleluminance 0.5", scenes.cornell_scene(32, 32), dict(integrator=INTEGRATOR_PATH, max_depth=4, spp=(3, 3), seed=3, max_sample_luminance=0.5)),
+            ("C4's scene, the Sobol' sampler proper (3.12)", scenes.cornell_scene(32, 32), dict(integrator=INTEGRATOR_PATH, max_depth=8, spp=(4, 4), seed=3, sampler="sobol_nd")),
             ("C1's scene: a sphere under a point light, direct lighting", scenes.sphere_scene(48, 48), dict(integrator=INTEGRATOR_DIRECT, max_depth=5, spp=(4, 4), seed=0)),
             ("300 triangles + two spheres, all four kinds of light, MIS", both, dict(integrator=2, max_depth=8, spp=(3, 2), seed=5)),
             ("C4's scene, 64 spp in two chunks", scenes.cornell_scene(24, 24), dict(integrator=INTEGRATOR_PATH, max_depth=3, spp=(8, 8), seed=1)),
             ("300 triangles, mirrors, all four kinds of light", mesh, dict(integrator=INTEGRATOR_PATH, max_depth=8, spp=(3, 2), seed=5)),
             ("the same, direct lighting", mesh, dict(integrator=INTEGRATOR_DIRECT, max_depth=5, spp=(2, 2), seed=2))]
+
+
+def _twin_kw(kw):
+    """the twin's arguments for a case: the Sobol' sampler's generator matrices are a table (checked entry for entry against the reference's
+    SOBOL_MATRICES32 in tests/test_host.py), handed in"""
+    if kw.get("sampler") == "sobol_nd":
+        from pbrt_amd.api import sobol_matrices
+        return dict(kw, sobol_matrices=sobol_matrices())
+    return kw
 
 
 def _c0_against_the_twin(render):
@@ -736,7 +749,8 @@ def test_oracle_image_equals_an_independent_float64_implementation_of_the_spec(o
     """north_star's "PSNR >= 50 dB vs the reference image", against a reference that is not the twin: tests/independent_twin.py is a SECOND
     implementation of DESIGN.md section 3 -- float64 numpy written from the spec's text, every ray against every triangle, the textbook's
     Moeller-Trumbore, the sphere's quadratic in float64 throughout, numpy's own sin / cos, no BVH, no own-box rule -- that shares the RANDOM NUMBERS (the PCG32 streams of 3.1, drawn in the
-    spec's order; the integer arithmetic of the padded (0,2)-sequence of 3.10 and of the Halton sampler of 3.13, restated) and no code.  Sample s of
+    spec's order; the integer arithmetic of the padded (0,2)-sequence of 3.10, the Sobol' sampler of 3.12 and the Halton sampler of 3.13, restated;
+    the fixed-point film of 3.11 and the luminance clamp) and no code.  Sample s of
     pixel (x, y) then walks the same path up to rounding, so the images compare directly: PSNR >= 90 dB (measured 105 ... 148) and 99 % of the pixels (measured: 99.5 ... 100 %) equal to 1e-4 in every channel, for integrators 0, 1 and 2
     (MIS), triangles and spheres -- where a wrong pdf, cosine, n_lights factor, draw
     order, depth rule or roulette weight would move every pixel; and BASELINE C0 exactly as it is stated (the scene file through the parser: checkerboard,
@@ -744,7 +758,7 @@ def test_oracle_image_equals_an_independent_float64_implementation_of_the_spec(o
     tests/test_gpu_parity.py."""
     import independent_twin as tw
     for name, sd, kw in _twin_cases():
-        twin = tw.render(sd, **kw)
+        twin = tw.render(sd, **_twin_kw(kw))
         film, _ = oracle.OracleScene(sd).render(**kw)
         rel = np.abs(twin[..., :3] - film[..., :3]) / np.maximum(np.abs(film[..., :3]), 1e-3 * film[..., :3].max())
         assert tw.psnr_db(twin, film) >= 90.0 and (rel.max(-1) < 1e-4).mean() >= 0.99, (name, tw.psnr_db(twin, film), (rel.max(-1) < 1e-4).mean())
