@@ -7,7 +7,7 @@ What it is for: north_star's "PSNR >= 50 dB vs the reference image".  The oracle
 restatements of ONE spec by one author agree; tests/independent_mc.py agrees with them statistically.  This file sits between the two: because
 sample s of pixel (x, y) draws the same numbers here, its path is the same path up to rounding, and the IMAGES can be compared directly --
 a wrong term (a pdf, a cosine, the n_lights factor, the order of the draws, the depth rule, the roulette weight) would show in every pixel.
-What differs legitimately: float64 against fp32 arithmetic (1e-6 relative), and a handful of paths per image whose discrete decisions (which
+Every sampler, integrator and film path of the spec has its second implementation here.  What differs legitimately: float64 against fp32 arithmetic (1e-6 relative), and a handful of paths per image whose discrete decisions (which
 triangle at an edge, roulette at the threshold, the picked light) fall the other way.
 
 Supported: triangles and spheres (matte / mirror; emissive triangles = area lights), point / distant / constant-infinite lights, integrators 0
