@@ -253,8 +253,10 @@ def _cosine_about(n, u1, u2):
     return v2 * dx[:, None] + v3 * dy[:, None] + n * z[:, None], z
 
 
-def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratified", filter_width=None, max_sample_luminance=0.0, sobol_matrices=None):
-    """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image, no crop window)"""
+def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratified", filter_width=None, max_sample_luminance=0.0, sobol_matrices=None,
+           window=None):
+    """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image; `window` = (x0, y0, w, h): those pixels of it only -- the
+    default filter: a pixel's samples land in it alone --, which is how a scene of a million triangles is affordable by brute force)"""
     sd = sd.normalized()
     sampler = {0: "stratified", 1: "sobol", 2: "sobol_nd", 3: "halton"}.get(sampler, sampler)  # (the C ABI's numbers: what a loaded scene file carries)
     assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2) and sampler in ("stratified", "sobol", "sobol_nd", "halton")
@@ -313,6 +315,9 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
     # the SAMPLED pixels (3.11): the image plus a halo of pad pixels for a box filter wider than 0.5; their streams are numbered in the
     # haloed image W' x H'
     py, px = np.mgrid[-pad_y:H + pad_y, -pad_x:W + pad_x]
+    if window is not None:
+        assert not wide
+        py, px = np.mgrid[window[1]:window[1] + window[3], window[0]:window[0] + window[2]]
     px, py = px.ravel(), py.ravel()
     n_px = len(px)
     Wn, Hn = W + 2 * pad_x, H + 2 * pad_y
@@ -525,7 +530,7 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
     if wide:
         return np.concatenate([(acc[..., :3].astype(np.float64) / 16777216.0) @ M.T, acc[..., 3:4].astype(np.float64)], -1)
     out = np.concatenate([film @ M.T, np.full((n_px, 1), float(n_spp))], 1)
-    return out.reshape(H, W, 4)
+    return out.reshape((H, W, 4) if window is None else (window[3], window[2], 4))
 
 
 def psnr_db(film_a, film_b):
