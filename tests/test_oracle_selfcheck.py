@@ -614,7 +614,7 @@ def test_every_walk_reaches_what_the_own_box_rule_accepts(oracle, name):
     that Triangle::Intersect accepts at distance t -- the triangle an adversarial ray aims at, and the winner of the brute force --, every
     node test on the way from the root of a product builder's QUANTISED tree to that triangle's leaf slot passes with tfar = t, in the
     production step's own arithmetic (fma on 8-bit planes, the 3 eps margins, the stand-in for 1 / 0: oracle/quad_walk.cpp).  So no walk whose
-    best hit is still >= t can be turned away from the triangle, whichever tree it walks: kOwnPad = 1 + 2^-17 sits inside kBoxPad = 1 + 2^-16
+    best hit is still >= t can be turned away from the triangle, whichever tree it walks: kOwnPad = 1 + 2^-21 sits inside kBoxPad = 1 + 2^-19
     with room for the quantised walk's roundings.  With the rule off the same check finds the pairs that trees disagreed on."""
     from pbrt_amd.api import quad_build_host_ex
     from util import adversarial_rays, random_rays
