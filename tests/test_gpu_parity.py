@@ -1601,7 +1601,10 @@ def test_optimized_tree_scene_matches_oracle(gpu, oracle):
     assert walk["host-optimized"] < walk["host"], walk
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PBRT_SOAK_SEEDS", "48"))))
+_SOAK_FIRST = int(os.environ.get("PBRT_SOAK_FIRST", "0"))  # (tools/soak.sh N FIRST: seeds FIRST ... FIRST + N - 1, scenes no earlier soak drew)
+
+
+@pytest.mark.parametrize("seed", range(_SOAK_FIRST, _SOAK_FIRST + int(os.environ.get("PBRT_SOAK_SEEDS", "48"))))
 def test_random_scenes_match_oracle(gpu, oracle, monkeypatch, seed):
     """Triangle counts 0..300 (with duplicates and degenerate triangles), random materials (mirrors, emitters),
     0-3 lights of every kind, 0-2 spheres, random camera / resolution / crop / strata / depth / integrator /
