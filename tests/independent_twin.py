@@ -259,7 +259,15 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
     default filter: a pixel's samples land in it alone --, which is how a scene of a million triangles is affordable by brute force)"""
     sd = sd.normalized()
     sampler = {0: "stratified", 1: "sobol", 2: "sobol_nd", 3: "halton"}.get(sampler, sampler)  # (the C ABI's numbers: what a loaded scene file carries)
-    assert tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and integrator in (0, 1, 2) and sampler in ("stratified", "sobol", "sobol_nd", "halton")
+    assert integrator in (0, 1, 2) and sampler in ("stratified", "sobol", "sobol_nd", "halton")
+    if tuple(sd.crop) != (0.0, 1.0, 0.0, 1.0):  # a crop window (Film::new, film.rs:82-137: ceil(resolution x crop) in float): those pixels of the whole image, streams numbered in it
+        assert window is None and not filter_width
+        f32 = np.float32
+        bx0, bx1 = (int(np.ceil(f32(sd.xres) * f32(c))) for c in sd.crop[:2])
+        by0, by1 = (int(np.ceil(f32(sd.yres) * f32(c))) for c in sd.crop[2:])
+        import dataclasses
+        return render(dataclasses.replace(sd, crop=(0.0, 1.0, 0.0, 1.0)), integrator, max_depth, spp, seed, sampler, None, max_sample_luminance,
+                      sobol_matrices, window=(bx0, by0, bx1 - bx0, by1 - by0))
     assert sampler != "sobol_nd" or sobol_matrices is not None  # (3.12's generator matrices are a table: the caller hands them over)
     rx, ry = (float(v) if float(v) != 0.0 else 0.5 for v in (filter_width or (0.5, 0.5)))
     wide = (rx, ry) != (0.5, 0.5)
@@ -278,6 +286,8 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
     e1, e2 = p1 - p0, p2 - p0
     mats = sd.materials.astype(np.float64)
     mat_of = np.concatenate([sd.mat_id.astype(np.int64), sph[:, 4].astype(np.int64)])  # by primitive number: triangles, then spheres
+    if len(mat_of) == 0:
+        mat_of = np.zeros(1, np.int64)  # (a scene of lights alone: nothing is ever hit)
     tri_area_all = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1) if T else np.zeros(0)
     textures = sd.textures.astype(np.float64)
     n_tex = len(textures)

@@ -210,6 +210,29 @@ def test_hip_image_equals_an_independent_float64_implementation_of_the_spec(gpu)
         assert tw.psnr_db(twin, film) >= 60.0 and (rel.max(-1) < 1e-4).mean() >= 0.9999, (sampler, tw.psnr_db(twin, film), (rel.max(-1) < 1e-4).mean())
 
 
+def test_hip_equals_the_independent_implementation_on_random_scenes(gpu):
+    """tests/test_oracle_selfcheck.py's comparison on the soak's random scenes (util.random_twin_case, seeds 0 ... 119: every kind of light,
+    emissive triangles, mirrors, spheres, crop windows, three samplers, three integrators), the HIP film against the float64 twin -- no oracle
+    in between: 99 % of each film's pixels equal to 1e-4 relative, the weights exactly, at most 3 % of the films below 90 dB (one grazing sample)."""
+    import independent_twin as tw
+    from util import meets_pixel_bar, random_twin_case, twin_agreement
+    done, below_90 = 0, []
+    with np.errstate(all="ignore"):
+        for seed in range(120):
+            case = random_twin_case(seed)
+            if case is None:
+                continue
+            sd, kw = case
+            with gpu.Scene(sd, builder="gpu" if seed % 2 else "host") as sc:
+                film, _ = sc.render(**kw)
+            ps, frac, wsame = twin_agreement(tw.render(sd, **kw), film)
+            assert meets_pixel_bar(frac, film) and wsame, (seed, ps, frac, wsame, kw)
+            done += 1
+            if ps < 90.0:
+                below_90.append((seed, ps))
+    assert done >= 80 and len(below_90) <= 0.03 * done, (done, below_90)
+
+
 def test_intersect_edge_cases(gpu, oracle):
     sd = SMALL_SCENES["mesh1k"]()
     with gpu.Scene(sd) as sc:
@@ -1529,51 +1552,7 @@ def test_gpu_built_scene_equals_host_built_scene_c2(gpu):
 
 # ---- randomised scenes: everything the path takes as input, drawn at random ----
 
-def _random_scene(seed):
-    from pbrt_amd.scenes import MATTE, MIRROR, _camera, _mat
-    rng = np.random.default_rng(1000 + seed)
-    # (seeds of the soak run -- PBRT_SOAK_SEEDS > 48, tools/soak.sh -- also draw trees deep enough for every stack variant)
-    n_tris = int(rng.choice([0, 1, 2, 5, 17, 64, 300] if seed < 48 else [0, 1, 2, 5, 17, 64, 300, 2500, 20000]))
-    c = rng.uniform(-1, 1, (n_tris, 1, 3))
-    P = (c + rng.uniform(-0.4, 0.4, (n_tris, 3, 3))).reshape(-1, 3).astype(np.float32)
-    if n_tris >= 5 and seed % 3 == 0:  # some exact duplicates and a degenerate triangle: the tie rule and |det| < 1e-8
-        P[3:6] = P[0:3]
-        P[6:9] = P[6]
-    idx = np.arange(3 * n_tris, dtype=np.uint32).reshape(-1, 3)
-    n_mats = int(rng.integers(1, 6))
-    mats = []
-    for m in range(n_mats):
-        kind = MIRROR if rng.random() < 0.3 else MATTE
-        le = tuple(rng.uniform(0.5, 8.0, 3)) if (kind == MATTE and rng.random() < 0.3) else (0, 0, 0)
-        mats.append(_mat(kind, tuple(rng.uniform(0.1, 0.95, 3)), le))
-    mat_id = rng.integers(0, n_mats, n_tris).astype(np.uint16)
-    lights = []
-    for _ in range(int(rng.integers(0, 4))):
-        kind = int(rng.integers(0, 3))
-        if kind == LIGHT_INFINITE:
-            lights.append([kind, 0, 0, 0, *rng.uniform(0.1, 1.0, 3)])
-        elif kind == 1:
-            d = rng.normal(size=3); d /= np.linalg.norm(d)
-            if seed % 6 == 5:  # a sun exactly along an axis: every shadow ray towards it is parallel to two slabs
-                k = int(np.argmax(np.abs(d)))
-                d = np.where(np.arange(3) == k, np.sign(d[k]), 0.0)
-            lights.append([kind, *d, *rng.uniform(0.5, 3.0, 3)])
-        else:
-            lights.append([kind, *rng.uniform(-3, 3, 3), *rng.uniform(2.0, 30.0, 3)])
-    spheres = [[*rng.uniform(-1, 1, 3), rng.uniform(0.1, 0.7), int(rng.integers(0, n_mats))] for _ in range(int(rng.integers(0, 3)))]
-    if seed >= 48 and seed % 7 == 3:   # (soak seeds, round 6) a cloud of small spheres: primitives of the tree like the triangles
-        spheres += [[*rng.uniform(-1, 1, 3), rng.uniform(0.02, 0.2), int(rng.integers(0, n_mats))] for _ in range(int(rng.integers(40, 200)))]
-    if seed >= 48 and seed % 11 == 7 and n_tris > 0:  # ... and a point light exactly ON a mesh vertex: the own-box rule's rays
-        lights.append([0, *P[int(rng.integers(0, len(P)))], *rng.uniform(2.0, 30.0, 3)])
-    eye = rng.uniform(-3.5, 3.5, 3)
-    if np.linalg.norm(eye) < 1.5:
-        eye = eye / max(np.linalg.norm(eye), 1e-3) * 2.5
-    xres, yres = int(rng.integers(5, 90)), int(rng.integers(5, 80))
-    crop = (0.0, 1.0, 0.0, 1.0) if seed % 4 else (0.1, 0.83, 0.25, 0.9)
-    return SceneData(P=P, idx=idx, mat_id=mat_id, materials=np.array(mats, np.float32),
-                     lights=np.array(lights, np.float32).reshape(-1, 7), spheres=np.array(spheres, np.float32).reshape(-1, 5),
-                     cam_to_world=_camera(tuple(eye), tuple(rng.uniform(-0.3, 0.3, 3)), (0, 0, 1)), fov=float(rng.uniform(25, 100)),
-                     xres=xres, yres=yres, crop=crop).normalized(), rng
+from util import random_scene as _random_scene  # noqa: E402  (the soak's scene generator: also the CPU soaks' and the twin's, tests/util.py)
 
 
 def test_optimized_tree_scene_matches_oracle(gpu, oracle):

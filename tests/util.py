@@ -501,3 +501,79 @@ def check_checker_sphere(rgb, su=8.0, sv=4.0, sub=4):
     on_sphere = pad(blk(hit).all((1, 3)))
     assert (rgb[on_sphere] >= c1 - 3e-6).all() and (rgb[on_sphere] <= c2 + 3e-6).all()  # a border pixel mixes the two
     return one_cell.mean()
+
+
+def random_scene(seed):
+    """the randomised parity test's scene number `seed` (tests/test_gpu_parity.py: test_random_scenes_match_oracle; tools/soak.sh) and the
+    generator it goes on drawing render arguments from"""
+    from pbrt_amd import LIGHT_INFINITE
+    from pbrt_amd.scenes import SceneData
+    from pbrt_amd.scenes import MATTE, MIRROR, _camera, _mat
+    rng = np.random.default_rng(1000 + seed)
+    # (seeds of the soak run -- PBRT_SOAK_SEEDS > 48, tools/soak.sh -- also draw trees deep enough for every stack variant)
+    n_tris = int(rng.choice([0, 1, 2, 5, 17, 64, 300] if seed < 48 else [0, 1, 2, 5, 17, 64, 300, 2500, 20000]))
+    c = rng.uniform(-1, 1, (n_tris, 1, 3))
+    P = (c + rng.uniform(-0.4, 0.4, (n_tris, 3, 3))).reshape(-1, 3).astype(np.float32)
+    if n_tris >= 5 and seed % 3 == 0:  # some exact duplicates and a degenerate triangle: the tie rule and |det| < 1e-8
+        P[3:6] = P[0:3]
+        P[6:9] = P[6]
+    idx = np.arange(3 * n_tris, dtype=np.uint32).reshape(-1, 3)
+    n_mats = int(rng.integers(1, 6))
+    mats = []
+    for m in range(n_mats):
+        kind = MIRROR if rng.random() < 0.3 else MATTE
+        le = tuple(rng.uniform(0.5, 8.0, 3)) if (kind == MATTE and rng.random() < 0.3) else (0, 0, 0)
+        mats.append(_mat(kind, tuple(rng.uniform(0.1, 0.95, 3)), le))
+    mat_id = rng.integers(0, n_mats, n_tris).astype(np.uint16)
+    lights = []
+    for _ in range(int(rng.integers(0, 4))):
+        kind = int(rng.integers(0, 3))
+        if kind == LIGHT_INFINITE:
+            lights.append([kind, 0, 0, 0, *rng.uniform(0.1, 1.0, 3)])
+        elif kind == 1:
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            if seed % 6 == 5:  # a sun exactly along an axis: every shadow ray towards it is parallel to two slabs (DESIGN.md 3.4)
+                k = int(np.argmax(np.abs(d)))
+                d = np.where(np.arange(3) == k, np.sign(d[k]), 0.0)
+            lights.append([kind, *d, *rng.uniform(0.5, 3.0, 3)])
+        else:
+            lights.append([kind, *rng.uniform(-3, 3, 3), *rng.uniform(2.0, 30.0, 3)])
+    spheres = [[*rng.uniform(-1, 1, 3), rng.uniform(0.1, 0.7), int(rng.integers(0, n_mats))] for _ in range(int(rng.integers(0, 3)))]
+    if seed >= 48 and seed % 7 == 3:   # (soak seeds, round 6) a cloud of small spheres: primitives of the tree like the triangles
+        spheres += [[*rng.uniform(-1, 1, 3), rng.uniform(0.02, 0.2), int(rng.integers(0, n_mats))] for _ in range(int(rng.integers(40, 200)))]
+    if seed >= 48 and seed % 11 == 7 and n_tris > 0:  # ... and a point light exactly ON a mesh vertex: the own-box rule's rays (DESIGN.md 3.5)
+        lights.append([0, *P[int(rng.integers(0, len(P)))], *rng.uniform(2.0, 30.0, 3)])
+    eye = rng.uniform(-3.5, 3.5, 3)
+    if np.linalg.norm(eye) < 1.5:
+        eye = eye / max(np.linalg.norm(eye), 1e-3) * 2.5
+    xres, yres = int(rng.integers(5, 90)), int(rng.integers(5, 80))
+    crop = (0.0, 1.0, 0.0, 1.0) if seed % 4 else (0.1, 0.83, 0.25, 0.9)
+    return SceneData(P=P, idx=idx, mat_id=mat_id, materials=np.array(mats, np.float32),
+                     lights=np.array(lights, np.float32).reshape(-1, 7), spheres=np.array(spheres, np.float32).reshape(-1, 5),
+                     cam_to_world=_camera(tuple(eye), tuple(rng.uniform(-0.3, 0.3, 3)), (0, 0, 1)), fov=float(rng.uniform(25, 100)),
+                     xres=xres, yres=yres, crop=crop).normalized(), rng
+
+
+def random_twin_case(seed):
+    """(scene, render arguments) number `seed` for the comparisons with tests/independent_twin.py: a random scene of the soak (at most 300
+    triangles and a few spheres: the twin tests every ray against every primitive) under integrator seed % 3, sampler (seed // 3) % 3 --
+    stratified, the padded (0,2)-sequence, Halton -- and random depth, strata and seed; None where the soak drew a scene too big for that"""
+    sd, rng = random_scene(seed)
+    if sd.idx.shape[0] > 300 or sd.spheres.shape[0] > 4:
+        return None
+    depth, spp, rseed = int(rng.integers(0, 12)), (int(rng.integers(1, 4)), int(rng.integers(1, 4))), int(rng.integers(0, 1 << 20))
+    return sd, dict(integrator=(0, 1, 2)[seed % 3], max_depth=depth, spp=spp, seed=rseed, sampler=("stratified", "sobol", "halton")[(seed // 3) % 3])
+
+
+def twin_agreement(twin, film):
+    """(PSNR in dB, share of the pixels equal to 1e-4 relative in every channel, weights equal) of a film against the twin's"""
+    import independent_twin as tw
+    rel = np.abs(twin[..., :3] - film[..., :3]) / np.maximum(np.abs(film[..., :3]), 1e-3 * max(float(film[..., :3].max()), 1e-30))
+    return tw.psnr_db(twin, film), float((rel.max(-1) < 1e-4).mean()), bool(np.array_equal(twin[..., 3], film[..., 3]))
+
+
+def meets_pixel_bar(frac, film):
+    """99 % of the pixels equal -- or all but one, for a film of fewer than a hundred pixels"""
+    n = film.shape[0] * film.shape[1]
+    return frac >= min(0.99, 1.0 - 1.0 / n) - 1e-12
+

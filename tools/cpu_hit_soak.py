@@ -16,8 +16,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import binding as oracle  # noqa: E402
 from pbrt_amd.api import quad_build_host_ex  # noqa: E402
-from test_gpu_parity import _random_scene  # noqa: E402
-from util import adversarial_rays, random_rays  # noqa: E402
+from util import random_scene as _random_scene  # noqa: E402
+from util import adversarial_rays, random_rays  # noqa: E402,F811
 
 
 def main():
