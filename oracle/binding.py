@@ -374,8 +374,8 @@ class OracleScene:
         r.max_sample_luminance = max_sample_luminance
         return r
 
-    def pixel_samples(self, x, y, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler=0):
-        r = self._rd(integrator, max_depth, spp, seed, 0, 1, sampler)
+    def pixel_samples(self, x, y, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler=0, filter_width=None, max_sample_luminance=0.0):
+        r = self._rd(integrator, max_depth, spp, seed, 0, 1, sampler, filter_width, max_sample_luminance)
         out = np.zeros((spp[0] * spp[1], 3), np.float32)
         self.l.orc_pixel_samples(self.h, C.byref(r), x, y, _p(out)); return out
 

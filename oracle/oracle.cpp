@@ -615,10 +615,11 @@ static inline void film_from_acc(const int64_t a[4], float out_xyzw[4]) {
 
 static void render_pixel(const Scene &s, const PathIntegrator &integ, const orc_render_desc &r, int x, int y,
                          float out_xyzw[4], float *per_sample, RayStats &st) {
-  StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s);
-  SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s);
-  SobolNdSampler sobol_nd(r.spp_x, r.spp_y, r.seed, s);
-  HaltonSampler halton(r.spp_x, r.spp_y, r.seed, s);
+  const WideFilter f = wide_filter(s, r);  // (pads 0 for the default filter; orc_pixel_samples under a wide filter numbers its streams as render_pixel_wide does)
+  StratifiedSampler strat(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
+  SobolSampler sobol(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
+  SobolNdSampler sobol_nd(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
+  HaltonSampler halton(r.spp_x, r.spp_y, r.seed, s, f.pad_x, f.pad_y);
   Sampler &sampler = r.sampler == 3 ? (Sampler &)halton : (r.sampler == 2 ? (Sampler &)sobol_nd : (r.sampler == 1 ? (Sampler &)sobol : (Sampler &)strat));
   Vec3 sum = {0, 0, 0};
   uint32_t i = 0;

@@ -254,7 +254,7 @@ def _cosine_about(n, u1, u2):
 
 
 def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratified", filter_width=None, max_sample_luminance=0.0, sobol_matrices=None,
-           window=None):
+           window=None, trace=None):
     """-> film [h, w, 4] float64 {X, Y, Z, weight} of SceneData `sd` (whole image; `window` = (x0, y0, w, h): those pixels of it only -- the
     default filter: a pixel's samples land in it alone --, which is how a scene of a million triangles is affordable by brute force)"""
     sd = sd.normalized()
@@ -523,13 +523,18 @@ def render(sd, integrator=0, max_depth=5, spp=(1, 1), seed=0, sampler="stratifie
             if max_sample_luminance > 0:  # Film "maxsampleluminance" (3.9)
                 with np.errstate(all="ignore"):
                     Ls = np.where((y > max_sample_luminance)[:, None] & ~bad[:, None], Ls * (max_sample_luminance / y)[:, None], Ls)
+            if trace is not None:  # (debugging: every sample's film point and radiance)
+                trace.append((s, px.copy(), py.copy(), fx.copy(), fy.copy(), Ls.copy()))
             if not wide:
                 part += Ls
             else:  # 3.11: every pixel within the radius of the film point gets the sample, as 2^-24 fixed point
                 q = (np.minimum(np.maximum(Ls, 0.0), 32768.0).astype(np.float32).astype(np.float64) * 16777216.0).astype(np.int64)
-                dx, dy = fx - 0.5, fy - 0.5
-                x0, x1 = np.maximum(np.ceil(dx - rx).astype(np.int64), 0), np.minimum(np.floor(dx + rx).astype(np.int64), W - 1)
-                y0, y1 = np.maximum(np.ceil(dy - ry).astype(np.int64), 0), np.minimum(np.floor(dy + ry).astype(np.int64), H - 1)
+                # (d - r and d + r are float32 sums, as 3.11 has them since the random-scene soak: a film point one ulp below 32 under r = 2.5
+                # rounds d + r up to 34 and the footprint reaches pixel 34 -- 2e-6 beyond the radius; the weights are compared EXACTLY)
+                f32 = np.float32
+                dx, dy = fx.astype(f32) - f32(0.5), fy.astype(f32) - f32(0.5)
+                x0, x1 = np.maximum(np.ceil(dx - f32(rx)).astype(np.int64), 0), np.minimum(np.floor(dx + f32(rx)).astype(np.int64), W - 1)
+                y0, y1 = np.maximum(np.ceil(dy - f32(ry)).astype(np.int64), 0), np.minimum(np.floor(dy + f32(ry)).astype(np.int64), H - 1)
                 for oy in range(2 * pad_y + 2):
                     for ox in range(2 * pad_x + 2):
                         xx, yy = x0 + ox, y0 + oy

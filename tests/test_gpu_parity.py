@@ -215,7 +215,7 @@ def test_hip_equals_the_independent_implementation_on_random_scenes(gpu):
     emissive triangles, mirrors, spheres, crop windows, three samplers, three integrators), the HIP film against the float64 twin -- no oracle
     in between: 99 % of each film's pixels equal to 1e-4 relative, the weights exactly, at most 3 % of the films below 90 dB (one grazing sample)."""
     import independent_twin as tw
-    from util import meets_pixel_bar, random_twin_case, twin_agreement
+    from util import meets_pixel_bar, random_twin_case, twin_agreement, twin_render
     done, below_90 = 0, []
     with np.errstate(all="ignore"):
         for seed in range(120):
@@ -225,8 +225,8 @@ def test_hip_equals_the_independent_implementation_on_random_scenes(gpu):
             sd, kw = case
             with gpu.Scene(sd, builder="gpu" if seed % 2 else "host") as sc:
                 film, _ = sc.render(**kw)
-            ps, frac, wsame = twin_agreement(tw.render(sd, **kw), film)
-            assert meets_pixel_bar(frac, film) and wsame, (seed, ps, frac, wsame, kw)
+            ps, frac, wsame = twin_agreement(twin_render(sd, kw), film)
+            assert meets_pixel_bar(frac, film, ps) and wsame, (seed, ps, frac, wsame, kw)
             done += 1
             if ps < 90.0:
                 below_90.append((seed, ps))

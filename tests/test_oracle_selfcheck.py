@@ -782,7 +782,7 @@ def test_oracle_equals_the_independent_implementation_on_random_scenes(oracle):
     below 90 dB -- a film that meets the pixel bar below 90 dB has ONE sample that went another way (a ray grazing a silhouette, decided in
     float32 here and float64 there: seed 106, a mirror sphere's rim).  tools/twin_soak.py runs thousands (profiles/r06s_twin_soak.txt)."""
     import independent_twin as tw
-    from util import meets_pixel_bar, random_twin_case, twin_agreement
+    from util import meets_pixel_bar, random_twin_case, twin_agreement, twin_render
     done, below_90 = 0, []
     with np.errstate(all="ignore"):
         for seed in range(120):
@@ -791,8 +791,8 @@ def test_oracle_equals_the_independent_implementation_on_random_scenes(oracle):
                 continue
             sd, kw = case
             film, _ = oracle.OracleScene(sd).render(**kw)
-            ps, frac, wsame = twin_agreement(tw.render(sd, **kw), film)
-            assert meets_pixel_bar(frac, film) and wsame, (seed, ps, frac, wsame, kw)
+            ps, frac, wsame = twin_agreement(twin_render(sd, kw), film)
+            assert meets_pixel_bar(frac, film, ps) and wsame, (seed, ps, frac, wsame, kw)
             done += 1
             if ps < 90.0:
                 below_90.append((seed, ps))

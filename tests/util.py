@@ -556,13 +556,29 @@ def random_scene(seed):
 
 def random_twin_case(seed):
     """(scene, render arguments) number `seed` for the comparisons with tests/independent_twin.py: a random scene of the soak (at most 300
-    triangles and a few spheres: the twin tests every ray against every primitive) under integrator seed % 3, sampler (seed // 3) % 3 --
-    stratified, the padded (0,2)-sequence, Halton -- and random depth, strata and seed; None where the soak drew a scene too big for that"""
+    triangles and a few spheres: the twin tests every ray against every primitive) under integrator seed % 3, sampler (seed // 3) % 4 --
+    stratified, the padded (0,2)-sequence, Halton, Sobol' -- and random depth, strata and seed, three in ten of the whole images under a wide box
+    filter, a quarter with the luminance clamp; None where the soak drew a scene too big for that"""
     sd, rng = random_scene(seed)
     if sd.idx.shape[0] > 300 or sd.spheres.shape[0] > 4:
         return None
     depth, spp, rseed = int(rng.integers(0, 12)), (int(rng.integers(1, 4)), int(rng.integers(1, 4))), int(rng.integers(0, 1 << 20))
-    return sd, dict(integrator=(0, 1, 2)[seed % 3], max_depth=depth, spp=spp, seed=rseed, sampler=("stratified", "sobol", "halton")[(seed // 3) % 3])
+    kw = dict(integrator=(0, 1, 2)[seed % 3], max_depth=depth, spp=spp, seed=rseed, sampler=("stratified", "sobol", "halton", "sobol_nd")[(seed // 3) % 4])
+    extra = np.random.default_rng(77_000 + seed)   # the film paths of 3.11 on some: a wide box filter (whole images only), the luminance clamp
+    if tuple(sd.crop) == (0.0, 1.0, 0.0, 1.0) and extra.random() < 0.3:
+        kw["filter_width"] = (float(extra.choice([0.5, 1.0, 1.5, 2.5])), float(extra.choice([0.75, 1.0, 2.0])))
+    if extra.random() < 0.25:
+        kw["max_sample_luminance"] = float(extra.choice([0.25, 1.0, 4.0]))
+    return sd, kw
+
+
+def twin_render(sd, kw):
+    """the twin's film for a case (the Sobol' sampler's generator matrices are a table, handed in)"""
+    import independent_twin as tw
+    if kw.get("sampler") == "sobol_nd":
+        from pbrt_amd.api import sobol_matrices
+        return tw.render(sd, **dict(kw, sobol_matrices=sobol_matrices()))
+    return tw.render(sd, **kw)
 
 
 def twin_agreement(twin, film):
@@ -572,8 +588,10 @@ def twin_agreement(twin, film):
     return tw.psnr_db(twin, film), float((rel.max(-1) < 1e-4).mean()), bool(np.array_equal(twin[..., 3], film[..., 3]))
 
 
-def meets_pixel_bar(frac, film):
-    """99 % of the pixels equal -- or all but one, for a film of fewer than a hundred pixels"""
+def meets_pixel_bar(frac, film, psnr=0.0):
+    """99 % of the pixels equal to 1e-4 relative -- or all but one, for a film of fewer than a hundred pixels --, or the whole film equal to
+    120 dB: under a wide filter ONE sample reaches (2 rx + 1)(2 ry + 1) pixels, and a sphere hit at grazing incidence is 1e-3 off in float32
+    (the discriminant cancels: seed 154, two such samples light most of a small film's lit pixels, 0.1 % off each, film equal to 144 dB)"""
     n = film.shape[0] * film.shape[1]
-    return frac >= min(0.99, 1.0 - 1.0 / n) - 1e-12
+    return frac >= min(0.99, 1.0 - 1.0 / n) - 1e-12 or psnr >= 120.0
 
