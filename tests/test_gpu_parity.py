@@ -213,9 +213,10 @@ def test_hip_image_equals_an_independent_float64_implementation_of_the_spec(gpu)
 def test_hip_equals_the_independent_implementation_on_random_scenes(gpu):
     """tests/test_oracle_selfcheck.py's comparison on the soak's random scenes (util.random_twin_case, seeds 0 ... 119: every kind of light,
     emissive triangles, mirrors, spheres, crop windows, three samplers, three integrators), the HIP film against the float64 twin -- no oracle
-    in between: 99 % of each film's pixels equal to 1e-4 relative, the weights exactly, at most 3 % of the films below 90 dB (one grazing sample)."""
+    in between: util.meets_random_scene_bar per film (the weights exactly; all but a sample's footprint or two of the pixels to 1e-4 / 1e-3
+    relative), at most 3 % of the films below 90 dB (one grazing sample)."""
     import independent_twin as tw
-    from util import meets_pixel_bar, random_twin_case, twin_agreement, twin_render
+    from util import meets_random_scene_bar, random_twin_case, twin_render
     done, below_90 = 0, []
     with np.errstate(all="ignore"):
         for seed in range(120):
@@ -225,8 +226,8 @@ def test_hip_equals_the_independent_implementation_on_random_scenes(gpu):
             sd, kw = case
             with gpu.Scene(sd, builder="gpu" if seed % 2 else "host") as sc:
                 film, _ = sc.render(**kw)
-            ps, frac, wsame = twin_agreement(twin_render(sd, kw), film)
-            assert meets_pixel_bar(frac, film, ps) and wsame, (seed, ps, frac, wsame, kw)
+            ok, ps, off = meets_random_scene_bar(twin_render(sd, kw), film, kw)
+            assert ok, (seed, ps, off, kw)
             done += 1
             if ps < 90.0:
                 below_90.append((seed, ps))

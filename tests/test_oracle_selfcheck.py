@@ -778,11 +778,12 @@ def test_oracle_equals_the_independent_implementation_on_random_scenes(oracle):
     """The comparison above on scenes nobody chose: the first 120 seeds of the soak's generator (util.random_twin_case: 0 ... 300 triangles with
     duplicates and degenerate ones, emissive triangles, mirrors, 0 ... 4 spheres, up to four lights of every kind, suns along axes, crop windows,
     5 ... 90 pixels a side) under integrator seed % 3, the stratified / padded (0,2) / Halton sampler, random depth 0 ... 11, strata and seed.
-    The bar per film: 99 % of the pixels equal to 1e-4 relative in every channel, the weights exactly; over the set, at most 3 % of the films
-    below 90 dB -- a film that meets the pixel bar below 90 dB has ONE sample that went another way (a ray grazing a silhouette, decided in
-    float32 here and float64 there: seed 106, a mirror sphere's rim).  tools/twin_soak.py runs thousands (profiles/r06s_twin_soak.txt)."""
+    The Sobol' sampler, a wide box filter and the luminance clamp on some.  The bar per film: util.meets_random_scene_bar (the weights exactly;
+    all but a sample's footprint or two of the pixels to 1e-4 / 1e-3 relative); over the set, at most 3 % of the films below 90 dB -- a film that
+    meets the pixel bar below 90 dB has ONE sample that went another way (a ray grazing a silhouette, decided in float32 here and float64
+    there: seed 106, a mirror sphere's rim).  tools/twin_soak.py runs thousands (profiles/r06s_twin_soak.txt)."""
     import independent_twin as tw
-    from util import meets_pixel_bar, random_twin_case, twin_agreement, twin_render
+    from util import meets_random_scene_bar, random_twin_case, twin_render
     done, below_90 = 0, []
     with np.errstate(all="ignore"):
         for seed in range(120):
@@ -791,8 +792,8 @@ def test_oracle_equals_the_independent_implementation_on_random_scenes(oracle):
                 continue
             sd, kw = case
             film, _ = oracle.OracleScene(sd).render(**kw)
-            ps, frac, wsame = twin_agreement(twin_render(sd, kw), film)
-            assert meets_pixel_bar(frac, film, ps) and wsame, (seed, ps, frac, wsame, kw)
+            ok, ps, off = meets_random_scene_bar(twin_render(sd, kw), film, kw)
+            assert ok, (seed, ps, off, kw)
             done += 1
             if ps < 90.0:
                 below_90.append((seed, ps))

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """The oracle (and with --hip, on a GPU box, the HIP path) against tests/independent_twin.py -- the float64 brute-force restatement of DESIGN.md
 section 3 with the same random numbers -- over the soak's RANDOM scenes instead of the suite's sixteen fixed cases: every kind of light, emissive
-triangles, mirrors, spheres, crop windows, three samplers, three integrators (tests/util.py: random_twin_case).  The bar: 99 % of a film's pixels
-(all but one of a film of fewer than a hundred) equal to 1e-4 relative in every channel, or the film equal to 120 dB, and the weights equal exactly.  A film that meets it below 90 dB is listed too: one sample of one
-pixel that went another way -- a ray grazing a silhouette or an edge decided in float32 here and in float64 there (seed 106: a mirror sphere's
-rim) --, which moves one pixel by a visible amount and no other.
+triangles, mirrors, spheres, crop windows, three samplers, three integrators (tests/util.py: random_twin_case).  The bar per film: tests/util.py's
+meets_random_scene_bar (the weights exactly; all but a sample's footprint or two of the pixels to 1e-4 / 1e-3 relative, or the film to 120 dB).
+A film that meets it below 90 dB is listed too: one sample that went another way -- a ray grazing a silhouette or an edge decided in float32
+here and in float64 there (seed 106: a mirror sphere's rim) --, which moves the pixels it reaches by a visible amount and no other.
 python3 tools/twin_soak.py N [FIRST] [--hip]      (profiles/r06s_twin_soak.txt)"""
 import os
 import sys
@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import independent_twin as tw  # noqa: E402
 from oracle import binding as oracle  # noqa: E402
-from util import meets_pixel_bar, random_twin_case, twin_agreement, twin_render  # noqa: E402
+from util import meets_random_scene_bar, random_twin_case, twin_render  # noqa: E402
 
 
 def main():
@@ -34,16 +34,16 @@ def main():
         sd, kw = case
         film, _ = oracle.OracleScene(sd).render(**kw)
         twin = twin_render(sd, kw)
-        ps, frac, wsame = twin_agreement(twin, film)
+        ok, ps, off = meets_random_scene_bar(twin, film, kw)
         done += 1
         exact += ps == np.inf
         if ps < worst[0]:
             worst = (float(ps), seed)
-        if not meets_pixel_bar(frac, film, ps) or not wsame:
-            low.append((seed, round(float(ps), 1), round(frac, 4), wsame))
-            print("BELOW THE BAR: seed", seed, "PSNR", ps, "pixels equal", frac, "weights equal", wsame, kw, flush=True)
+        if not ok:
+            low.append((seed, round(float(ps), 1), off))
+            print("BELOW THE BAR: seed", seed, "PSNR", ps, "pixels off", off, "of", film.shape[0] * film.shape[1], kw, flush=True)
         elif ps < 90.0:
-            grazing.append((seed, round(float(ps), 1), int(round((1 - frac) * film.shape[0] * film.shape[1]))))
+            grazing.append((seed, round(float(ps), 1), off))
         if hip:
             with pbrt_amd.Scene(sd) as sc:
                 got, _ = sc.render(**kw)
