@@ -558,7 +558,7 @@ def random_twin_case(seed):
     """(scene, render arguments) number `seed` for the comparisons with tests/independent_twin.py: a random scene of the soak (at most 300
     triangles and a few spheres: the twin tests every ray against every primitive) under integrator seed % 3, sampler (seed // 3) % 4 --
     stratified, the padded (0,2)-sequence, Halton, Sobol' -- and random depth, strata and seed, three in ten of the whole images under a wide box
-    filter, a quarter with the luminance clamp; None where the soak drew a scene too big for that"""
+    filter, a quarter with the luminance clamp, a third with checkerboard textures; None where the soak drew a scene too big for that"""
     sd, rng = random_scene(seed)
     if sd.idx.shape[0] > 300 or sd.spheres.shape[0] > 4:
         return None
@@ -569,6 +569,12 @@ def random_twin_case(seed):
         kw["filter_width"] = (float(extra.choice([0.5, 1.0, 1.5, 2.5])), float(extra.choice([0.75, 1.0, 2.0])))
     if extra.random() < 0.25:
         kw["max_sample_luminance"] = float(extra.choice([0.25, 1.0, 4.0]))
+    if extra.random() < 0.35:  # 3.15: random checkerboards as the Kd of some matte materials over random corner (u, v); spheres by their (phi, theta)
+        import dataclasses
+        n_tex = int(extra.integers(1, 4))
+        tex = np.concatenate([np.zeros((n_tex, 1)), extra.uniform(0.05, 0.95, (n_tex, 6)), extra.uniform(-9, 9, (n_tex, 2)), extra.uniform(-2, 2, (n_tex, 2))], 1)
+        mat_tex = np.where((sd.materials[:, 0] == 0) & (extra.random(len(sd.materials)) < 0.7), extra.integers(1, n_tex + 1, len(sd.materials)), 0).astype(np.uint32)
+        sd = dataclasses.replace(sd, textures=tex.astype(np.float32), mat_tex=mat_tex, tri_uv=extra.uniform(-1.5, 2.5, (len(sd.idx), 6)).astype(np.float32)).normalized()
     return sd, kw
 
 
