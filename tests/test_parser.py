@@ -431,7 +431,7 @@ def test_mutated_scene_files_load_or_are_refused_through_the_abi():
     """4 000 mutations of two scene files (tools/parser_fuzz.py: tokens inserted, stretches deleted / duplicated, truncation, numbers turned into
     0 / -1 / 2^32 / 2^24 + 1 / 1e30): each either loads or comes back as PbrtHipError -- an error code and a message through the C ABI; no
     exception of another kind, no crash (1.2 M files: profiles/r06u_parser_fuzz.txt).  A loaded file's arrays are consistent with each other; VALUES are
-    pbrt_hip_scene_create's to refuse (`LookAt 1e30 0 5 ...` loads with a camera matrix of NaNs as it would in the reference: "scene_create: camera
+    pbrt_hip_scene_create's to refuse (a resolution of 0; `LookAt 1e30 0 5 ...` loads with a camera matrix of NaNs as it would in the reference: "scene_create: camera
     matrix is not finite")."""
     import os
     import random
@@ -450,4 +450,3 @@ def test_mutated_scene_files_load_or_are_refused_through_the_abi():
         n = sd.idx.shape[0]
         assert sd.mat_id.shape[0] == n and (n == 0 or int(sd.idx.max()) < sd.P.shape[0]) and sd.tri_uv.shape[0] in (0, n)
         assert (n == 0 or int(sd.mat_id.max()) < sd.materials.shape[0]) and (sd.spheres.shape[0] == 0 or int(sd.spheres[:, 4].max()) < sd.materials.shape[0])
-        assert sd.xres >= 1 and sd.yres >= 1
