@@ -2,7 +2,10 @@
 """Mutated scene files through the parser (pbrt_hip_parse_*: C++ behind the C ABI, no device): insertions of tokens the grammar knows and of
 garbage, deletions, truncations, duplicated stretches, numbers replaced by 0 / -1 / 2^32 / 2^24 + 1 / 1e30 -- every file must either load or
 be refused with PbrtHipError (an error code and a message through the ABI); a crash or an exception of another kind is a finding.
-python3 tools/parser_fuzz.py SEED N      (profiles/r06u_parser_fuzz.txt: 1.2 M files; tests/test_parser.py runs 4 000)"""
+python3 tools/parser_fuzz.py SEED N      (profiles/r06u_parser_fuzz.txt: 1.2 M files; tests/test_parser.py runs 4 000)
+python3 tools/parser_fuzz.py SEED N --hip   on a GPU box: every file that loads goes on to pbrt_hip_scene_create (the device builder) and, when
+its film is at most 65 536 pixels, one sample per pixel at depth 3: created and rendered, or refused with PbrtHipError -- the VALUES are
+scene_create's to check (a resolution of 0, a camera matrix of NaNs from `LookAt 1e30 ...`, vertices at 1e30 ...)."""
 import os
 import random
 import re
@@ -84,7 +87,36 @@ def run(seed, n):
     return ok, err
 
 
+def run_hip(seed, n):
+    import pbrt_amd
+    rnd = random.Random(seed)
+    loaded = created = rendered = refused = 0
+    reasons = {}
+    for _ in range(n):
+        try:
+            sd = loader.load_string(mutate(rnd.choice(texts), rnd)).scene
+        except PbrtHipError:
+            continue
+        loaded += 1
+        try:
+            with pbrt_amd.Scene(sd) as sc:
+                created += 1
+                if sd.xres * sd.yres <= 65536:
+                    sc.render(spp=(1, 1), max_depth=3, seed=1)
+                    rendered += 1
+        except PbrtHipError as e:
+            refused += 1
+            k = str(e).split(":")[1].strip()[:60] if ":" in str(e) else str(e)[:60]
+            reasons[k] = reasons.get(k, 0) + 1
+    return loaded, created, rendered, refused, reasons
+
+
 if __name__ == "__main__":
     t0 = time.time()
+    if "--hip" in sys.argv:
+        loaded, created, rendered, refused, reasons = run_hip(int(sys.argv[1]), int(sys.argv[2]))
+        print(f"{sys.argv[2]} mutated scene files (seed {sys.argv[1]}): {loaded} loaded; of those {created} created on the device ({rendered} rendered), {refused} refused by "
+              f"scene_create / render with PbrtHipError {reasons}; no crash, no hang, no other exception, {time.time() - t0:.0f} s")
+        sys.exit(0)
     ok, err = run(int(sys.argv[1]), int(sys.argv[2]))
     print(f"{sys.argv[2]} mutated scene files (seed {sys.argv[1]}): {ok} loaded, {err} refused with PbrtHipError, no crash, no other exception, {time.time() - t0:.0f} s")
