@@ -4,7 +4,7 @@ garbage, deletions, truncations, duplicated stretches, numbers replaced by 0 / -
 be refused with PbrtHipError (an error code and a message through the ABI); a crash or an exception of another kind is a finding.
 python3 tools/parser_fuzz.py SEED N      (profiles/r06u_parser_fuzz.txt: 1.2 M files; tests/test_parser.py runs 4 000)
 python3 tools/parser_fuzz.py SEED N --hip   on a GPU box: every file that loads goes on to pbrt_hip_scene_create (the device builder) and, when
-its film is at most 65 536 pixels, one sample per pixel at depth 3: created and rendered, or refused with PbrtHipError -- the VALUES are
+its film is at most 262 144 pixels, one sample per pixel at depth 3: created and rendered, or refused with PbrtHipError -- the VALUES are
 scene_create's to check (a resolution of 0, a camera matrix of NaNs from `LookAt 1e30 ...`, vertices at 1e30 ...)."""
 import os
 import random
@@ -101,12 +101,12 @@ def run_hip(seed, n):
         try:
             with pbrt_amd.Scene(sd) as sc:
                 created += 1
-                if sd.xres * sd.yres <= 65536:
+                if sd.xres * sd.yres <= 262144:
                     sc.render(spp=(1, 1), max_depth=3, seed=1)
                     rendered += 1
         except PbrtHipError as e:
             refused += 1
-            k = str(e).split(":")[1].strip()[:60] if ":" in str(e) else str(e)[:60]
+            k = str(e).split(": ", 1)[-1][:70]
             reasons[k] = reasons.get(k, 0) + 1
     return loaded, created, rendered, refused, reasons
 
