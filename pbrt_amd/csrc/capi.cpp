@@ -92,6 +92,9 @@ FilmGeom film_geom(const pbrt_hip_scene_desc &d, const pbrt_hip_render_desc &r) 
     g.sb[3] = (int32_t)std::ceil(((float)g.crop[3] - 0.5f) + g.ry);
     g.pad_x = std::max(0, (int32_t)std::ceil(g.rx - 0.5f));
     g.pad_y = std::max(0, (int32_t)std::ceil(g.ry - 0.5f));
+    // an empty crop window has no sample bounds either: nothing is sampled for a film of no pixels (as the oracle: 0 rays)
+    if (g.crop[2] <= g.crop[0] || g.crop[3] <= g.crop[1])
+      for (int k = 0; k < 4; k++) g.sb[k] = g.crop[k];
   }
   return g;
 }
@@ -1381,7 +1384,8 @@ int pbrt_hip_render(pbrt_hip_scene *s, const pbrt_hip_render_desc *r, float *fil
   if (n_px) HIP_TRY(hipMemsetAsync(s->d_film.p, 0, n_px * 16, s->stream));
   rc = pbrt_hip_render_device(s, r, s->d_slab.p, s->stream);
   if (rc) return rc;
-  if (fg.wide) rc = pbrt_hip_film_from_acc_device(s, s->d_slab.p, s->d_film.p, s->stream);
+  if (!n_px) rc = PBRT_HIP_OK;  // (an empty crop window: nothing was sampled, there is no film to assemble -- an empty film like the oracle's, not an error)
+  else if (fg.wide) rc = pbrt_hip_film_from_acc_device(s, s->d_slab.p, s->d_film.p, s->stream);
   else rc = pbrt_hip_film_assemble_device(s, s->d_slab.p, r->rank, r->world_size, s->d_film.p, s->stream);
   hipError_t e = hipSuccess;
   if (!rc && n_px) e = hipMemcpyAsync(film, s->d_film.p, n_px * 16, hipMemcpyDeviceToHost, s->stream);

@@ -234,6 +234,21 @@ def test_hip_equals_the_independent_implementation_on_random_scenes(gpu):
     assert done >= 80 and len(below_90) <= 0.03 * done, (done, below_90)
 
 
+def test_an_empty_crop_window_is_an_empty_film(gpu, oracle):
+    """A crop window that holds no pixel (ceil(res x c0) == ceil(res x c1): Film::new, film.rs:82-137) is a film of no pixels and no rays, on
+    both sides and under a wide filter too (its halo is not sampled for nothing) -- it came back as "film_assemble: null argument" until the
+    parser fuzz sent three such files through pbrt_hip_render (tools/parser_fuzz.py --hip)."""
+    for crop in ((0.5, 0.5, 0.0, 1.0), (0.2, 0.8, 0.3, 0.3), (0.51, 0.52, 0.0, 1.0)):
+        sd = scenes.cornell_scene(16, 16, crop=crop)
+        for kw in (dict(spp=(2, 1), max_depth=3), dict(spp=(1, 2), max_depth=2, filter_width=(1.5, 2.5)), dict(spp=(1, 1), max_depth=2, sampler="halton", integrator=2)):
+            ref, rst = oracle.OracleScene(sd).render(**kw)
+            with gpu.Scene(sd) as sc:
+                film, st = sc.render(**kw)
+                _, cst = sc.render(counters=True, **kw)
+            assert film.shape == ref.shape and film.size == 0, (crop, film.shape, ref.shape)
+            assert cst["camera_rays"] == rst["camera_rays"] == 0 and st["samples"] == 0, (crop, kw, cst, st)
+
+
 def test_intersect_edge_cases(gpu, oracle):
     sd = SMALL_SCENES["mesh1k"]()
     with gpu.Scene(sd) as sc:
