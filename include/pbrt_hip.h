@@ -204,7 +204,8 @@ int pbrt_hip_scene_info(const pbrt_hip_scene *scene, uint32_t *n_nodes, uint32_t
 /* Render this rank's super-tiles and return the assembled film in HOST memory:
  * film_xyzw = (crop_w * crop_h * 4) floats, row-major over the cropped pixel bounds,
  * {X, Y, Z, filter_weight_sum} per pixel = Film.pixels after merge_film_tile (film.rs:47-55,313-326).
- * Pixels of super-tiles owned by other ranks are written as zeros. */
+ * Pixels of super-tiles owned by other ranks are written as zeros.  A crop window that holds no pixel (crop_w or crop_h
+ * 0) is a film of no floats: nothing is sampled, nothing is written, PBRT_HIP_OK (film_xyzw must still be non-NULL). */
 int pbrt_hip_render(pbrt_hip_scene *scene, const pbrt_hip_render_desc *desc, float *film_xyzw, pbrt_hip_stats *stats);
 /* Allocates (or grows) the device scratch a render of `scene` with this description needs -- the lanes' path-state records, the
  * partial film sums of the work items, the overflow area of the walk's stack, sampler 2's matrices -- without launching anything.
