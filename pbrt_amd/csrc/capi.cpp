@@ -1360,10 +1360,12 @@ int pbrt_hip_render_wait(pbrt_hip_scene *s, pbrt_hip_stats *stats) {
 
 int pbrt_hip_film_assemble_device(const pbrt_hip_scene *s, const void *d_slab, uint32_t rank, uint32_t world,
                                   void *d_film, void *stream) {
-  if (!s || !d_film) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: null argument");
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: null argument");
   if (world == 0 || rank >= world) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: rank must be < world_size");
-  HIP_TRY(hipSetDevice(s->device));
   const Shard sh = make_shard(s->desc.xres, s->desc.yres, s->desc.crop, rank, world);
+  if (sh.w <= 0 || sh.h <= 0) return PBRT_HIP_OK;  // (an empty crop window: a film of no pixels, which a caller may well hold in a NULL buffer)
+  if (!d_film) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: null argument");
+  HIP_TRY(hipSetDevice(s->device));
   if (sh.n_local && !d_slab) return fail(PBRT_HIP_ERR_INVALID, "film_assemble: null slab");
   HIP_TRY(launch_assemble((const float4 *)d_slab, (float4 *)d_film, sh.w, sh.h, rank, world, sh.n_local,
                           (hipStream_t)stream));
@@ -1408,10 +1410,12 @@ int64_t pbrt_hip_render_buffer_bytes(const pbrt_hip_scene *s, const pbrt_hip_ren
 }
 
 int pbrt_hip_film_from_acc_device(const pbrt_hip_scene *s, const void *d_acc, void *d_film, void *stream) {
-  if (!s || !d_film) return fail(PBRT_HIP_ERR_INVALID, "film_from_acc: null argument");
+  if (!s) return fail(PBRT_HIP_ERR_INVALID, "film_from_acc: null argument");
   int32_t b[4];
   film_cropped_bounds(s->desc.xres, s->desc.yres, s->desc.crop, b);
   const size_t n_px = (size_t)std::max(0, b[2] - b[0]) * (size_t)std::max(0, b[3] - b[1]);
+  if (!n_px) return PBRT_HIP_OK;  // (an empty crop window)
+  if (!d_film) return fail(PBRT_HIP_ERR_INVALID, "film_from_acc: null argument");
   if (n_px && !d_acc) return fail(PBRT_HIP_ERR_INVALID, "film_from_acc: null accumulators");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(launch_film_from_acc((const unsigned long long *)d_acc, (float4 *)d_film, n_px, (hipStream_t)stream));

@@ -234,7 +234,7 @@ def test_hip_equals_the_independent_implementation_on_random_scenes(gpu):
     assert done >= 80 and len(below_90) <= 0.03 * done, (done, below_90)
 
 
-def test_an_empty_crop_window_is_an_empty_film(gpu, oracle):
+def test_an_empty_crop_window_is_an_empty_film(gpu, oracle, monkeypatch):
     """A crop window that holds no pixel (ceil(res x c0) == ceil(res x c1): Film::new, film.rs:82-137) is a film of no pixels and no rays, on
     both sides and under a wide filter too (its halo is not sampled for nothing) -- it came back as "film_assemble: null argument" until the
     parser fuzz sent three such files through pbrt_hip_render (tools/parser_fuzz.py --hip)."""
@@ -247,6 +247,16 @@ def test_an_empty_crop_window_is_an_empty_film(gpu, oracle):
                 cst = sc.render(counters=True, **kw)[1] if len(kw) == 2 else None  # (the counting instantiations: default filter, stratified sampler)
             assert film.shape == ref.shape and film.size == 0, (crop, film.shape, ref.shape)
             assert rst["camera_rays"] == 0 and st["samples"] == 0 and (cst is None or cst["camera_rays"] == 0), (crop, kw, cst, st)
+    # ... a rank's share of it, and the in-library multi-GPU path (two ranks looped back onto this device): empty films, no error
+    monkeypatch.setenv("PBRT_HIP_MULTI_LOOPBACK", "1")
+    sd = scenes.cornell_scene(16, 16, crop=(0.5, 0.5, 0.0, 1.0))
+    with gpu.Scene(sd) as sc:
+        for r in range(2):
+            assert sc.render(rank=r, world_size=2, spp=(1, 1))[0].size == 0
+    with gpu.MultiScene(sd, 2) as ms:
+        for kw in (dict(spp=(1, 1)), dict(spp=(1, 1), filter_width=(1.5, 1.5))):
+            film, stats = ms.render(**kw)
+            assert film.size == 0 and sum(st["samples"] for st in stats) == 0
 
 
 def test_intersect_edge_cases(gpu, oracle):
